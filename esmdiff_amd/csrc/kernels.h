@@ -1,0 +1,54 @@
+// kernels.h — internal launch functions of libesmdiff_hip.so (gfx950 only).
+// Every function enqueues on `stream` and returns the hipError_t of the launch.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/esmdiff_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+namespace ed {
+
+// ---- sampler.hip -----------------------------------------------------------------------------
+hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, float mc_t, float mc_s, int final_,
+                            const float* u, int use_philox, uint64_t seed, uint64_t sample_offset, int step,
+                            int B, int L, hipStream_t stream);
+
+// ---- gemm.hip --------------------------------------------------------------------------------
+// out = epilogue(A[M,K] · W[N,K]^T); K % 64 == 0, N % 128 == 0 (weights are padded at load time).
+hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
+                            int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream);
+
+// ---- norm.hip --------------------------------------------------------------------------------
+hipError_t launch_layernorm_bf16(const float* x, const float* w, const float* b, bf16_t* y, int M, int D,
+                                 hipStream_t stream);
+hipError_t launch_layernorm_bf16_in(const bf16_t* x, const float* w, const float* b, bf16_t* y, int M, int D,
+                                    hipStream_t stream);
+// qkv bf16 [M,3D] -> q,k bf16 [B,H,Lp,64] (LayerNorm over D, rotary, q pre-scaled), vt bf16 [B,H,64,Lp]
+hipError_t launch_qk_norm_rope(const bf16_t* qkv, const float* q_ln_w, const float* k_ln_w,
+                               const float* rope_cos, const float* rope_sin, bf16_t* q, bf16_t* k, bf16_t* vt,
+                               int B, int L, int Lp, int H, hipStream_t stream);
+
+// ---- attention.hip ---------------------------------------------------------------------------
+// q,k [B,H,Lp,64], vt [B,H,64,Lp] -> ctx bf16 [B*L, H*64]
+hipError_t launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* ctx, int B, int L,
+                            int Lp, int H, hipStream_t stream);
+
+// ---- embed.hip -------------------------------------------------------------------------------
+// x[b,l,:] = E_seq[seq] + E_struct[struct'] + c + cond   (net.py:445-466)
+hipError_t launch_embed(const int64_t* seq, const int64_t* xtok, const bf16_t* e_seq, const bf16_t* e_struct,
+                        const float* cvec, const float* cond, float* out, int B, int L, int D,
+                        hipStream_t stream);
+// cond = W2 · silu(W1 · t_freq + b1) + b2   (net.py:489-492,519-522), f32
+hipError_t launch_sigma_mlp(const float* t_freq, const float* w1, const float* b1, const float* w2,
+                            const float* b2, float* hidden, float* cond, int F, int D, hipStream_t stream);
+
+// ---- convert.hip (weight preparation at engine create) ---------------------------------------
+hipError_t launch_to_bf16(const void* src, int src_dtype, bf16_t* dst, int64_t n, hipStream_t stream);
+hipError_t launch_to_f32(const void* src, int src_dtype, float* dst, int64_t n, hipStream_t stream);
+// dst rows: blocks of 32: [gate 32t..32t+31 | up 32t..32t+31]; src [2H, K]: gate rows 0..H-1, up rows H..2H-1
+hipError_t launch_interleave_swiglu(const void* src, int src_dtype, bf16_t* dst, int H, int K,
+                                    hipStream_t stream);
+
+}  // namespace ed

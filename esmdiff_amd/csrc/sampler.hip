@@ -1,0 +1,163 @@
+// sampler.hip — fused reverse-diffusion update for one batch of token rows (gfx950).
+//
+// Replaces, in ONE pass over the raw network logits,
+//   logits_parameterization   /root/reference/slm/models/model.py:527-533
+//   q_xs + mask column        /root/reference/slm/models/model.py:602-603
+//   _sample_categorical       /root/reference/slm/models/model.py:24-28
+//   carry-over                /root/reference/slm/models/model.py:606-607
+//   noise-removal argmax      /root/reference/slm/models/model.py:575-579
+// which the reference runs as ~10 elementwise/reduction passes over a (B,L,4101) float tensor.
+//
+// Mapping: one 256-thread workgroup (4 waves) per (b,l) row; the row (4101 floats, 16.4 KB) is read
+// ONCE into registers (17 per thread, coalesced dword loads) and every later stage works from
+// registers.  Rows whose token is already unmasked exit immediately (they keep their id and, with
+// position-indexed noise, consume nothing).  HBM-bound: algorithmic bytes per masked row = 4·V (logits)
+// [+ 4·V explicit uniforms in parity mode].
+//
+// Float-operation order is the canonical one documented in oracle/csrc/sampler_oracle.c; this TU is
+// compiled with -ffp-contract=off so that ed_math.h evaluates identically on host and device.
+#include "ed_math.h"
+#include "kernels.h"
+
+namespace ed {
+
+constexpr int NT = 256;
+constexpr int MASK_ID = ESMDIFF_MASK_ID;
+constexpr int MAX_PER_THREAD = 20;  // supports V <= 5120
+
+__device__ __forceinline__ float wave_halving_sum(float v) {
+  // t[i] = t[i] + t[i+off], off = 32..1; lane 0 ends with the canonical tree value
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_down(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+template <int PER>
+__global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, const float* __restrict__ logits,
+                                                       int ld, int V, float mc_t, float mc_s, int final_,
+                                                       const float* __restrict__ u, int use_philox,
+                                                       uint64_t seed, uint64_t sample_offset, int step, int L) {
+  const int row = blockIdx.x;
+  if (x[row] != MASK_ID) return;  // carry-over: copy_flag * x  (model.py:606-607)
+
+  __shared__ float s_red[8];
+  __shared__ int s_idx[4];
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const float* z = logits + (int64_t)row * ld;
+
+  float zz[PER];
+  float m = -3.402823466e38f;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int v = t + j * NT;
+    float val = -3.402823466e38f;
+    if (v < V) {
+      val = z[v];
+      if (v == MASK_ID) val = val + -1000000.0f;  // logits[:, :, mask] += neg_infinity
+      m = fmaxf(m, val);
+    }
+    zz[j] = val;
+  }
+  m = wave_max(m);
+  if (lane == 0) s_red[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+
+  float acc = 0.0f;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int v = t + j * NT;
+    if (v < V) acc = acc + ed_expf(zz[j] - m);
+  }
+  acc = wave_halving_sum(acc);
+  if (lane == 0) s_red[4 + wave] = acc;
+  __syncthreads();
+  const float s = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+  const float lse = m + ed_logf(s);
+
+  const float d = mc_t - mc_s;
+  const int b = row / L, l = row - b * L;
+  const float* urow = u ? u + (int64_t)row * V : nullptr;
+  float best = -3.402823466e38f;
+  int best_i = 0x7fffffff;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int v = t + j * NT;
+    if (v < V) {
+      const float lp = zz[j] - lse;
+      float val;
+      if (final_) {
+        val = lp;
+      } else {
+        float q = ed_expf(lp) * d;
+        if (v == MASK_ID) q = mc_s;
+        float uu;
+        if (use_philox)
+          uu = ed_philox_uniform(seed, sample_offset + (uint64_t)b, (uint32_t)step, (uint32_t)l, (uint32_t)v);
+        else
+          uu = urow[v];
+        const float g = 1e-10f - ed_logf(uu + 1e-10f);
+        val = q / g;
+      }
+      if (best_i == 0x7fffffff || val > best) {
+        best = val;
+        best_i = v;
+      }
+    }
+  }
+  // argmax with lowest-index tie-break; (max, min index) is order-independent
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ob = __shfl_xor(best, off, 64);
+    const int oi = __shfl_xor(best_i, off, 64);
+    if (ob > best || (ob == best && oi < best_i)) {
+      best = ob;
+      best_i = oi;
+    }
+  }
+  __syncthreads();  // s_red reuse
+  if (lane == 0) {
+    s_red[wave] = best;
+    s_idx[wave] = best_i;
+  }
+  __syncthreads();
+  if (t == 0) {
+    float bb = s_red[0];
+    int bi = s_idx[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+      if (s_red[w] > bb || (s_red[w] == bb && s_idx[w] < bi)) {
+        bb = s_red[w];
+        bi = s_idx[w];
+      }
+    x[row] = (int64_t)bi;
+  }
+}
+
+hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, float mc_t, float mc_s, int final_,
+                            const float* u, int use_philox, uint64_t seed, uint64_t sample_offset, int step,
+                            int B, int L, hipStream_t stream) {
+  const int rows = B * L;
+  if (rows <= 0) return hipSuccess;
+  const int per = (V + NT - 1) / NT;
+  if (per > MAX_PER_THREAD) return hipErrorInvalidValue;
+  dim3 grid(rows), block(NT);
+#define ED_LAUNCH(P)                                                                                       \
+  hipLaunchKernelGGL(ddpm_step_kernel<P>, grid, block, 0, stream, x, logits, ld, V, mc_t, mc_s, final_, u, \
+                     use_philox, seed, sample_offset, step, L)
+  if (per <= 1) ED_LAUNCH(1);
+  else if (per <= 4) ED_LAUNCH(4);
+  else if (per <= 17) ED_LAUNCH(17);
+  else ED_LAUNCH(MAX_PER_THREAD);
+#undef ED_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace ed

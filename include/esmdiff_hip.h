@@ -1,0 +1,171 @@
+/*
+ * esmdiff_hip.h — C ABI of libesmdiff_hip.so, the MI355X (gfx950) engine for the
+ * ESMDiff sampling hot path.
+ *
+ * The reference (lujiarui/esmdiff) has no FFI: its hot path is a chain of Python
+ * call sites.  Each entry point below is what a binding for ONE of those call
+ * sites would bind; the call site it replaces is cited as file:line relative to
+ * the reference tree.  INTEGRATION.md shows the ctypes stubs a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   ownership  every pointer passed in/out is DEVICE memory owned by the caller
+ *              (e.g. a PyTorch-ROCm tensor's data_ptr()) unless marked [host].
+ *              The engine owns only its bf16 weight copies and its workspace,
+ *              both sized at create time for (max_batch, max_len).
+ *   errors     every entry returns int: 0 = ok, <0 = esmdiff_status.  Nothing
+ *              throws across the boundary.  esmdiff_last_error() gives the text.
+ *   threading  one engine per (process, device); not thread-safe.  All work is
+ *              enqueued on the caller's hipStream_t (passed as void*); no entry
+ *              synchronises the stream except where stated.
+ *   dtypes     token ids int64 (the reference's LongTensor), logits float32,
+ *              schedule scalars float32 computed by the HOST exactly as
+ *              model.py:564-567,584-595 does and passed in.
+ */
+#ifndef ESMDIFF_HIP_H
+#define ESMDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESMDIFF_ABI_VERSION 1
+
+/* structure-track vocabulary: esm constants mirrored at model.py:380-381 */
+#define ESMDIFF_VOCAB 4101
+#define ESMDIFF_MASK_ID 4096
+#define ESMDIFF_STRUCT_EOS 4097
+#define ESMDIFF_STRUCT_BOS 4098
+#define ESMDIFF_STRUCT_PAD 4099
+#define ESMDIFF_STRUCT_CHAINBREAK 4100
+
+typedef enum {
+  ESMDIFF_OK = 0,
+  ESMDIFF_E_INVALID = -1,   /* bad argument (the reference: assert / ValueError)   */
+  ESMDIFF_E_MISSING = -2,   /* weight missing from the table (load_state_dict strict) */
+  ESMDIFF_E_SHAPE = -3,     /* weight has the wrong shape / dtype                   */
+  ESMDIFF_E_HIP = -4,       /* HIP runtime error                                    */
+  ESMDIFF_E_CAPACITY = -5,  /* B > max_batch or L > max_len                         */
+  ESMDIFF_E_NODEVICE = -6   /* no gfx950 device                                     */
+} esmdiff_status;
+
+typedef enum { ESMDIFF_F32 = 0, ESMDIFF_BF16 = 1 } esmdiff_dtype;
+
+/* Hyper-parameters of CustomizedESM3 (net.py:322-332) + TimestepEmbedder (net.py:487) +
+ * StructureOutputHeads (net.py:299); values for ESM3-open: 1536 / 24 / 48 / 4096 / 4101 / 256. */
+typedef struct {
+  int32_t d_model;
+  int32_t n_heads;      /* head dim must be 64 */
+  int32_t n_layers;
+  int32_t ffn_hidden;   /* SwiGLU hidden (gate+up is 2x this) */
+  int32_t vocab_out;    /* n_structure_heads: 4101 (ESMDiff) or 4096 (stock ESM3) */
+  int32_t freq_dim;     /* TimestepEmbedder.frequency_embedding_size */
+  int32_t max_batch;
+  int32_t max_len;      /* tokens incl. BOS/EOS */
+  float residue_scale;  /* sqrt(n_layers/36) — esm TransformerStack */
+  int32_t time_conditioning; /* mdlm.yaml:41 */
+} esmdiff_config;
+
+/* One state-dict entry.  `name` uses the reference's key layout for the ESMDiff
+ * checkpoint ('module' dict, checkpoint_utils.py:62-64): "net.transformer.blocks.0.attn.…",
+ * "sigma_embedder.mlp.0.weight", …  `data` is a DEVICE pointer to a contiguous tensor. */
+typedef struct {
+  const char* name;
+  const void* data;
+  int32_t dtype;     /* esmdiff_dtype */
+  int32_t ndim;
+  int64_t shape[4];
+} esmdiff_weight;
+
+/* Counter-based noise source (performance mode).  Uniform for (sample, step, position l,
+ * vocabulary id v) = Philox4x32-10(key = seed, counter = {v>>2, l, sample, step})[v&3] >> 8 · 2^-24,
+ * so results do not depend on batch composition or on how samples are sharded over GPUs. */
+typedef struct {
+  uint64_t seed;
+  uint64_t sample_offset; /* global index of batch row 0 */
+} esmdiff_rng;
+
+typedef struct esmdiff_engine esmdiff_engine;
+
+int esmdiff_abi_version(void);
+
+/* Replaces load_state_dict_from_lightning_ckpt (checkpoint_utils.py:41-74) + hydra instantiate
+ * of mdlm.yaml:26-58: builds bf16 device copies (SwiGLU rows interleaved, head padded) of the
+ * weights in `table` [host array of n entries] on `device` and allocates the workspace.
+ * Synchronous. */
+int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table, int32_t n,
+                          int32_t device, esmdiff_engine** out);
+void esmdiff_engine_destroy(esmdiff_engine* eng);
+
+/* Text of the last error on `eng` (or of the last failed create when eng == NULL). [host] */
+const char* esmdiff_last_error(const esmdiff_engine* eng);
+
+/* Replaces self.net(structure_tokens=x, sequence_tokens=seq, auxiliary_embeddings=cond).structure_logits
+ * (model.py:475-481 -> net.py:371-483) including conditions = sigma_embedder(sigma) (model.py:466-471,
+ * net.py:519-522).  t_freq = TimestepEmbedder.timestep_embedding(sigma, freq_dim) [freq_dim] floats for
+ * the single sigma all rows share (model.py:570-571), or NULL for no time conditioning.
+ * seq, x: [B,L] int64.  logits_out: [B,L,ld_logits] float32, ld_logits >= vocab_out. */
+int esmdiff_forward_logits(esmdiff_engine* eng, const int64_t* seq, const int64_t* x,
+                           const float* t_freq, float* logits_out, int32_t ld_logits,
+                           int32_t B, int32_t L, void* stream);
+
+/* Replaces logits_parameterization + the sampling half of _ddpm_update + _sample_categorical
+ * (model.py:527-533, 602-607, 24-28): given RAW network logits, writes x' in place.
+ *   final == 0: x' = where(x != MASK, x, argmax_v q_v / (1e-10 - log(u_v + 1e-10)))
+ *   final != 0: noise-removal step (model.py:575-579): x' = argmax_v log_p_v
+ * Noise: `u` = explicit uniforms [B,L,vocab] row-major (what torch.rand_like draws, model.py:27),
+ * or u == NULL and `rng` != NULL for the Philox source at step index `step`. */
+int esmdiff_ddpm_step(esmdiff_engine* eng, int64_t* x_inout, const float* logits, int32_t ld_logits,
+                      float move_chance_t, float move_chance_s, int32_t final, const float* u,
+                      const esmdiff_rng* rng, int32_t step, int32_t B, int32_t L, void* stream);
+
+/* Replaces MaskedDiffusionLanguageModeling.ddpm_sample (model.py:543-581) for one batch, entirely on
+ * the device, Philox noise: T updates + the noise-removal pass.  x_inout holds the prior on entry
+ * (all MASK, model.py:555, or input_prior, :561) and the sample on return.
+ * mc_t, mc_s: [T] move chances per step [host]; t_freq: [(T+1), freq_dim] [host] (row T = noise removal). */
+int esmdiff_ddpm_sample(esmdiff_engine* eng, const int64_t* seq, int64_t* x_inout, int32_t B, int32_t L,
+                        int32_t T, const float* mc_t, const float* mc_s, const float* t_freq,
+                        const esmdiff_rng* rng, void* stream);
+
+/* Per-kernel entry points (used by the parity tests and the bench's roofline leg). */
+
+/* C[M,N] (+)= A[M,K] · W[N,K]^T, bf16 in, f32 accumulate.  epilogue: see esmdiff_gemm_epilogue. */
+typedef enum {
+  ESMDIFF_EPI_BF16 = 0,       /* out bf16 [M,N]                                   */
+  ESMDIFF_EPI_RESID_F32 = 1,  /* out f32 [M,N] += acc * alpha   (residual stream)   */
+  ESMDIFF_EPI_SWIGLU_BF16 = 2,/* W rows interleaved gate/up in blocks of 32; out bf16 [M,N/2] */
+  ESMDIFF_EPI_BIAS_GELU_BF16 = 3, /* out bf16 = gelu(acc + bias[N])                 */
+  ESMDIFF_EPI_BIAS_F32 = 4    /* out f32 [M,ldc] = acc + bias, columns >= n_valid skipped */
+} esmdiff_gemm_epilogue;
+
+int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N,
+                      int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream);
+
+/* Wall-clock helper for the bench's roofline leg: runs the GEMM `iters` times on `stream` bracketed by
+ * HIP events on that stream and returns the average milliseconds per launch in *ms_out [host]. */
+int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float* bias, int32_t M,
+                            int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha,
+                            int32_t epilogue, int32_t iters, float* ms_out, void* stream);
+
+/* y bf16 [M,D] = LayerNorm(x f32 [M,D]) * w (+ b); b may be NULL.  eps = 1e-5. */
+int esmdiff_layernorm_bf16(const float* x, const float* w, const float* b, void* y, int32_t M, int32_t D,
+                           void* stream);
+
+/* Attention over pre-processed heads: qkv bf16 [B*L, 3*D] (GEMM output) -> ctx bf16 [B*L, D].
+ * Applies the full-width q/k LayerNorm (weights f32 [D]), rotary, 1/sqrt(64) scaling, non-causal softmax. */
+int esmdiff_attention_bf16(esmdiff_engine* eng, const void* qkv, const float* q_ln_w, const float* k_ln_w,
+                           void* ctx, int32_t B, int32_t L, void* stream);
+
+/* Accumulated per-section device time of the last esmdiff_forward_logits/ddpm_sample calls when
+ * profiling is enabled (esmdiff_set_profiling(eng,1)); sections: 0 embed, 1 layernorm, 2 gemm_qkv,
+ * 3 qk_norm_rope, 4 attention, 5 gemm_out, 6 gemm_ffn_up, 7 gemm_ffn_down, 8 head, 9 sampler.
+ * ms_out: [16] floats, launches_out: [16] ints [host].  Synchronises the device. */
+int esmdiff_set_profiling(esmdiff_engine* eng, int32_t on);
+int esmdiff_get_profile(esmdiff_engine* eng, float* ms_out, int32_t* launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESMDIFF_HIP_H */

@@ -1,0 +1,22 @@
+"""oracle/ — CPU restatement of the reference's sampling hot path.  TEST INFRASTRUCTURE.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import
+anything from this package, and only as the checker / the reported CPU baseline — never as
+the thing shipped.  The product (`esmdiff_amd`) never imports it and fails loudly when
+libesmdiff_hip.so is missing.
+
+Parts
+  sampler_ref.py   torch-CPU float32 restatement, op for op, of the reference's sampler
+                   (model.py / noise_utils.py / net.py::TimestepEmbedder / sample_esmdiff.py batching /
+                   eval_utils.merge_pdbfiles).  PINNED: reproduces tests/golden/g1..g8, which were
+                   produced by importing the reference's own code (tests/golden/make_goldens.py).
+  csrc/sampler_oracle.c
+                   plain-C restatement of one update in the canonical float-op order the HIP kernel
+                   uses (bit-exact gate).  PINNED through g3..g6 (ids exact, log-probs <= 4 ulp).
+  esm3_ref.py      torch-CPU float32 restatement of the ESM3-open network as CustomizedESM3 wires it
+                   (net.py:322-483).  PARITY UNPINNED: the arithmetic lives in the third-party package
+                   esm==3.0.4 (requirements.txt:30) which is neither vendored in the reference nor
+                   installable here; it is restated from the published architecture (SURVEY.md
+                   Appendix A) and anchored only on the reference's call sites and in-tree
+                   hyper-parameters (net.py:325-346, mdlm.yaml:26-58).
+"""

@@ -1,0 +1,191 @@
+"""CPU: the oracle (torch restatement + C canonical-order restatement) against the golden vectors that
+tests/golden/make_goldens.py produced by running the REFERENCE's own sampler code."""
+import json
+import tempfile
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import sampler_ref as R
+from tests.standin_net import StandinNet, standin_sigma_embedder_state
+
+torch.set_num_threads(1)
+
+
+def _ulp_diff(a, b):
+    a = np.asarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.asarray(b, np.float32).view(np.int32).astype(np.int64)
+    return np.abs(a - b)
+
+
+def test_g1_schedules(golden_dir):
+    g = np.load(golden_dir / "g1_schedules.npz")
+    for T in (5, 25, 50):
+        for nm, noise in (("loglinear", R.LogLinearNoiseRef()), ("cosine", R.CosineNoiseRef(1e-3))):
+            s = R.ddpm_schedule_ref(T, 1e-5, 1.0, noise)
+            assert np.array_equal(s["timesteps"].numpy(), g[f"timesteps_T{T}"])
+            assert s["dt"] == float(g[f"dt_T{T}"])
+            for k in ("sigma_t", "sigma_s", "mc_t", "mc_s"):
+                assert np.array_equal(s[k].numpy(), g[f"{nm}_{k}_T{T}"]), (nm, k, T)
+            ds = noise(s["timesteps"][:, None])[1].squeeze(-1).numpy()
+            assert np.array_equal(ds, g[f"{nm}_dsigma_t_T{T}"])
+    # D.2 spot values
+    assert abs(float(g["loglinear_sigma_t_T25"][0]) - 6.90776825) < 1e-5
+    assert abs(float(g["loglinear_mc_t_T25"][1]) - 0.95904040) < 1e-6
+
+
+def test_g2_timestep_embedding(golden_dir):
+    g = np.load(golden_dir / "g2_timestep.npz")
+    sig = torch.from_numpy(g["sigma"])
+    assert np.array_equal(R.timestep_embedding_ref(sig, 256).numpy(), g["freq_embedding_256"])
+    assert np.array_equal(R.timestep_embedding_ref(sig, 7).numpy(), g["freq_embedding_7"])
+    for h in (32, 64):
+        emb = R.TimestepEmbedderRef(h)
+        emb.load_state_dict(standin_sigma_embedder_state(h))
+        with torch.no_grad():
+            out = emb(sig).numpy()
+        np.testing.assert_allclose(out, g[f"mlp_out_h{h}"], rtol=0, atol=2e-6)
+
+
+def test_g3_logits_parameterization(golden_dir):
+    g = np.load(golden_dir / "g3_logits_param.npz")
+    lp = R.logits_parameterization_ref(torch.from_numpy(g["logits"]), torch.from_numpy(g["xt"])).numpy()
+    assert np.array_equal(lp, g["log_p"])
+    # C oracle: canonical reduction order -> within a few ulp of torch's logsumexp
+    lpc = c_oracle.logits_parameterization(g["logits"], g["xt"])
+    masked = g["xt"] == R.MASK
+    assert np.array_equal(lpc[~masked], g["log_p"][~masked])
+    fin = g["log_p"][masked] > -1e5
+    np.testing.assert_allclose(lpc[masked][fin], g["log_p"][masked][fin], rtol=0, atol=4e-6)
+    assert (lpc[masked][~fin] < -9e5).all()
+
+
+def test_g4_sample_categorical(golden_dir):
+    g = np.load(golden_dir / "g4_categorical.npz")
+    probs = torch.from_numpy(g["probs"])
+    torch.manual_seed(int(g["seed"]))
+    ids = R.sample_categorical_ref(probs)            # draws its own uniforms like model.py:27
+    assert np.array_equal(ids.numpy(), g["ids"])
+    ids_u = R.sample_categorical_ref(probs, torch.from_numpy(g["u"]))
+    assert np.array_equal(ids_u.numpy(), g["ids"])
+    torch.manual_seed(int(g["seed"]))
+    assert np.array_equal(torch.rand(*probs.shape).numpy(), g["u"])   # D.3: shape-independent MT stream
+
+
+def _model(hidden=32):
+    emb = R.TimestepEmbedderRef(hidden)
+    emb.load_state_dict(standin_sigma_embedder_state(hidden))
+    return R.MDLMSamplerRef(StandinNet(hidden), emb, R.LogLinearNoiseRef(), True, True)
+
+
+def test_g5_ddpm_update(golden_dir):
+    g = np.load(golden_dir / "g5_ddpm_update.npz")
+    m = _model()
+    x = torch.from_numpy(g["x"])
+    seq = torch.from_numpy(g["seq"])
+    t = torch.from_numpy(g["t"])
+    with torch.no_grad():
+        torch.manual_seed(int(g["seed"]))
+        new, logp = m.ddpm_update(x.clone(), t, seq, float(g["dt"]), return_logp=True)
+    np.testing.assert_allclose(logp.numpy(), g["log_p"], rtol=0, atol=4e-6)
+    assert np.array_equal(new.numpy(), g["x_new"])
+    # C oracle on the RAW logits of the stand-in net + the recorded uniforms -> identical ids
+    with torch.no_grad():
+        sigma_t = m.noise(t)[0].squeeze(-1)
+        cond = torch.tile(m.sigma_embedder(sigma_t)[:, None, :], (1, x.shape[1], 1))
+        raw = m.net(structure_tokens=x, sequence_tokens=seq, auxiliary_embeddings=cond).structure_logits
+    s = R.ddpm_schedule_ref(int(g["T"]))
+    i = int(g["step"])
+    xc = c_oracle.ddpm_step(g["x"], raw.numpy(), s["mc_t"][i].item(), s["mc_s"][i].item(), u=g["u"])
+    assert np.array_equal(xc, g["x_new"])
+
+
+@pytest.mark.parametrize("tag", ["T5_noprior", "T25_noprior", "T25_prior", "T5_prior"])
+def test_g6_ddpm_sample(golden_dir, tag):
+    g = np.load(golden_dir / "g6_ddpm_sample.npz")
+    m = _model()
+    seq = torch.from_numpy(g[f"{tag}_seq"])
+    prior = torch.from_numpy(g[f"{tag}_prior"]) if f"{tag}_prior" in g else None
+    traj = []
+    torch.manual_seed(int(g[f"{tag}_seed"]))
+    xf = m.ddpm_sample(seq, int(g[f"{tag}_T"]), 1e-5, prior, 1.0, trajectory=traj)
+    assert np.array_equal(torch.stack(traj).numpy(), g[f"{tag}_traj"])
+    assert np.array_equal(xf.numpy(), g[f"{tag}_final"])
+
+
+@pytest.mark.parametrize("tag", ["T25_noprior", "T5_prior"])
+def test_g6_c_oracle_trajectory(golden_dir, tag):
+    """Drive the C oracle step by step with the reference's uniform stream: ids match every step."""
+    g = np.load(golden_dir / "g6_ddpm_sample.npz")
+    m = _model()
+    seq = torch.from_numpy(g[f"{tag}_seq"])
+    T = int(g[f"{tag}_T"])
+    B, L = seq.shape
+    x = g[f"{tag}_prior"].copy() if f"{tag}_prior" in g else np.full((B, L), R.MASK, np.int64)
+    s = R.ddpm_schedule_ref(T)
+    torch.manual_seed(int(g[f"{tag}_seed"]))
+    with torch.no_grad():
+        for i in range(T + 1):
+            sig = s["sigma_t"][i] * torch.ones(B)
+            cond = torch.tile(m.sigma_embedder(sig)[:, None, :], (1, L, 1))
+            raw = m.net(structure_tokens=torch.from_numpy(x), sequence_tokens=seq,
+                        auxiliary_embeddings=cond).structure_logits.numpy()
+            if i < T:
+                u = torch.rand(B, L, R.VOCAB).numpy()
+                x = c_oracle.ddpm_step(x, raw, s["mc_t"][i].item(), s["mc_s"][i].item(), u=u)
+                assert np.array_equal(x, g[f"{tag}_traj"][i]), i
+            else:
+                x = c_oracle.ddpm_step(x, raw, 0.0, 0.0, final=True)
+    assert np.array_equal(x, g[f"{tag}_final"])
+
+
+def test_g7_batch_split(golden_dir):
+    cases = json.loads((golden_dir / "g7_batch_split.json").read_text())
+    for key, want in cases.items():
+        L, N = (int(v) for v in key.split(","))
+        assert R.batch_split_ref(L, N) == want
+    assert R.batch_split_ref(258, 100) == [63, 37] and R.batch_split_ref(1026, 32) == [3] * 8 + [8]
+
+
+def test_g8_merge_pdbfiles(golden_dir):
+    g = json.loads((golden_dir / "g8_merge_pdb.json").read_text())
+    with tempfile.TemporaryDirectory() as d:
+        pa, pb, pm = Path(d) / "a.pdb", Path(d) / "b.pdb", Path(d) / "m.pdb"
+        pa.write_text(g["a"])
+        pb.write_text(g["b"])
+        R.merge_pdbfiles_ref([pa, pb], pm)
+        assert pm.read_text() == g["merged"]
+
+
+def test_shared_math_accuracy():
+    """ed_math.h exp/log vs float64 libm: <= 2 ulp over the ranges the sampler uses."""
+    rs = np.random.RandomState(0)
+    x = np.concatenate([rs.uniform(-87, 0, 200000), rs.uniform(-1e-3, 1e-3, 1000), [0.0, -103.0, -1e6, 88.0]])
+    x = x.astype(np.float32)
+    got = c_oracle.expf(x)
+    want = np.exp(x.astype(np.float64)).astype(np.float32)
+    normal = want > 1.2e-38
+    assert _ulp_diff(got[normal], want[normal]).max() <= 2
+    assert got[-2] == 0.0 and got[-4] == 1.0
+    y = np.concatenate([rs.uniform(1e-10, 1.0, 200000), rs.uniform(1, 5000, 100000),
+                        [1.0, 1e-10, 2.0 ** -24 + 1e-10]]).astype(np.float32)
+    gl = c_oracle.logf(y)
+    wl = np.log(y.astype(np.float64))
+    err = np.abs(gl.astype(np.float64) - wl)
+    ulp = np.maximum(np.spacing(np.abs(wl).astype(np.float32)), 1e-45)
+    assert (err / np.maximum(ulp, 2.0 ** -24 * 1e-1)).max() <= 2.5 or (err <= 1.2e-7).all()
+    assert gl[-3] == 0.0
+
+
+def test_philox_known_answer():
+    """Random123 known-answer vectors for Philox4x32-10."""
+    assert c_oracle.philox([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert c_oracle.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6,
+                                                                   0x6D5451FD]
+    assert c_oracle.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == [
+        0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    u = c_oracle.philox_uniforms(7, 3, 2, 5)
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02
