@@ -1,0 +1,87 @@
+"""ctypes binding of libesmdiff_hip.so (include/esmdiff_hip.h).  There is NO fallback: if the library is
+missing or no gfx950 device is present, every entry point raises."""
+from __future__ import annotations
+
+import ctypes
+from pathlib import Path
+
+_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libesmdiff_hip.so"
+_lib = None
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+
+EPI_BF16, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_F32 = range(5)
+DT_F32, DT_BF16 = 0, 1
+SECTIONS = ["embed", "layernorm", "gemm_qkv", "qk_norm_rope", "attention", "gemm_out", "gemm_ffn_up",
+            "gemm_ffn_down", "head", "sampler"]
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("d_model", ctypes.c_int32), ("n_heads", ctypes.c_int32), ("n_layers", ctypes.c_int32),
+                ("ffn_hidden", ctypes.c_int32), ("vocab_out", ctypes.c_int32), ("freq_dim", ctypes.c_int32),
+                ("max_batch", ctypes.c_int32), ("max_len", ctypes.c_int32), ("residue_scale", ctypes.c_float),
+                ("time_conditioning", ctypes.c_int32)]
+
+
+class Weight(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("data", ctypes.c_void_p), ("dtype", ctypes.c_int32),
+                ("ndim", ctypes.c_int32), ("shape", ctypes.c_int64 * 4)]
+
+
+class Rng(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("sample_offset", ctypes.c_uint64)]
+
+
+EXPORTS = [
+    "esmdiff_abi_version", "esmdiff_engine_create", "esmdiff_engine_destroy", "esmdiff_last_error",
+    "esmdiff_forward_logits", "esmdiff_ddpm_step", "esmdiff_ddpm_sample", "esmdiff_gemm_bf16",
+    "esmdiff_gemm_bf16_timed", "esmdiff_layernorm_bf16", "esmdiff_attention_bf16", "esmdiff_set_profiling",
+    "esmdiff_get_profile",
+]
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def lib():
+    """Load the shared library (building is __graft_entry__.build()'s / `python -m esmdiff_amd.build`'s job)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise RuntimeError(
+            f"{_LIB_PATH} not found: build it with `python -m esmdiff_amd.build` (needs hipcc). "
+            "esmdiff_amd has no CPU fallback.")
+    L = ctypes.CDLL(str(_LIB_PATH))
+    vp, i32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_float
+    L.esmdiff_abi_version.restype = ctypes.c_int
+    L.esmdiff_engine_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(Weight), i32, i32,
+                                        ctypes.POINTER(vp)]
+    L.esmdiff_engine_destroy.argtypes = [vp]
+    L.esmdiff_engine_destroy.restype = None
+    L.esmdiff_last_error.argtypes = [vp]
+    L.esmdiff_last_error.restype = ctypes.c_char_p
+    L.esmdiff_forward_logits.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.esmdiff_ddpm_step.argtypes = [vp, vp, vp, i32, f32, f32, i32, vp, ctypes.POINTER(Rng), i32, i32, i32, vp]
+    L.esmdiff_ddpm_sample.argtypes = [vp, vp, vp, i32, i32, i32, c_f32p, c_f32p, c_f32p, ctypes.POINTER(Rng), vp]
+    L.esmdiff_gemm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
+    L.esmdiff_gemm_bf16_timed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, c_f32p, vp]
+    L.esmdiff_layernorm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.esmdiff_attention_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
+    L.esmdiff_set_profiling.argtypes = [vp, i32]
+    L.esmdiff_get_profile.argtypes = [vp, c_f32p, ctypes.POINTER(i32)]
+    for n in EXPORTS:
+        if n not in ("esmdiff_engine_destroy", "esmdiff_last_error"):
+            getattr(L, n).restype = ctypes.c_int
+    if L.esmdiff_abi_version() != 1:
+        raise RuntimeError("libesmdiff_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(code: int, eng=None):
+    if code != 0:
+        msg = lib().esmdiff_last_error(eng)
+        raise RuntimeError(f"libesmdiff_hip error {code}: {msg.decode() if msg else '?'}")

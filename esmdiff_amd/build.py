@@ -1,0 +1,80 @@
+"""Builds esmdiff_amd/lib/libesmdiff_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m esmdiff_amd.build [--force]
+
+One translation unit per kernel family; sampler.hip is compiled with -ffp-contract=off so that
+csrc/ed_math.h evaluates bit-identically on host and device (see oracle/csrc/sampler_oracle.c).
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIBDIR = PKG / "lib"
+OBJDIR = PKG / "build"
+LIB = LIBDIR / "libesmdiff_hip.so"
+INCLUDE = PKG.parent / "include"
+
+UNITS = {
+    "engine": [],
+    "gemm": [],
+    "attention": [],
+    "norm": [],
+    "embed": [],
+    "convert": [],
+    "sampler": ["-ffp-contract=off"],
+}
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
+          "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newest_src() -> float:
+    files = list(CSRC.glob("*")) + [INCLUDE / "esmdiff_hip.h", Path(__file__)]
+    return max(f.stat().st_mtime for f in files)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if LIB.exists() and not force and LIB.stat().st_mtime >= _newest_src():
+        return LIB
+    LIBDIR.mkdir(exist_ok=True)
+    OBJDIR.mkdir(exist_ok=True)
+    cc = _hipcc()
+    headers = [p.stat().st_mtime for p in list(CSRC.glob("*.h")) + [INCLUDE / "esmdiff_hip.h"]]
+
+    def compile_one(name):
+        src, obj = CSRC / f"{name}.hip", OBJDIR / f"{name}.o"
+        if (not force and obj.exists() and obj.stat().st_mtime >= max([src.stat().st_mtime] + headers)):
+            return name, ""
+        cmd = [cc, *COMMON, *UNITS[name], "-c", str(src), "-o", str(obj)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stderr}")
+        return name, r.stderr
+
+    with ThreadPoolExecutor(max_workers=min(8, len(UNITS))) as ex:
+        for name, err in ex.map(compile_one, UNITS):
+            if verbose and err.strip():
+                print(f"[{name}] {err}", file=sys.stderr)
+    objs = [str(OBJDIR / f"{n}.o") for n in UNITS]
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB)],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, verbose=True)
+    print(p)

@@ -1,0 +1,33 @@
+"""Static model configuration — the inference-time content of the reference's Hydra config
+(/root/reference/configs/experiment/mdlm.yaml:26-58) and of CustomizedESM3's defaults
+(/root/reference/slm/models/net.py:322-332)."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class ModelConfig:
+    d_model: int = 1536            # net.py:325
+    n_heads: int = 24              # net.py:326
+    v_heads: int = 256             # net.py:327 (geometric attention; unused without coordinates)
+    n_layers: int = 48             # net.py:328
+    n_structure_heads: int = 4101  # mdlm.yaml:57
+    freq_dim: int = 256            # TimestepEmbedder.frequency_embedding_size, net.py:487
+    time_conditioning: bool = True # mdlm.yaml:41
+    noise_eps: float = 1e-3        # LogLinearNoise(eps), noise_utils.py:196
+    noise_removal: bool = True     # checkpoint_utils.py:71
+
+    @property
+    def ffn_hidden(self) -> int:   # esm swiglu_ln_ffn: ceil(8/3 d / 256) * 256
+        return int(((8.0 / 3.0 * self.d_model) + 255) // 256 * 256)
+
+    @property
+    def residue_scale(self) -> float:  # esm TransformerStack: sqrt(n_layers / 36)
+        return math.sqrt(self.n_layers / 36)
+
+
+ESM3_OPEN = ModelConfig()
+# small configuration with the same structure, for tests (d_model must be a multiple of 512)
+TINY = ModelConfig(d_model=512, n_heads=8, v_heads=32, n_layers=2)

@@ -1,0 +1,202 @@
+// attention.hip — non-causal multi-head attention, head dim 64, flash-style (gfx950).
+//
+// Replaces F.scaled_dot_product_attention(q, k, v) as esm's MultiHeadAttention calls it with
+// sequence_id=None (the reference passes None: /root/reference/slm/models/net.py:468), i.e. no mask.
+// The (B,24,L,L) score tensor is never materialised: each wave owns 32 queries and streams the keys
+// in tiles of 64 through LDS with an online softmax, so L = 1026 (BASELINE config 4; K/V per head =
+// 263 KB > 160 KB LDS) needs no special casing — only the number of tiles changes.
+//
+// Workgroup = 4 waves = 128 queries of one (batch, head).  Per 64-key tile:
+//   S^T = K · Q^T      2 x 4 v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = Q^T held in registers)
+//     "swapped" product: C[key][query] puts a query in a LANE (col = lane & 31) and its 64 scores in
+//     that lane's registers (+ the partner lane ^ 32), so row max / row sum are register reductions
+//     plus one cross-lane exchange, and the running rescale factor is a per-lane scalar.
+//   O^T += V^T · P^T   2 x 4 MFMAs (A = V^T rows from LDS — vt is stored keys-contiguous by
+//     v_transpose — B = P^T taken directly from the S^T accumulators: the key order inside a
+//     16-key MFMA k-step is permuted identically on both operands, so no lane shuffles are needed).
+// K and V^T tiles are 64 rows x 128 B, staged by LDS-DMA with the same source-side XOR swizzle as the
+// GEMM (conflict-free ds_read_b128 for K; 2-way for the 8-byte V^T reads), double buffered.
+// q arrives pre-scaled by log2(e)/8 (qk_norm_rope), so the softmax runs on exp2.
+#include "kernels.h"
+
+namespace ed {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int KV_TILE = 64;
+constexpr int KV_BYTES = KV_TILE * 128;  // 8 KiB per operand per stage
+
+__device__ __forceinline__ void glds16a(const void* gsrc, void* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
+  ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
+  return ua | (ub << 16);
+}
+
+__global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ q,
+                                                           const bf16_t* __restrict__ k,
+                                                           const bf16_t* __restrict__ vt, bf16_t* __restrict__ ctx,
+                                                           int L, int Lp, int H) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_BYTES];  // [stage][K 8K | Vt 8K]
+
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool active = q0 < L;  // wave-uniform
+  const int qi = lane & 31, hi = lane >> 5;
+
+  const bf16_t* kbase = k + ((int64_t)bh * Lp) * 64;
+  const bf16_t* vbase = vt + ((int64_t)bh * 64) * Lp;
+
+  // ---- LDS-DMA: per tile 8 instructions for K (64 rows x 128 B) + 8 for Vt; 2 + 2 per wave ------
+  // instruction i of this wave covers rows (i*4 + wave)*8 + (lane>>3), 16-byte slot lane&7
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  const bf16_t* k_src[2];
+  const bf16_t* v_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (i * 4 + wave) * 8 + srow;
+    k_src[i] = kbase + (int64_t)r * 64 + schunk * 8;      // + kt*64 rows
+    v_src[i] = vbase + (int64_t)r * Lp + schunk * 8;      // + kt*64 columns
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * (2 * KV_BYTES);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      char* d = base + (i * 4 + wave) * 1024;
+      glds16a(k_src[i] + (int64_t)kt * KV_TILE * 64, d);
+      glds16a(v_src[i] + kt * KV_TILE, d + KV_BYTES);
+    }
+  };
+
+  // ---- Q^T fragments (B operand): lane -> query qi, d chunk ks*2 + hi -------------------------
+  bf16x8 qf[4];
+  {
+    const bf16_t* qrow = q + ((int64_t)bh * Lp + q0 + qi) * 64;  // rows < Lp always readable
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + (ks * 2 + hi) * 8);
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  const int fsw = (qi >> 1) & 7;
+  const int nkt = (L + KV_TILE - 1) / KV_TILE;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    if (active) {
+      const char* kl = smem + cur * (2 * KV_BYTES);
+      const char* vl = kl + KV_BYTES;
+      // ---- S^T = K · Q^T -----------------------------------------------------------------------
+      f32x16 s[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kf =
+              *reinterpret_cast<const bf16x8*>(kl + (t * 32 + qi) * 128 + (((ks * 2 + hi) ^ fsw) << 4));
+          s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
+        }
+      }
+      // ---- mask keys >= L (last tile only; wave-uniform branch) ---------------------------------
+      if (kt * KV_TILE + KV_TILE > L) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt * KV_TILE + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (key >= L) s[t][r] = -1e30f;
+          }
+      }
+      // ---- online softmax (base 2) -------------------------------------------------------------
+      float mx = s[0][0];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      m_run = m_new;
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[t][r] = exp2f(s[t][r] - m_new);
+          ps += s[t][r];
+        }
+      l_run = l_run * alpha + ps;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      // ---- O^T += V^T · P^T ; k-step kk covers keys kk*16 + 4*hi + {0..3, 8..11} ------------------
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const int t = kk >> 1, r0 = (kk & 1) * 8;
+        union { uint32_t u[4]; bf16x8 v; } pb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pb.u[e] = pk_bf16(s[t][r0 + 2 * e], s[t][r0 + 2 * e + 1]);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const char* vrow = vl + (d * 32 + qi) * 128 + 8 * hi;
+          union { bf16x4 h[2]; bf16x8 v; } va;
+          va.h[0] = *reinterpret_cast<const bf16x4*>(vrow + (((kk * 2) ^ fsw) << 4));
+          va.h[1] = *reinterpret_cast<const bf16x4*>(vrow + (((kk * 2 + 1) ^ fsw) << 4));
+          o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pb.v, o[d], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  if (!active) return;
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qrow = q0 + qi;
+  if (qrow < L) {
+    bf16_t* dst = ctx + ((int64_t)b * L + qrow) * (H * 64) + h * 64;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 p;
+        p.x = pk_bf16(o[d][g * 4 + 0] * inv, o[d][g * 4 + 1] * inv);
+        p.y = pk_bf16(o[d][g * 4 + 2] * inv, o[d][g * 4 + 3] * inv);
+        *reinterpret_cast<uint2*>(dst + d * 32 + g * 8 + 4 * hi) = p;
+      }
+  }
+}
+
+hipError_t launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* ctx, int B, int L,
+                            int Lp, int H, hipStream_t stream) {
+  if (B <= 0 || L <= 0) return hipSuccess;
+  if (Lp % 128 != 0 || Lp < L) return hipErrorInvalidValue;
+  dim3 grid((L + 127) / 128, B * H), block(256);
+  hipLaunchKernelGGL(attention_kernel, grid, block, 0, stream, q, k, vt, ctx, L, Lp, H);
+  return hipGetLastError();
+}
+
+}  // namespace ed

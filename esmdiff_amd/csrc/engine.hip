@@ -1,0 +1,526 @@
+// engine.hip — C ABI of libesmdiff_hip.so (see include/esmdiff_hip.h) and the per-forward launch
+// sequence for the ESM3-open structure-token transformer as the reference wires it
+// (/root/reference/slm/models/net.py:371-483, model.py:464-492, 543-607).
+//
+// Per forward (B x L tokens, M = B*L rows):
+//   sigma_mlp (2 GEMV)  -> embed -> 48 x [ LN -> QKV GEMM -> q/k LN + rotary + V^T -> attention ->
+//   out-proj GEMM (+= residual/scale) -> LN -> FFN-up GEMM (SwiGLU epilogue) -> FFN-down GEMM (+= residual/scale) ]
+//   -> final LN -> head GEMM (bias+GELU) -> LN -> head GEMM (bias) -> f32 logits -> fused sampler.
+// Block 0's geometric attention contributes exactly 0 in this path (coordinates are all-NaN ->
+// affine_mask all False, net.py:433-441 with mask_and_zero_frameless=True, net.py:344) and is skipped.
+// Everything is enqueued on the caller's stream; the engine never synchronises except in create and in
+// the profiling readback.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace ed;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum Section { S_EMBED = 0, S_LN, S_QKV, S_QKROPE, S_ATTN, S_OUT, S_FFN_UP, S_FFN_DOWN, S_HEAD, S_SAMPLER, S_COUNT };
+
+struct Layer {
+  float *ln1_w, *ln1_b, *q_ln_w, *k_ln_w, *ln2_w, *ln2_b;
+  bf16_t *w_qkv, *w_out, *w_up, *w_down;
+};
+
+}  // namespace
+
+struct esmdiff_engine {
+  esmdiff_config cfg{};
+  int device = 0;
+  std::string err;
+  std::vector<void*> allocs;
+  // weights
+  std::vector<Layer> layers;
+  float *e_seq = nullptr, *e_struct = nullptr, *cvec = nullptr;
+  float *final_ln_w = nullptr;
+  bf16_t *head_w0 = nullptr, *head_w3 = nullptr;
+  float *head_b0 = nullptr, *head_ln_w = nullptr, *head_ln_b = nullptr, *head_b3 = nullptr;
+  float *sig_w1 = nullptr, *sig_b1 = nullptr, *sig_w2 = nullptr, *sig_b2 = nullptr;
+  float *rope_cos = nullptr, *rope_sin = nullptr;
+  int vocab_pad = 0;
+  // workspace
+  float* x = nullptr;
+  bf16_t *h = nullptr, *h2 = nullptr, *qkv = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr,
+         *mid = nullptr;
+  float *logits = nullptr, *cond = nullptr, *sig_hidden = nullptr, *tfreq = nullptr;
+  int ld_logits = 0, Lp_max = 0, tfreq_rows = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> ev_section;
+  size_t ev_used = 0;
+  float prof_ms[16] = {0};
+  int prof_launches[16] = {0};
+};
+
+namespace {
+
+int fail(esmdiff_engine* e, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(e, call)                                                                         \
+  do {                                                                                           \
+    hipError_t _s = (call);                                                                      \
+    if (_s != hipSuccess) return fail(e, ESMDIFF_E_HIP, "%s: %s", #call, hipGetErrorString(_s)); \
+  } while (0)
+
+template <typename T>
+int dalloc(esmdiff_engine* e, T** p, size_t n_elems, bool zero = false) {
+  void* v = nullptr;
+  hipError_t s = hipMalloc(&v, n_elems * sizeof(T) + 256);
+  if (s != hipSuccess) return fail(e, ESMDIFF_E_HIP, "hipMalloc(%zu): %s", n_elems * sizeof(T), hipGetErrorString(s));
+  if (zero) hipMemset(v, 0, n_elems * sizeof(T) + 256);
+  e->allocs.push_back(v);
+  *p = reinterpret_cast<T*>(v);
+  return 0;
+}
+
+struct Table {
+  std::map<std::string, const esmdiff_weight*> m;
+  const esmdiff_weight* find(const std::string& name) const {
+    auto it = m.find(name);
+    if (it != m.end()) return it->second;
+    it = m.find("net." + name);
+    return it == m.end() ? nullptr : it->second;
+  }
+};
+
+int64_t numel(const esmdiff_weight* w) {
+  int64_t n = 1;
+  for (int i = 0; i < w->ndim; ++i) n *= w->shape[i];
+  return n;
+}
+
+int need(esmdiff_engine* e, const Table& t, const std::string& name, std::initializer_list<int64_t> shape,
+         const esmdiff_weight** out) {
+  const esmdiff_weight* w = t.find(name);
+  if (!w) return fail(e, ESMDIFF_E_MISSING, "missing weight '%s' (state dict is loaded strictly, checkpoint_utils.py:64)", name.c_str());
+  if (w->ndim != (int)shape.size()) return fail(e, ESMDIFF_E_SHAPE, "weight '%s': ndim %d, expected %zu", name.c_str(), w->ndim, shape.size());
+  int i = 0;
+  for (int64_t s : shape) {
+    if (w->shape[i] != s) return fail(e, ESMDIFF_E_SHAPE, "weight '%s': dim %d is %lld, expected %lld", name.c_str(), i, (long long)w->shape[i], (long long)s);
+    ++i;
+  }
+  if (w->dtype != ESMDIFF_F32 && w->dtype != ESMDIFF_BF16) return fail(e, ESMDIFF_E_SHAPE, "weight '%s': unsupported dtype %d", name.c_str(), w->dtype);
+  if (!w->data) return fail(e, ESMDIFF_E_INVALID, "weight '%s': null data", name.c_str());
+  *out = w;
+  return 0;
+}
+
+int load_f32(esmdiff_engine* e, const Table& t, const std::string& name, std::initializer_list<int64_t> shape, float** dst) {
+  const esmdiff_weight* w;
+  if (int r = need(e, t, name, shape, &w)) return r;
+  if (int r = dalloc(e, dst, (size_t)numel(w))) return r;
+  HIP_TRY(e, launch_to_f32(w->data, w->dtype, *dst, numel(w), 0));
+  return 0;
+}
+
+int load_bf16(esmdiff_engine* e, const Table& t, const std::string& name, std::initializer_list<int64_t> shape,
+              bf16_t** dst, int64_t pad_rows_to = 0) {
+  const esmdiff_weight* w;
+  if (int r = need(e, t, name, shape, &w)) return r;
+  int64_t n = numel(w);
+  int64_t rows = w->shape[0], cols = n / rows;
+  int64_t rows_p = pad_rows_to > rows ? pad_rows_to : rows;
+  if (int r = dalloc(e, dst, (size_t)(rows_p * cols), rows_p != rows)) return r;
+  HIP_TRY(e, launch_to_bf16(w->data, w->dtype, *dst, n, 0));
+  return 0;
+}
+
+// RAII-less section timer: when profiling, records an event before/after each launch.
+struct Prof {
+  esmdiff_engine* e;
+  hipStream_t s;
+  void mark(int section) {
+    if (!e->profiling) return;
+    if (e->ev_used + 2 > e->ev.size()) {
+      for (int i = 0; i < 256; ++i) {
+        hipEvent_t ev;
+        hipEventCreate(&ev);
+        e->ev.push_back(ev);
+        e->ev_section.push_back(0);
+      }
+    }
+    e->ev_section[e->ev_used] = section;
+    hipEventRecord(e->ev[e->ev_used++], s);
+  }
+};
+
+void prof_collect(esmdiff_engine* e) {
+  if (!e->profiling || e->ev_used < 2) {
+    e->ev_used = 0;
+    return;
+  }
+  hipEventSynchronize(e->ev[e->ev_used - 1]);
+  for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]);
+    e->prof_ms[e->ev_section[i]] += ms;
+    e->prof_launches[e->ev_section[i]] += 1;
+  }
+  e->ev_used = 0;
+}
+
+int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int check_bl(esmdiff_engine* e, int B, int L) {
+  if (B <= 0 || L <= 0) return fail(e, ESMDIFF_E_INVALID, "B=%d L=%d must be positive", B, L);
+  if (B > e->cfg.max_batch || L > e->cfg.max_len || (int64_t)B * round_up(L, 128) > (int64_t)e->cfg.max_batch * e->Lp_max)
+    return fail(e, ESMDIFF_E_CAPACITY, "B=%d L=%d exceeds the engine capacity (max_batch=%d, max_len=%d)", B, L, e->cfg.max_batch, e->cfg.max_len);
+  return 0;
+}
+
+// the whole network: tokens -> f32 logits [M, ld]
+int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const float* t_freq_dev, float* logits,
+            int ld, int B, int L, hipStream_t st) {
+  const esmdiff_config& c = e->cfg;
+  const int D = c.d_model, H = c.n_heads, FH = c.ffn_hidden, M = B * L;
+  const int Lp = round_up(L, 128);
+  const float inv_scale = 1.0f / c.residue_scale;
+  Prof p{e, st};
+#define RUN(section, call)   \
+  do {                       \
+    p.mark(section);         \
+    HIP_TRY(e, (call));      \
+    p.mark(section);         \
+  } while (0)
+
+  const float* cond = nullptr;
+  if (t_freq_dev && c.time_conditioning) {
+    RUN(S_EMBED, launch_sigma_mlp(t_freq_dev, e->sig_w1, e->sig_b1, e->sig_w2, e->sig_b2, e->sig_hidden, e->cond,
+                                  c.freq_dim, D, st));
+    cond = e->cond;
+  }
+  RUN(S_EMBED, launch_embed(seq, xtok, e->e_seq, e->e_struct, e->cvec, cond, e->x, B, L, D, st));
+  for (int i = 0; i < c.n_layers; ++i) {
+    const Layer& ly = e->layers[i];
+    RUN(S_LN, launch_layernorm_bf16(e->x, ly.ln1_w, ly.ln1_b, e->h, M, D, st));
+    RUN(S_QKV, launch_gemm_bf16(e->h, ly.w_qkv, e->qkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_EPI_BF16, st));
+    RUN(S_QKROPE, launch_qk_norm_rope(e->qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, e->q, e->k, e->vt, B, L, Lp, H, st));
+    RUN(S_ATTN, launch_attention(e->q, e->k, e->vt, e->ctx, B, L, Lp, H, st));
+    RUN(S_OUT, launch_gemm_bf16(e->ctx, ly.w_out, e->x, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_RESID_F32, st));
+    RUN(S_LN, launch_layernorm_bf16(e->x, ly.ln2_w, ly.ln2_b, e->h, M, D, st));
+    RUN(S_FFN_UP, launch_gemm_bf16(e->h, ly.w_up, e->mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, st));
+    RUN(S_FFN_DOWN, launch_gemm_bf16(e->mid, ly.w_down, e->x, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_RESID_F32, st));
+  }
+  RUN(S_LN, launch_layernorm_bf16(e->x, e->final_ln_w, nullptr, e->h, M, D, st));
+  RUN(S_HEAD, launch_gemm_bf16(e->h, e->head_w0, e->h2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, st));
+  RUN(S_LN, launch_layernorm_bf16_in(e->h2, e->head_ln_w, e->head_ln_b, e->h, M, D, st));
+  RUN(S_HEAD, launch_gemm_bf16(e->h, e->head_w3, logits, e->head_b3, M, e->vocab_pad, D, ld, c.vocab_out, 1.f, ESMDIFF_EPI_BIAS_F32, st));
+#undef RUN
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int esmdiff_abi_version(void) { return ESMDIFF_ABI_VERSION; }
+
+const char* esmdiff_last_error(const esmdiff_engine* eng) { return eng ? eng->err.c_str() : g_create_error.c_str(); }
+
+void esmdiff_engine_destroy(esmdiff_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  hipDeviceSynchronize();
+  for (void* p : e->allocs) hipFree(p);
+  for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
+  delete e;
+}
+
+int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table, int32_t n, int32_t device,
+                          esmdiff_engine** out) {
+  if (!cfg || !table || !out || n <= 0) return fail(nullptr, ESMDIFF_E_INVALID, "null argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device >= ndev)
+    return fail(nullptr, ESMDIFF_E_NODEVICE, "no HIP device %d (found %d) — libesmdiff_hip.so needs an MI355X (gfx950)", device, ndev);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, ESMDIFF_E_NODEVICE, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, ESMDIFF_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+  const int D = cfg->d_model, H = cfg->n_heads, FH = cfg->ffn_hidden, V = cfg->vocab_out, F = cfg->freq_dim;
+  if (D != H * 64) return fail(nullptr, ESMDIFF_E_INVALID, "d_model (%d) must be n_heads (%d) x 64", D, H);
+  if (D % 512 || D > 2048) return fail(nullptr, ESMDIFF_E_INVALID, "d_model must be a multiple of 512, <= 2048");
+  if (FH % 128 || cfg->n_layers <= 0 || V <= ESMDIFF_MASK_ID || V > 5120 || F <= 0 || cfg->max_batch <= 0 || cfg->max_len <= 0)
+    return fail(nullptr, ESMDIFF_E_INVALID, "invalid configuration");
+
+  esmdiff_engine* e = new esmdiff_engine;
+  e->cfg = *cfg;
+  e->device = device;
+  auto bail = [&](int code) {
+    g_create_error = e->err;
+    esmdiff_engine_destroy(e);
+    return code;
+  };
+  if (hipSetDevice(device) != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "hipSetDevice failed"));
+
+  Table t;
+  for (int i = 0; i < n; ++i)
+    if (table[i].name) t.m[table[i].name] = &table[i];
+
+#define TRY(x)                  \
+  do {                          \
+    if (int _r = (x)) return bail(_r); \
+  } while (0)
+
+  e->layers.resize(cfg->n_layers);
+  for (int i = 0; i < cfg->n_layers; ++i) {
+    Layer& ly = e->layers[i];
+    const std::string b = "transformer.blocks." + std::to_string(i) + ".";
+    TRY(load_f32(e, t, b + "attn.layernorm_qkv.0.weight", {D}, &ly.ln1_w));
+    TRY(load_f32(e, t, b + "attn.layernorm_qkv.0.bias", {D}, &ly.ln1_b));
+    TRY(load_bf16(e, t, b + "attn.layernorm_qkv.1.weight", {3 * D, D}, &ly.w_qkv));
+    TRY(load_f32(e, t, b + "attn.q_ln.weight", {D}, &ly.q_ln_w));
+    TRY(load_f32(e, t, b + "attn.k_ln.weight", {D}, &ly.k_ln_w));
+    TRY(load_bf16(e, t, b + "attn.out_proj.weight", {D, D}, &ly.w_out));
+    TRY(load_f32(e, t, b + "ffn.0.weight", {D}, &ly.ln2_w));
+    TRY(load_f32(e, t, b + "ffn.0.bias", {D}, &ly.ln2_b));
+    {
+      const esmdiff_weight* w;
+      TRY(need(e, t, b + "ffn.1.weight", {2 * FH, D}, &w));
+      TRY(dalloc(e, &ly.w_up, (size_t)2 * FH * D));
+      if (launch_interleave_swiglu(w->data, w->dtype, ly.w_up, FH, D, 0) != hipSuccess)
+        return bail(fail(e, ESMDIFF_E_HIP, "interleave_swiglu launch failed"));
+    }
+    TRY(load_bf16(e, t, b + "ffn.3.weight", {D, FH}, &ly.w_down));
+  }
+  TRY(load_f32(e, t, "transformer.norm.weight", {D}, &e->final_ln_w));
+  TRY(load_bf16(e, t, "output_heads.structure_head.0.weight", {D, D}, &e->head_w0));
+  TRY(load_f32(e, t, "output_heads.structure_head.0.bias", {D}, &e->head_b0));
+  TRY(load_f32(e, t, "output_heads.structure_head.2.weight", {D}, &e->head_ln_w));
+  TRY(load_f32(e, t, "output_heads.structure_head.2.bias", {D}, &e->head_ln_b));
+  e->vocab_pad = round_up(V, 128);
+  TRY(load_bf16(e, t, "output_heads.structure_head.3.weight", {V, D}, &e->head_w3, e->vocab_pad));
+  {
+    const esmdiff_weight* w;
+    TRY(need(e, t, "output_heads.structure_head.3.bias", {V}, &w));
+    TRY(dalloc(e, &e->head_b3, (size_t)e->vocab_pad, true));
+    if (launch_to_f32(w->data, w->dtype, e->head_b3, V, 0) != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "to_f32 failed"));
+  }
+  TRY(load_f32(e, t, "encoder.sequence_embed.weight", {64, D}, &e->e_seq));
+  TRY(load_f32(e, t, "encoder.structure_tokens_embed.weight", {ESMDIFF_VOCAB, D}, &e->e_struct));
+  if (cfg->time_conditioning) {
+    TRY(load_f32(e, t, "sigma_embedder.mlp.0.weight", {D, F}, &e->sig_w1));
+    TRY(load_f32(e, t, "sigma_embedder.mlp.0.bias", {D}, &e->sig_b1));
+    TRY(load_f32(e, t, "sigma_embedder.mlp.2.weight", {D, D}, &e->sig_w2));
+    TRY(load_f32(e, t, "sigma_embedder.mlp.2.bias", {D}, &e->sig_b2));
+  }
+  // constant vector of the defaulted tracks (net.py:410-431 -> esm EncodeInputs): average_plddt = 1,
+  // per_res_plddt = 0 through rbf(.,0,1,16) and a Linear(16,D); ss8 / sasa pad id 0; function and
+  // residue-annotation pads embed to zero (padding_idx=0).
+  {
+    float *pw, *pb, *sw, *sb, *ss8, *sasa;
+    TRY(load_f32(e, t, "encoder.plddt_projection.weight", {D, 16}, &pw));
+    TRY(load_f32(e, t, "encoder.plddt_projection.bias", {D}, &pb));
+    TRY(load_f32(e, t, "encoder.structure_per_res_plddt_projection.weight", {D, 16}, &sw));
+    TRY(load_f32(e, t, "encoder.structure_per_res_plddt_projection.bias", {D}, &sb));
+    TRY(load_f32(e, t, "encoder.ss8_embed.weight", {11, D}, &ss8));
+    TRY(load_f32(e, t, "encoder.sasa_embed.weight", {19, D}, &sasa));
+    if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "weight conversion failed: %s", hipGetErrorString(hipGetLastError())));
+    std::vector<float> hpw((size_t)D * 16), hsw((size_t)D * 16), hpb(D), hsb(D), hss8(D), hsasa(D), hc(D);
+    hipMemcpy(hpw.data(), pw, hpw.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(hsw.data(), sw, hsw.size() * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(hpb.data(), pb, D * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(hsb.data(), sb, D * 4, hipMemcpyDeviceToHost);
+    hipMemcpy(hss8.data(), ss8, D * 4, hipMemcpyDeviceToHost);   // row 0
+    hipMemcpy(hsasa.data(), sasa, D * 4, hipMemcpyDeviceToHost); // row 0
+    float rbf1[16], rbf0[16];
+    for (int i = 0; i < 16; ++i) {
+      const float center = (float)i / 15.0f, stdv = 1.0f / 16.0f;
+      const float z1 = (1.0f - center) / stdv, z0 = (0.0f - center) / stdv;
+      rbf1[i] = expf(-z1 * z1);
+      rbf0[i] = expf(-z0 * z0);
+    }
+    for (int d = 0; d < D; ++d) {
+      float a = hpb[d], b2 = hsb[d];
+      for (int i = 0; i < 16; ++i) {
+        a += hpw[(size_t)d * 16 + i] * rbf1[i];
+        b2 += hsw[(size_t)d * 16 + i] * rbf0[i];
+      }
+      hc[d] = ((a + b2) + hss8[d]) + hsasa[d];
+    }
+    TRY(dalloc(e, &e->cvec, (size_t)D));
+    hipMemcpy(e->cvec, hc.data(), D * 4, hipMemcpyHostToDevice);
+  }
+  // rotary tables: inv_freq = 10000^(-2i/64), positions 0..max_len-1 (BOS is position 0)
+  {
+    const int Lm = cfg->max_len;
+    std::vector<float> hc((size_t)Lm * 32), hs((size_t)Lm * 32);
+    for (int i = 0; i < 32; ++i) {
+      const float inv = 1.0f / powf(10000.0f, (float)(2 * i) / 64.0f);
+      for (int l = 0; l < Lm; ++l) {
+        const float ang = (float)l * inv;
+        hc[(size_t)l * 32 + i] = (float)cos((double)ang);
+        hs[(size_t)l * 32 + i] = (float)sin((double)ang);
+      }
+    }
+    TRY(dalloc(e, &e->rope_cos, hc.size()));
+    TRY(dalloc(e, &e->rope_sin, hs.size()));
+    hipMemcpy(e->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(e->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
+  }
+  // workspace
+  {
+    const size_t Mx = (size_t)cfg->max_batch * cfg->max_len;
+    e->Lp_max = round_up(cfg->max_len, 128);
+    const size_t hp = (size_t)cfg->max_batch * H * e->Lp_max * 64;
+    e->ld_logits = round_up(V, 4);
+    TRY(dalloc(e, &e->x, Mx * D));
+    TRY(dalloc(e, &e->h, Mx * D));
+    TRY(dalloc(e, &e->h2, Mx * D));
+    TRY(dalloc(e, &e->qkv, Mx * 3 * D));
+    TRY(dalloc(e, &e->q, hp, true));
+    TRY(dalloc(e, &e->k, hp, true));
+    TRY(dalloc(e, &e->vt, hp, true));
+    TRY(dalloc(e, &e->ctx, Mx * D));
+    TRY(dalloc(e, &e->mid, Mx * FH));
+    TRY(dalloc(e, &e->logits, Mx * e->ld_logits));
+    TRY(dalloc(e, &e->cond, (size_t)D));
+    TRY(dalloc(e, &e->sig_hidden, (size_t)D));
+    e->tfreq_rows = 1026;
+    TRY(dalloc(e, &e->tfreq, (size_t)e->tfreq_rows * F));
+  }
+#undef TRY
+  if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "engine create: %s", hipGetErrorString(hipGetLastError())));
+  *out = e;
+  return 0;
+}
+
+int esmdiff_forward_logits(esmdiff_engine* e, const int64_t* seq, const int64_t* x, const float* t_freq,
+                           float* logits_out, int32_t ld_logits, int32_t B, int32_t L, void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!seq || !x || !logits_out) return fail(e, ESMDIFF_E_INVALID, "null pointer");
+  if (ld_logits < e->cfg.vocab_out || (ld_logits & 3)) return fail(e, ESMDIFF_E_INVALID, "ld_logits (%d) must be >= vocab (%d) rounded up to a multiple of 4", ld_logits, e->cfg.vocab_out);
+  if (int r = check_bl(e, B, L)) return r;
+  int r = forward(e, seq, x, t_freq, logits_out, ld_logits, B, L, (hipStream_t)stream);
+  if (e->profiling) prof_collect(e);
+  return r;
+}
+
+int esmdiff_ddpm_step(esmdiff_engine* e, int64_t* x_inout, const float* logits, int32_t ld_logits,
+                      float mc_t, float mc_s, int32_t final_, const float* u, const esmdiff_rng* rng,
+                      int32_t step, int32_t B, int32_t L, void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!x_inout || !logits) return fail(e, ESMDIFF_E_INVALID, "null pointer");
+  if (!final_ && !u && !rng) return fail(e, ESMDIFF_E_INVALID, "need explicit uniforms or an rng");
+  if (B <= 0 || L <= 0 || ld_logits < e->cfg.vocab_out) return fail(e, ESMDIFF_E_INVALID, "bad shape");
+  Prof p{e, (hipStream_t)stream};
+  p.mark(S_SAMPLER);
+  HIP_TRY(e, launch_ddpm_step(x_inout, logits, ld_logits, e->cfg.vocab_out, mc_t, mc_s, final_, u, u ? 0 : 1,
+                              rng ? rng->seed : 0, rng ? rng->sample_offset : 0, step, B, L, (hipStream_t)stream));
+  p.mark(S_SAMPLER);
+  if (e->profiling) prof_collect(e);
+  return 0;
+}
+
+int esmdiff_ddpm_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout, int32_t B, int32_t L, int32_t T,
+                        const float* mc_t, const float* mc_s, const float* t_freq, const esmdiff_rng* rng,
+                        void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!seq || !x_inout || !mc_t || !mc_s || !rng) return fail(e, ESMDIFF_E_INVALID, "null pointer");
+  if (T <= 0 || T + 1 > e->tfreq_rows) return fail(e, ESMDIFF_E_INVALID, "num_steps %d out of range (1..%d)", T, e->tfreq_rows - 1);
+  if (e->cfg.time_conditioning && !t_freq) return fail(e, ESMDIFF_E_INVALID, "t_freq required with time conditioning");
+  if (int r = check_bl(e, B, L)) return r;
+  hipStream_t st = (hipStream_t)stream;
+  const int F = e->cfg.freq_dim;
+  if (t_freq) HIP_TRY(e, hipMemcpyAsync(e->tfreq, t_freq, (size_t)(T + 1) * F * sizeof(float), hipMemcpyHostToDevice, st));
+  Prof p{e, st};
+  for (int i = 0; i <= T; ++i) {
+    if (int r = forward(e, seq, x_inout, t_freq ? e->tfreq + (size_t)i * F : nullptr, e->logits, e->ld_logits, B, L, st)) return r;
+    const int fin = i == T;
+    p.mark(S_SAMPLER);
+    HIP_TRY(e, launch_ddpm_step(x_inout, e->logits, e->ld_logits, e->cfg.vocab_out, fin ? 0.f : mc_t[i], fin ? 0.f : mc_s[i],
+                                fin, nullptr, 1, rng->seed, rng->sample_offset, i, B, L, st));
+    p.mark(S_SAMPLER);
+    if (e->profiling) prof_collect(e);
+  }
+  return 0;
+}
+
+int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N, int32_t K,
+                      int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream) {
+  if (!A || !W || !out) return ESMDIFF_E_INVALID;
+  hipError_t s = launch_gemm_bf16((const bf16_t*)A, (const bf16_t*)W, out, bias, M, N, K, ldc, n_valid, alpha, epilogue,
+                                  (hipStream_t)stream);
+  if (s != hipSuccess) return fail(nullptr, s == hipErrorInvalidValue ? ESMDIFF_E_INVALID : ESMDIFF_E_HIP, "gemm: %s", hipGetErrorString(s));
+  return 0;
+}
+
+int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N,
+                            int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, int32_t iters,
+                            float* ms_out, void* stream) {
+  if (!ms_out || iters <= 0) return ESMDIFF_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  int r = esmdiff_gemm_bf16(A, W, out, bias, M, N, K, ldc, n_valid, alpha, epilogue, stream);  // warm-up
+  hipEventRecord(a, st);
+  for (int i = 0; i < iters && r == 0; ++i) r = esmdiff_gemm_bf16(A, W, out, bias, M, N, K, ldc, n_valid, alpha, epilogue, stream);
+  hipEventRecord(b, st);
+  hipEventSynchronize(b);
+  float ms = 0;
+  hipEventElapsedTime(&ms, a, b);
+  *ms_out = ms / iters;
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  return r;
+}
+
+int esmdiff_layernorm_bf16(const float* x, const float* w, const float* b, void* y, int32_t M, int32_t D, void* stream) {
+  if (!x || !w || !y) return ESMDIFF_E_INVALID;
+  hipError_t s = launch_layernorm_bf16(x, w, b, (bf16_t*)y, M, D, (hipStream_t)stream);
+  if (s != hipSuccess) return fail(nullptr, ESMDIFF_E_HIP, "layernorm: %s", hipGetErrorString(s));
+  return 0;
+}
+
+int esmdiff_attention_bf16(esmdiff_engine* e, const void* qkv, const float* q_ln_w, const float* k_ln_w, void* ctx,
+                           int32_t B, int32_t L, void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!qkv || !q_ln_w || !k_ln_w || !ctx) return fail(e, ESMDIFF_E_INVALID, "null pointer");
+  if (int r = check_bl(e, B, L)) return r;
+  const int Lp = round_up(L, 128);
+  HIP_TRY(e, launch_qk_norm_rope((const bf16_t*)qkv, q_ln_w, k_ln_w, e->rope_cos, e->rope_sin, e->q, e->k, e->vt, B, L, Lp,
+                                 e->cfg.n_heads, (hipStream_t)stream));
+  HIP_TRY(e, launch_attention(e->q, e->k, e->vt, (bf16_t*)ctx, B, L, Lp, e->cfg.n_heads, (hipStream_t)stream));
+  return 0;
+}
+
+int esmdiff_set_profiling(esmdiff_engine* e, int32_t on) {
+  if (!e) return ESMDIFF_E_INVALID;
+  e->profiling = on != 0;
+  e->ev_used = 0;
+  memset(e->prof_ms, 0, sizeof e->prof_ms);
+  memset(e->prof_launches, 0, sizeof e->prof_launches);
+  return 0;
+}
+
+int esmdiff_get_profile(esmdiff_engine* e, float* ms_out, int32_t* launches_out) {
+  if (!e || !ms_out || !launches_out) return ESMDIFF_E_INVALID;
+  prof_collect(e);
+  memcpy(ms_out, e->prof_ms, sizeof e->prof_ms);
+  memcpy(launches_out, e->prof_launches, sizeof e->prof_launches);
+  return 0;
+}
+
+}  // extern "C"

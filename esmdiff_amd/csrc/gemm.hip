@@ -1,0 +1,230 @@
+// gemm.hip — bf16 MFMA GEMM for gfx950 with fused epilogues:  out = epi(A[M,K] · W[N,K]^T).
+//
+// These are the linears of the ESM3 block the reference reaches through esm's TransformerStack
+// (/root/reference/slm/models/net.py:339-346, :468) and of RegressionHead (net.py:301): QKV, attention
+// out-projection, SwiGLU FFN up/down, and the 4101-way structure head.  The reference runs them as
+// separate cuBLAS/rocBLAS GEMMs followed by separate elementwise kernels (residual add and scale,
+// SwiGLU, GELU, bias); here each epilogue is fused into the GEMM that produces its input.
+//
+// Both operands are K-contiguous (activations [M,K], nn.Linear weights [N,K]), which is exactly the
+// MFMA fragment shape: every lane's A and B fragment is 8 contiguous bf16 (one 16-byte LDS read).
+//
+// Tile: 128(M) x 128(N) x 64(K), 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 tiles of
+// v_mfma_f32_32x32x16_bf16.  Staging: global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+// wave instruction = 8 tile rows), double buffered, next tile issued before the current tile's MFMAs.
+// LDS image: rows of 128 B (8 chunks of 16 B).  LDS-DMA writes lane-linear, so the bank-conflict
+// swizzle is applied to the per-lane SOURCE address and again on the fragment read
+// (chunk' = chunk ^ ((row >> 1) & 7)): the 16 lanes of every ds_read_b128 group then hit 16 distinct
+// 16-byte slots of the 256-byte bank row (conflict free for the 32x32x16 fragment pattern).
+// Epilogue: accumulators go through the (now idle) LDS so that global stores are whole 128/256-byte
+// row segments instead of 2-4 byte scatters.
+// Grid: one workgroup per tile, XCD-aware (block b runs on XCD b%8, so each XCD is given a contiguous
+// run of tiles) and rasterised in 8x8 super-tiles so the 64 tiles resident on an XCD share 8 A panels
+// and 8 W panels in that XCD's L2.
+#include "kernels.h"
+
+namespace ed {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+constexpr int GROUP_M = 8;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  // round-to-nearest-even f32 -> bf16 (finite inputs)
+  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
+  ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
+  return ua | (ub << 16);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
+                                                           const bf16_t* __restrict__ W, void* __restrict__ out,
+                                                           const float* __restrict__ bias, int M, int N, int K,
+                                                           int ldc, int n_valid, float alpha, int tiles_m,
+                                                           int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
+
+  // ---- tile assignment: XCD-contiguous, 8x8 super-tile raster --------------------------------
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int per_group = GROUP_M * tiles_n;
+  const int grp = lin / per_group, in_grp = lin - grp * per_group;
+  const int gm0 = grp * GROUP_M;
+  const int gsz = min(GROUP_M, tiles_m - gm0);
+  const int mt = gm0 + in_grp % gsz, nt = in_grp / gsz;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- LDS-DMA source pointers (4 instructions per operand per wave per K-tile) ---------------
+  // instruction i covers tile rows (i*4 + wave)*8 .. +8 ; lane -> row + (lane>>3), 16-byte slot lane&7
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7);  // logical chunk stored at slot lane&7
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (i * 4 + wave) * 8 + srow;
+    const int am = min(m0 + r, M - 1);
+    a_src[i] = A + (int64_t)am * K + schunk * 8;
+    w_src[i] = W + (int64_t)(n0 + r) * K + schunk * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * (2 * TILE_BYTES);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      char* da = base + (i * 4 + wave) * 1024;
+      glds16(a_src[i] + kt * BK, da);
+      glds16(w_src[i] + kt * BK, da + TILE_BYTES);
+    }
+  };
+
+  // ---- fragment read offsets ------------------------------------------------------------------
+  const int frow = lane & 31, khalf = lane >> 5;
+  const int fsw = (frow >> 1) & 7;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    a_off[i] = (wm * 64 + i * 32 + frow) * 128;
+    b_off[i] = TILE_BYTES + (wn * 64 + i * 32 + frow) * 128;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int nk = K / BK;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* base = smem + cur * (2 * TILE_BYTES);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int coff = ((ks * 2 + khalf) ^ fsw) << 4;
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i] + coff);
+        b[i] = *reinterpret_cast<const bf16x8*>(base + b_off[i] + coff);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: registers -> this wave's LDS slab -> whole-row global stores -------------------
+  float* slab = reinterpret_cast<float*>(smem) + wave * (64 * 64);
+  constexpr int SW = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? 32 : 64;  // slab width in floats
+  const int ccol = lane & 31, rhalf = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if constexpr (EPI == ESMDIFF_EPI_SWIGLU_BF16) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+        const float g = acc[i][0][r], u = acc[i][1][r];
+        slab[row * SW + ccol] = (g / (1.0f + __expf(-g))) * u;  // silu(gate) * up
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+          slab[row * SW + j * 32 + ccol] = acc[i][j][r];
+        }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // own LDS writes done (slab is private to the wave)
+  __builtin_amdgcn_wave_barrier();
+
+  constexpr int LPR = SW / 4;            // lanes per row (float4 each)
+  constexpr int RPI = 64 / LPR;          // rows per iteration
+  const int rr_ = lane / LPR, c4 = (lane % LPR) * 4;
+  const int ncol0 = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? (n0 + wn * 64) / 2 : (n0 + wn * 64);
+#pragma unroll 4
+  for (int it = 0; it < 64 / RPI; ++it) {
+    const int row = it * RPI + rr_;
+    const int m = m0 + wm * 64 + row;
+    if (m >= M) continue;
+    f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * SW + c4);
+    const int n = ncol0 + c4;
+    if constexpr (EPI == ESMDIFF_EPI_BF16 || EPI == ESMDIFF_EPI_SWIGLU_BF16) {
+      uint2 p;
+      p.x = pack_bf16x2(v[0], v[1]);
+      p.y = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = p;
+    } else if constexpr (EPI == ESMDIFF_EPI_RESID_F32) {
+      float* o = reinterpret_cast<float*>(out) + (int64_t)m * ldc + n;
+      f32x4 x = *reinterpret_cast<const f32x4*>(o);
+      x[0] += v[0] * alpha; x[1] += v[1] * alpha; x[2] += v[2] * alpha; x[3] += v[3] * alpha;
+      *reinterpret_cast<f32x4*>(o) = x;
+    } else if constexpr (EPI == ESMDIFF_EPI_BIAS_GELU_BF16) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
+      uint2 p;
+      p.x = pack_bf16x2(gelu_erf(v[0] + bb[0]), gelu_erf(v[1] + bb[1]));
+      p.y = pack_bf16x2(gelu_erf(v[2] + bb[2]), gelu_erf(v[3] + bb[3]));
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = p;
+    } else {  // ESMDIFF_EPI_BIAS_F32
+      if (n + 4 <= ldc) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
+        f32x4 x;
+        x[0] = v[0] + bb[0]; x[1] = v[1] + bb[1]; x[2] = v[2] + bb[2]; x[3] = v[3] + bb[3];
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (int64_t)m * ldc + n) = x;
+      }
+    }
+  }
+  (void)n_valid;
+}
+
+hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
+                            int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  if (N % BN != 0 || K % BK != 0 || (ldc & 3)) return hipErrorInvalidValue;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+  dim3 grid(tiles_m * tiles_n), block(256);
+  const size_t lds = 4 * TILE_BYTES;
+#define ED_GEMM(E)                                                                                          \
+  hipLaunchKernelGGL(gemm_bf16_kernel<E>, grid, block, lds, stream, A, W, out, bias, M, N, K, ldc, n_valid, \
+                     alpha, tiles_m, tiles_n)
+  switch (epilogue) {
+    case ESMDIFF_EPI_BF16: ED_GEMM(ESMDIFF_EPI_BF16); break;
+    case ESMDIFF_EPI_RESID_F32: ED_GEMM(ESMDIFF_EPI_RESID_F32); break;
+    case ESMDIFF_EPI_SWIGLU_BF16: ED_GEMM(ESMDIFF_EPI_SWIGLU_BF16); break;
+    case ESMDIFF_EPI_BIAS_GELU_BF16: ED_GEMM(ESMDIFF_EPI_BIAS_GELU_BF16); break;
+    case ESMDIFF_EPI_BIAS_F32: ED_GEMM(ESMDIFF_EPI_BIAS_F32); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef ED_GEMM
+  return hipGetLastError();
+}
+
+}  // namespace ed

@@ -37,7 +37,7 @@ hipError_t launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, 
 
 // ---- embed.hip -------------------------------------------------------------------------------
 // x[b,l,:] = E_seq[seq] + E_struct[struct'] + c + cond   (net.py:445-466)
-hipError_t launch_embed(const int64_t* seq, const int64_t* xtok, const bf16_t* e_seq, const bf16_t* e_struct,
+hipError_t launch_embed(const int64_t* seq, const int64_t* xtok, const float* e_seq, const float* e_struct,
                         const float* cvec, const float* cond, float* out, int B, int L, int D,
                         hipStream_t stream);
 // cond = W2 · silu(W1 · t_freq + b1) + b2   (net.py:489-492,519-522), f32

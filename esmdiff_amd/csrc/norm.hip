@@ -1,0 +1,255 @@
+// norm.hip — row-wise kernels between the GEMMs (gfx950).  All HBM-bound; one wave64 per token row,
+// 16-byte loads, the row lives in registers between the statistics pass and the write.
+//
+//   layernorm_bf16        LayerNorm(D)[weight(+bias)] of the f32 residual stream -> bf16 GEMM operand
+//                         (esm UnifiedTransformerBlock: attn.layernorm_qkv.0, ffn.0; TransformerStack.norm;
+//                          constructed at /root/reference/slm/models/net.py:339-346)
+//   layernorm_bf16_in     same on a bf16 input (RegressionHead's LayerNorm after GELU, net.py:301)
+//   qk_norm_rope          full-width (D) LayerNorm of q and of k (attn.q_ln / attn.k_ln, no bias), rotary
+//                         (rotate-half, base 10000) per 64-wide head, q pre-scaled by log2(e)/sqrt(64);
+//                         writes head-major q,k [B,H,Lp,64]
+//   v_transpose           v part of the QKV GEMM output -> vt [B,H,64,Lp] (keys contiguous) so that the
+//                         attention kernel's PV MFMA A-operand is a straight 8-byte LDS read
+#include "kernels.h"
+
+namespace ed {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f2bf(float a) {
+  uint32_t u = __float_as_uint(a);
+  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: NV = ceil(D / 256) float4 per lane; D % 4 == 0.
+template <int NV, bool IN_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ xin, const float* __restrict__ w,
+                                                        const float* __restrict__ b, bf16_t* __restrict__ y, int M,
+                                                        int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < D) {
+      if constexpr (IN_BF16) {
+        const uint2 p = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(xin) + (int64_t)row * D + c);
+        v[j][0] = bf2f(p.x & 0xffffu); v[j][1] = bf2f(p.x >> 16);
+        v[j][2] = bf2f(p.y & 0xffffu); v[j][3] = bf2f(p.y >> 16);
+      } else {
+        v[j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(xin) + (int64_t)row * D + c);
+      }
+      s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    } else {
+      v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wsum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[j][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wsum(q) / (float)D + 1e-5f);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < D) {
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * ww[e];
+      if (b) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += bb[e];
+      }
+      uint2 p;
+      p.x = pack2(o[0], o[1]);
+      p.y = pack2(o[2], o[3]);
+      *reinterpret_cast<uint2*>(y + (int64_t)row * D + c) = p;
+    }
+  }
+}
+
+template <bool IN_BF16>
+static hipError_t launch_ln(const void* x, const float* w, const float* b, bf16_t* y, int M, int D,
+                            hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  if (D % 4 != 0 || D > 2048) return hipErrorInvalidValue;
+  const int nv = (D + 255) / 256;
+  dim3 grid((M + 3) / 4), block(256);
+#define ED_LN(N) hipLaunchKernelGGL((layernorm_kernel<N, IN_BF16>), grid, block, 0, stream, x, w, b, y, M, D)
+  switch (nv) {
+    case 1: ED_LN(1); break;
+    case 2: ED_LN(2); break;
+    case 3: ED_LN(3); break;
+    case 4: ED_LN(4); break;
+    case 5: ED_LN(5); break;
+    case 6: ED_LN(6); break;
+    case 7: ED_LN(7); break;
+    default: ED_LN(8); break;
+  }
+#undef ED_LN
+  return hipGetLastError();
+}
+
+hipError_t launch_layernorm_bf16(const float* x, const float* w, const float* b, bf16_t* y, int M, int D,
+                                 hipStream_t stream) {
+  return launch_ln<false>(x, w, b, y, M, D, stream);
+}
+hipError_t launch_layernorm_bf16_in(const bf16_t* x, const float* w, const float* b, bf16_t* y, int M, int D,
+                                    hipStream_t stream) {
+  return launch_ln<true>(x, w, b, y, M, D, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// q/k LayerNorm + rotary.  One wave per token; lane holds 8 contiguous columns per 512-column slab
+// (16-byte loads), NS = D / 512 slabs.  A head is 64 columns = 8 lanes; the rotate-half partner of
+// column offset o is o +/- 32, i.e. lane ^ 4.
+template <int NS>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restrict__ qkv,
+                                                           const float* __restrict__ q_w,
+                                                           const float* __restrict__ k_w,
+                                                           const float* __restrict__ rope_cos,
+                                                           const float* __restrict__ rope_sin,
+                                                           bf16_t* __restrict__ qo, bf16_t* __restrict__ ko, int B,
+                                                           int L, int Lp, int H) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= B * L) return;
+  const int D = H * 64;
+  const int b = tok / L, l = tok - b * L;
+  const float qscale = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e): softmax in base 2
+
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    const bf16_t* src = qkv + (int64_t)tok * (3 * D) + which * D;
+    const float* w = which ? k_w : q_w;
+    float v[NS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const uint4 p = *reinterpret_cast<const uint4*>(src + j * 512 + lane * 8);
+      const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[j][2 * e] = bf2f(pw[e] & 0xffffu);
+        v[j][2 * e + 1] = bf2f(pw[e] >> 16);
+        s += v[j][2 * e] + v[j][2 * e + 1];
+      }
+    }
+    const float mean = wsum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NS; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[j][e] - mean;
+        q += d * d;
+      }
+    const float rstd = rsqrtf(wsum(q) / (float)D + 1e-5f);
+    const int o = (lane & 7) * 8;          // column offset inside the head
+    const int fi = o & 31;                 // rotary frequency index of element 0
+    const bool second = o >= 32;
+    bf16_t* dst = which ? ko : qo;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      const int c0 = j * 512 + lane * 8;
+      const int h = c0 >> 6;
+      float n[8], r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) n[e] = (v[j][e] - mean) * rstd * w[c0 + e];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float partner = __shfl_xor(n[e], 4, 64);
+        const float cs = rope_cos[l * 32 + fi + e], sn = rope_sin[l * 32 + fi + e];
+        // rotate_half: first half gets -x2, second half gets +x1
+        r[e] = second ? (n[e] * cs + partner * sn) : (n[e] * cs - partner * sn);
+        if (which == 0) r[e] *= qscale;
+      }
+      uint4 p;
+      p.x = pack2(r[0], r[1]); p.y = pack2(r[2], r[3]); p.z = pack2(r[4], r[5]); p.w = pack2(r[6], r[7]);
+      *reinterpret_cast<uint4*>(dst + (((int64_t)b * H + h) * Lp + l) * 64 + o) = p;
+    }
+  }
+}
+
+// vt[b,h,d,l] = qkv[b*L + l, 2D + h*64 + d];  block = one (b,h) x 64 tokens, 64x64 transpose through LDS.
+__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt,
+                                                          int L, int Lp, int H) {
+  __shared__ bf16_t tile[64][72];  // [token][d], +8 pad
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int l0 = blockIdx.x * 64;
+  const int D = H * 64;
+  const int tid = threadIdx.x;
+  // load: 64 tokens x 128 B; thread -> token tid>>2, 32-byte piece tid&3
+  {
+    const int t = tid >> 2, piece = tid & 3;
+    uint4 a = {0, 0, 0, 0}, c = {0, 0, 0, 0};
+    if (l0 + t < L) {
+      const bf16_t* src = qkv + ((int64_t)b * L + l0 + t) * (3 * D) + 2 * D + h * 64 + piece * 16;
+      a = *reinterpret_cast<const uint4*>(src);
+      c = *reinterpret_cast<const uint4*>(src + 8);
+    }
+    *reinterpret_cast<uint4*>(&tile[t][piece * 16]) = a;
+    *reinterpret_cast<uint4*>(&tile[t][piece * 16 + 8]) = c;
+  }
+  __syncthreads();
+  // store: 64 d-rows x 128 B; thread -> d = tid>>2, 16 tokens tid&3
+  {
+    const int d = tid >> 2, piece = tid & 3;
+    uint32_t o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t lo = tile[piece * 16 + 2 * e][d], hi = tile[piece * 16 + 2 * e + 1][d];
+      o[e] = lo | (hi << 16);
+    }
+    bf16_t* dst = vt + (((int64_t)b * H + h) * 64 + d) * Lp + l0 + piece * 16;
+    *reinterpret_cast<uint4*>(dst) = uint4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<uint4*>(dst + 8) = uint4{o[4], o[5], o[6], o[7]};
+  }
+}
+
+hipError_t launch_qk_norm_rope(const bf16_t* qkv, const float* q_ln_w, const float* k_ln_w,
+                               const float* rope_cos, const float* rope_sin, bf16_t* q, bf16_t* k, bf16_t* vt,
+                               int B, int L, int Lp, int H, hipStream_t stream) {
+  const int D = H * 64, M = B * L;
+  if (M <= 0) return hipSuccess;
+  if (D % 512 != 0 || D > 2048 || Lp % 64 != 0) return hipErrorInvalidValue;
+  dim3 grid((M + 3) / 4), block(256);
+#define ED_QK(N) \
+  hipLaunchKernelGGL(qk_norm_rope_kernel<N>, grid, block, 0, stream, qkv, q_ln_w, k_ln_w, rope_cos, rope_sin, q, k, B, L, Lp, H)
+  switch (D / 512) {
+    case 1: ED_QK(1); break;
+    case 2: ED_QK(2); break;
+    case 3: ED_QK(3); break;
+    default: ED_QK(4); break;
+  }
+#undef ED_QK
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  dim3 g2((L + 63) / 64, B * H);
+  hipLaunchKernelGGL(v_transpose_kernel, g2, block, 0, stream, qkv, vt, L, Lp, H);
+  return hipGetLastError();
+}
+
+}  // namespace ed

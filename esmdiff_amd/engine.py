@@ -1,0 +1,207 @@
+"""Python host side of the C ABI (include/esmdiff_hip.h): owns an esmdiff_engine and exposes the call
+sites of the reference's hot path with PyTorch-ROCm tensors as plain device-memory containers.
+
+  Engine.forward_logits  <- self.net(...).structure_logits           model.py:475-481
+  Engine.ddpm_step       <- _ddpm_update's sampling half              model.py:583-607, 24-28
+  Engine.ddpm_sample     <- MaskedDiffusionLanguageModeling.ddpm_sample  model.py:543-581
+(paths relative to /root/reference/slm/models)
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _native as N
+from .config import ModelConfig
+from .constants import STRUCTURE_MASK_TOKEN, STRUCTURE_VOCAB
+from .schedule import DDPMSchedule
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("esmdiff_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False and "
+                           "there is no CPU fallback")
+
+
+class Engine:
+    """One engine per (process, device).  Not thread-safe.  All work is enqueued on torch's current stream."""
+
+    def __init__(self, cfg: ModelConfig, state_dict: Dict[str, torch.Tensor], max_batch: int, max_len: int,
+                 device: int = 0):
+        _require_gpu()
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self.max_batch, self.max_len = max_batch, max_len
+        self._lib = N.lib()
+        self._h = ctypes.c_void_p(0)
+        c = N.Config(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden, cfg.n_structure_heads, cfg.freq_dim,
+                     max_batch, max_len, cfg.residue_scale, int(cfg.time_conditioning))
+        # upload the caller's tensors (any float dtype) as device containers; the engine makes its own
+        # bf16 / re-laid-out copies, after which these are released.
+        keep, table = [], (N.Weight * len(state_dict))()
+        with torch.cuda.device(self.device):
+            for i, (name, t) in enumerate(state_dict.items()):
+                if t.dtype not in (torch.float32, torch.bfloat16):
+                    t = t.float()
+                d = t.detach().to(self.device).contiguous()
+                keep.append(d)
+                shape = (ctypes.c_int64 * 4)(*(list(d.shape) + [0] * (4 - d.dim())))
+                table[i] = N.Weight(name.encode(), d.data_ptr(), N.DT_F32 if d.dtype == torch.float32 else N.DT_BF16,
+                                    d.dim(), shape)
+            torch.cuda.synchronize()
+            code = self._lib.esmdiff_engine_create(ctypes.byref(c), table, len(state_dict), device,
+                                                   ctypes.byref(self._h))
+        if code != 0:
+            raise RuntimeError(f"esmdiff_engine_create failed ({code}): "
+                               f"{self._lib.esmdiff_last_error(None).decode()}")
+        del keep
+        self.ld_logits = (cfg.n_structure_heads + 3) // 4 * 4
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.esmdiff_engine_destroy(self._h)
+            self._h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def _chk(self, code):
+        N.check(code, self._h)
+
+    def _tok(self, t: torch.Tensor, B: int, L: int) -> torch.Tensor:
+        t = t.to(device=self.device, dtype=torch.int64)
+        if t.dim() == 1:
+            t = t[None].expand(B, L)
+        return t.contiguous()
+
+    def forward_logits(self, x: torch.Tensor, sequence_tokens: torch.Tensor, t_freq: Optional[torch.Tensor],
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x, sequence_tokens: (B,L) int64.  t_freq: (freq_dim,) f32 sinusoid of sigma, or None.
+        Returns raw structure logits, a (B,L,4101) view of a (B,L,ld) float32 buffer."""
+        B, L = x.shape
+        x = self._tok(x, B, L)
+        seq = self._tok(sequence_tokens, B, L)
+        if out is None:
+            out = torch.empty(B, L, self.ld_logits, dtype=torch.float32, device=self.device)
+        tf = None if t_freq is None else t_freq.to(device=self.device, dtype=torch.float32).contiguous()
+        self._chk(self._lib.esmdiff_forward_logits(self._h, _ptr(seq), _ptr(x), _ptr(tf), _ptr(out), out.shape[-1],
+                                                   B, L, _stream()))
+        return out[..., :self.cfg.n_structure_heads]
+
+    def ddpm_step(self, x: torch.Tensor, logits: torch.Tensor, mc_t: float, mc_s: float, *, final: bool = False,
+                  u: Optional[torch.Tensor] = None, seed: Optional[int] = None, sample_offset: int = 0,
+                  step: int = 0) -> torch.Tensor:
+        """In-place update of x (B,L) int64 from RAW logits (B,L,>=4101) float32 (last dim may be a strided
+        view of a padded buffer).  Noise: explicit `u` (B,L,4101) or Philox(seed, sample_offset, step)."""
+        B, L = x.shape
+        assert x.dtype == torch.int64 and x.is_cuda and x.is_contiguous()
+        assert logits.dtype == torch.float32 and logits.is_cuda and logits.stride(-1) == 1
+        ld = logits.stride(1)
+        assert logits.stride(0) == ld * L and ld >= STRUCTURE_VOCAB
+        rng = None
+        if u is not None:
+            u = u.to(device=self.device, dtype=torch.float32).contiguous()
+            assert u.shape == (B, L, STRUCTURE_VOCAB)
+        elif not final:
+            if seed is None:
+                raise ValueError("ddpm_step needs explicit uniforms `u` or a Philox `seed`")
+        if seed is not None:
+            rng = N.Rng(int(seed), int(sample_offset))
+        self._chk(self._lib.esmdiff_ddpm_step(self._h, _ptr(x), _ptr(logits), ld, float(mc_t), float(mc_s),
+                                              int(final), _ptr(u), ctypes.byref(rng) if rng else None, int(step),
+                                              B, L, _stream()))
+        return x
+
+    def ddpm_sample(self, sequence_tokens: torch.Tensor, schedule: DDPMSchedule, *, seed: int,
+                    sample_offset: int = 0, input_prior: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Whole ancestral sampling loop on the device with Philox noise (esmdiff_ddpm_sample)."""
+        B, L = sequence_tokens.shape
+        seq = self._tok(sequence_tokens, B, L)
+        if input_prior is None:
+            x = torch.full((B, L), STRUCTURE_MASK_TOKEN, dtype=torch.int64, device=self.device)
+        else:
+            if tuple(input_prior.shape) != (B, L):
+                raise ValueError(f"Invalid input_prior shape: {tuple(input_prior.shape)} v.s. (seq) {(B, L)}")
+            x = input_prior.to(device=self.device, dtype=torch.int64).contiguous().clone()
+        T = schedule.num_steps
+        f32 = lambda t: t.detach().to("cpu", torch.float32).contiguous()
+        mc_t, mc_s, tf = f32(schedule.mc_t[:T]), f32(schedule.mc_s[:T]), f32(schedule.t_freq)
+        rng = N.Rng(int(seed), int(sample_offset))
+        as_p = lambda t: t.numpy().ctypes.data_as(N.c_f32p)
+        self._chk(self._lib.esmdiff_ddpm_sample(self._h, _ptr(seq), _ptr(x), B, L, T, as_p(mc_t), as_p(mc_s),
+                                                as_p(tf) if self.cfg.time_conditioning else None,
+                                                ctypes.byref(rng), _stream()))
+        return x
+
+    # ---- per-kernel entry points (parity tests / roofline bench) ---------------------------------
+    def set_profiling(self, on: bool):
+        self._chk(self._lib.esmdiff_set_profiling(self._h, int(on)))
+
+    def get_profile(self) -> Dict[str, Dict[str, float]]:
+        ms = (ctypes.c_float * 16)()
+        n = (ctypes.c_int32 * 16)()
+        self._chk(self._lib.esmdiff_get_profile(self._h, ms, n))
+        return {s: {"ms": float(ms[i]), "launches": int(n[i])} for i, s in enumerate(N.SECTIONS)}
+
+    def attention(self, qkv: torch.Tensor, q_ln_w: torch.Tensor, k_ln_w: torch.Tensor, B: int, L: int) -> torch.Tensor:
+        D = self.cfg.d_model
+        assert qkv.dtype == torch.bfloat16 and qkv.shape == (B * L, 3 * D) and qkv.is_contiguous()
+        ctx = torch.empty(B * L, D, dtype=torch.bfloat16, device=self.device)
+        self._chk(self._lib.esmdiff_attention_bf16(self._h, _ptr(qkv), _ptr(q_ln_w.float().contiguous()),
+                                                   _ptr(k_ln_w.float().contiguous()), _ptr(ctx), B, L, _stream()))
+        return ctx
+
+
+def gemm_bf16(A: torch.Tensor, W: torch.Tensor, epilogue: int, *, out: Optional[torch.Tensor] = None,
+              bias: Optional[torch.Tensor] = None, alpha: float = 1.0, n_valid: Optional[int] = None) -> torch.Tensor:
+    """out = epilogue(A[M,K] @ W[N,K]^T) through esmdiff_gemm_bf16 (N % 128 == 0, K % 64 == 0)."""
+    _require_gpu()
+    M, K = A.shape
+    Nn = W.shape[0]
+    assert A.dtype == W.dtype == torch.bfloat16 and A.is_contiguous() and W.is_contiguous() and W.shape[1] == K
+    if out is None:
+        if epilogue in (N.EPI_BF16, N.EPI_BIAS_GELU_BF16):
+            out = torch.empty(M, Nn, dtype=torch.bfloat16, device=A.device)
+        elif epilogue == N.EPI_SWIGLU_BF16:
+            out = torch.empty(M, Nn // 2, dtype=torch.bfloat16, device=A.device)
+        else:
+            raise ValueError("f32 epilogues need an explicit `out`")
+    ldc = out.stride(0)
+    N.check(N.lib().esmdiff_gemm_bf16(_ptr(A), _ptr(W), _ptr(out), _ptr(bias), M, Nn, K, ldc,
+                                      Nn if n_valid is None else n_valid, float(alpha), epilogue, _stream()))
+    return out
+
+
+def gemm_bf16_timed(A, W, out, epilogue, iters=20, bias=None, alpha=1.0) -> float:
+    """Average milliseconds per launch, HIP events on the launch stream (esmdiff_gemm_bf16_timed)."""
+    _require_gpu()
+    M, K = A.shape
+    ms = ctypes.c_float(0)
+    N.check(N.lib().esmdiff_gemm_bf16_timed(_ptr(A), _ptr(W), _ptr(out), _ptr(bias), M, W.shape[0], K,
+                                            out.stride(0), W.shape[0], float(alpha), epilogue, iters,
+                                            ctypes.byref(ms), _stream()))
+    return float(ms.value)
+
+
+def layernorm_bf16(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    _require_gpu()
+    M, D = x.shape
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    N.check(N.lib().esmdiff_layernorm_bf16(_ptr(x.float().contiguous()), _ptr(w.float().contiguous()),
+                                           _ptr(None if b is None else b.float().contiguous()), _ptr(y), M, D,
+                                           _stream()))
+    return y

@@ -1,0 +1,78 @@
+"""Weights: random initialisation with the reference's state-dict key layout, and checkpoint loading.
+
+Key layout: the ESMDiff checkpoint stores a DeepSpeed 'module' dict
+(/root/reference/slm/utils/checkpoint_utils.py:62-64) whose keys are `net.<esm3 key>` plus
+`sigma_embedder.mlp.{0,2}.{weight,bias}` (net.py:489-492).
+"""
+from __future__ import annotations
+
+import math
+from pathlib import Path
+from typing import Dict
+
+import torch
+
+from .config import ModelConfig
+
+
+def _linear(g, out_f, in_f, bias):
+    # nn.Linear default init: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(in), 1/sqrt(in)) for weight and bias
+    bound = 1.0 / math.sqrt(in_f)
+    w = (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound
+    b = (torch.rand(out_f, generator=g) * 2 - 1) * bound if bias else None
+    return w, b
+
+
+def random_init_state_dict(cfg: ModelConfig, seed: int = 0, prefix: str = "net.") -> Dict[str, torch.Tensor]:
+    """ESM3-architecture random weights (PyTorch default initialisers per layer type), float32, CPU.
+
+    LayerNorm weights are drawn around 1 (not exactly 1) and biases around 0 so that tests exercise them."""
+    g = torch.Generator().manual_seed(seed)
+    D, FH, V = cfg.d_model, cfg.ffn_hidden, cfg.n_structure_heads
+    sd: Dict[str, torch.Tensor] = {}
+
+    def ln(name, bias=True):
+        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(D, generator=g)
+        if bias:
+            sd[name + ".bias"] = 0.05 * torch.randn(D, generator=g)
+
+    e = prefix + "encoder."
+    sd[e + "sequence_embed.weight"] = torch.randn(64, D, generator=g)
+    sd[e + "structure_tokens_embed.weight"] = torch.randn(4096 + 5, D, generator=g)
+    sd[e + "ss8_embed.weight"] = torch.randn(8 + 3, D, generator=g)
+    sd[e + "sasa_embed.weight"] = torch.randn(16 + 3, D, generator=g)
+    for nm in ("plddt_projection", "structure_per_res_plddt_projection"):
+        w, b = _linear(g, D, 16, True)
+        sd[e + nm + ".weight"], sd[e + nm + ".bias"] = w, b
+    for i in range(cfg.n_layers):
+        b = f"{prefix}transformer.blocks.{i}."
+        ln(b + "attn.layernorm_qkv.0")
+        sd[b + "attn.layernorm_qkv.1.weight"] = _linear(g, 3 * D, D, False)[0]
+        sd[b + "attn.q_ln.weight"] = 1.0 + 0.1 * torch.randn(D, generator=g)
+        sd[b + "attn.k_ln.weight"] = 1.0 + 0.1 * torch.randn(D, generator=g)
+        sd[b + "attn.out_proj.weight"] = _linear(g, D, D, False)[0]
+        ln(b + "ffn.0")
+        sd[b + "ffn.1.weight"] = _linear(g, 2 * FH, D, False)[0]
+        sd[b + "ffn.3.weight"] = _linear(g, D, FH, False)[0]
+    sd[prefix + "transformer.norm.weight"] = 1.0 + 0.1 * torch.randn(D, generator=g)
+    h = prefix + "output_heads.structure_head."
+    sd[h + "0.weight"], sd[h + "0.bias"] = _linear(g, D, D, True)
+    ln(h + "2")
+    sd[h + "3.weight"], sd[h + "3.bias"] = _linear(g, V, D, True)
+    s = "sigma_embedder.mlp."
+    sd[s + "0.weight"], sd[s + "0.bias"] = _linear(g, D, cfg.freq_dim, True)
+    sd[s + "2.weight"], sd[s + "2.bias"] = _linear(g, D, D, True)
+    return sd
+
+
+def load_checkpoint_state_dict(path) -> Dict[str, torch.Tensor]:
+    """The reference's format (checkpoint_utils.py:41-64): a .pt whose 'module' entry is the state dict."""
+    path = Path(path)
+    if not path.exists():
+        raise FileNotFoundError(f"Checkpoint not found: {path}")
+    if path.suffix not in (".ckpt", ".pt"):
+        raise ValueError(f"Unsupported ckpt format: {path}")
+    if path.is_dir():
+        path = path / "checkpoint/mp_rank_00_model_states.pt"
+    blob = torch.load(path, map_location="cpu", weights_only=True)
+    return blob["module"] if "module" in blob else blob
