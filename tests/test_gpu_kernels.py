@@ -93,7 +93,9 @@ def test_sampler_full_size_config2(tiny):
     out0 = eng.ddpm_step(xs.clone(), z, 0.04, 0.0, seed=77, step=24).cpu()
     assert int((out0 == MASK).sum()) == 0          # q[MASK] = mc_s = 0 can never win
     fin = eng.ddpm_step(xs.clone(), z, 0.0, 0.0, final=True).cpu()
-    assert torch.equal(fin[:, 1], z[:, 1, :V].cpu()[..., :4096].argmax(-1))  # MASK column is -1e6
+    zz = z[:, 1, :V].cpu().clone()
+    zz[:, MASK] -= 1e6                                # only the MASK column is suppressed (model.py:528)
+    assert torch.equal(fin[:, 1], zz.argmax(-1))
 
 
 def test_sampler_golden_reference_ids(tiny, golden_dir):
@@ -200,9 +202,12 @@ def test_layernorm():
         x = (torch.randn(70, D, generator=g) * 3 + 0.5).cuda()
         w, b = torch.randn(D, generator=g).cuda(), torch.randn(D, generator=g).cuda()
         ref = torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
-        assert float((layernorm_bf16(x, w, b).float() - ref).abs().max()) < 3e-2   # bf16 output rounding
+        # f32 statistics; the only rounding is the bf16 store: |err| <= 2^-8 |ref| (+ f32 noise)
+        err = (layernorm_bf16(x, w, b).float() - ref).abs()
+        assert float((err - ref.abs() * 2 ** -8).max()) < 1e-4
         ref = torch.nn.functional.layer_norm(x, (D,), w, None, 1e-5)
-        assert float((layernorm_bf16(x, w, None).float() - ref).abs().max()) < 3e-2
+        err = (layernorm_bf16(x, w, None).float() - ref).abs()
+        assert float((err - ref.abs() * 2 ** -8).max()) < 1e-4
 
 
 @pytest.mark.parametrize("B,L", [(2, 60), (1, 258), (3, 130)])
