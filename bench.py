@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py — conformation samples/sec of the ESMDiff ancestral sampler on MI355X.
+
+One "step" = one pass of the hot path over one batch: `samples_per_gpu` independent conformations of a
+256-residue protein (L_tok = 258), 25 reverse-diffusion updates + the noise-removal pass = 26 forwards of
+the ESM3-open-sized (1.4 B parameter, random-init, bf16 MFMA) structure-token transformer plus 26 fused
+sampler launches (BASELINE.json configs[1]; reference loop: slm/models/model.py:543-581 driven by
+slm/sample_esmdiff.py:137-233).  Inputs (tokens, weights) are resident in HBM when the timed region starts.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (FFN-up GEMM, bf16 MFMA): algorithmic FLOP per launch / mean launch duration
+                measured with HIP events on the launch stream inside the timed region.
+  cpu_baseline  the oracle (torch-CPU float32 restatement, oracle/) timed on this box's host cores on a
+                bounded sample; kind = "port" (the reference's own Python cannot run here: esm==3.0.4 absent).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md: ~2.5 PF dense)
+
+
+def flops_forward_per_sample(L: int, cfg) -> float:
+    """2 FLOP/MAC; linears + attention per layer + head."""
+    D, FH, V = cfg.d_model, cfg.ffn_hidden, cfg.n_structure_heads
+    lin = 2 * D * 3 * D + 2 * D * D + 2 * D * 2 * FH + 2 * FH * D
+    attn = 4 * D * L     # QK^T + PV: 2 * 2 * L * 64 * heads
+    head = 2 * D * D + 2 * D * V
+    return L * (cfg.n_layers * (lin + attn) + head)
+
+
+def usable_cores() -> int:
+    """Host cores this process may really use: min(affinity, cgroup cpu quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(cfg, sd, L, T, seconds_budget=20.0):
+    """Oracle on the host cores: whole reverse-diffusion updates (f32 torch forward of the full network +
+    C-oracle sampler) at a small batch, extrapolated to samples/s for a (T+1)-forward run."""
+    from esmdiff_amd.schedule import ddpm_schedule
+    from oracle import c_oracle
+    from oracle.esm3_ref import build_from_state_dict
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    net, emb = build_from_state_dict(cfg, {k: v.cpu() for k, v in sd.items()})
+    sch = ddpm_schedule(T)
+    g = torch.Generator().manual_seed(0)
+    seq1 = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])
+    Bc = 2
+    x = torch.full((Bc, L), 4096, dtype=torch.int64)
+    seq = seq1[None].repeat(Bc, 1)
+    n, el, t0 = 0, 0.0, time.perf_counter()
+    while n < 6 and el < seconds_budget:
+        with torch.no_grad():
+            cond = torch.tile(emb(sch.sigma_t[0] * torch.ones(Bc))[:, None, :], (1, L, 1))
+            lg = net(structure_tokens=x, sequence_tokens=seq, auxiliary_embeddings=cond).structure_logits
+        c_oracle.ddpm_step(x.numpy(), lg.numpy(), sch.mc_t[0].item(), sch.mc_s[0].item(), seed=0, step=0)
+        n += 1
+        el = time.perf_counter() - t0
+    per_update = el / n
+    return {"value": Bc / (per_update * (T + 1)), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{n} whole reverse-diffusion update(s) (f32 torch forward of all {cfg.n_layers} blocks + C "
+                      f"sampler) at B={Bc}, L_tok={L}: {per_update:.2f} s each; samples/s = B / ({T + 1} x that)",
+            "cpu_count": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--samples-per-gpu", type=int, default=100)
+    ap.add_argument("--residues", type=int, default=256)
+    ap.add_argument("--num-steps", type=int, default=25)
+    ap.add_argument("--tiny", action="store_true", help="small model (debug only; prints data=debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from esmdiff_amd.config import ESM3_OPEN, TINY
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+
+    cfg = TINY if args.tiny else ESM3_OPEN
+    B, L, T = args.samples_per_gpu, args.residues + 2, args.num_steps
+    sd = random_init_state_dict(cfg, seed=args.seed, device=str(dev))   # same weights on every rank (GPU generator)
+    eng = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank)
+    g = torch.Generator().manual_seed(args.seed)
+    seq1 = torch.cat([torch.tensor([0]), torch.randint(4, 24, (args.residues,), generator=g), torch.tensor([2])])
+    seq = seq1[None].repeat(B, 1).to(dev)
+    sch = ddpm_schedule(T, freq_dim=cfg.freq_dim)
+    gathered = [torch.empty(B, L, dtype=torch.int16, device=dev) for _ in range(world)] if world > 1 else None
+
+    def one_step(step_idx):
+        ids = eng.ddpm_sample(seq, sch, seed=args.seed + step_idx, sample_offset=rank * B)
+        if world > 1:                                            # one exchange at the end: int16 ids over RCCL
+            dist.all_gather(gathered, ids.to(torch.int16))
+        return ids
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for w in range(args.warmup):
+        one_step(1000 + w)
+    sync()
+    eng.set_profiling(True)                                      # in-stream HIP events, collected after the region
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ids = one_step(k)
+    sync()
+    t1 = time.perf_counter()
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    prof = eng.get_profile()
+    eng.set_profiling(False)
+    assert int((ids == 4096).sum()) == 0
+
+    if rank == 0:
+        total_samples = B * world * args.steps
+        value = total_samples / elapsed
+        f_sample = flops_forward_per_sample(L, cfg) * (T + 1)
+        # dominant kernel: FFN-up GEMM  [M,1536] x [8192,1536]^T with the SwiGLU epilogue
+        M = B * L
+        up = prof["gemm_ffn_up"]
+        flop_up = 2.0 * M * cfg.d_model * 2 * cfg.ffn_hidden
+        ms_up = up["ms"] / max(up["launches"], 1)
+        ach = flop_up / (ms_up * 1e-3) / 1e12 if ms_up > 0 else 0.0
+        gemm_ms = sum(prof[s]["ms"] for s in ("gemm_qkv", "gemm_out", "gemm_ffn_up", "gemm_ffn_down", "head"))
+        tot_ms = sum(v["ms"] for v in prof.values())
+        lin_flop_fwd = M * (cfg.n_layers * (2 * cfg.d_model * (3 * cfg.d_model + cfg.d_model + 2 * cfg.ffn_hidden)
+                                            + 2 * cfg.ffn_hidden * cfg.d_model)
+                            + 2 * cfg.d_model * cfg.d_model + 2 * cfg.d_model * cfg.n_structure_heads)
+        n_fwd = (T + 1) * args.steps
+        out = {
+            "metric": "conformation samples/sec (256-res, 25 steps)",
+            "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic" if not args.tiny else "debug-tiny-model",
+            "config": {"workload": f"BASELINE configs[1]: single MI355X, {args.residues}-residue synthetic sequence, "
+                                   f"num_steps={T}, num_samples={B}/GPU, ESM3-open-sized random-init weights, bf16 MFMA",
+                       "samples_per_gpu": B, "L_tok": L, "num_steps": T, "forwards_per_sample": T + 1,
+                       "layers": cfg.n_layers, "d_model": cfg.d_model, "noise": "philox4x32-10",
+                       "parallelism": f"sample-sharded x{world}, one RCCL all_gather of int16 ids"},
+            "flop_per_sample": f_sample,
+            "mfma_frac_whole_job": round(value / world * f_sample / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<SWIGLU> (FFN-up, M=%d N=%d K=%d)" % (M, 2 * cfg.ffn_hidden, cfg.d_model),
+                         "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launch_ms": round(ms_up, 4), "launches": up["launches"],
+                         "all_gemm_tflops": round(lin_flop_fwd * n_fwd / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms else None},
+            "sections_ms_per_forward": {k: round(v["ms"] / n_fwd, 3) for k, v in prof.items()},
+            "device_ms_per_forward": round(tot_ms / n_fwd, 3),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, sd, L, T)
+            except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -153,7 +153,7 @@ struct Prof {
   void mark(int section) {
     if (!e->profiling) return;
     if (e->ev_used + 2 > e->ev.size()) {
-      for (int i = 0; i < 256; ++i) {
+      for (int i = 0; i < 4096; ++i) {
         hipEvent_t ev;
         hipEventCreate(&ev);
         e->ev.push_back(ev);
@@ -170,7 +170,7 @@ void prof_collect(esmdiff_engine* e) {
     e->ev_used = 0;
     return;
   }
-  hipEventSynchronize(e->ev[e->ev_used - 1]);
+  hipDeviceSynchronize();
   for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
     float ms = 0;
     hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]);
@@ -412,9 +412,7 @@ int esmdiff_forward_logits(esmdiff_engine* e, const int64_t* seq, const int64_t*
   if (!seq || !x || !logits_out) return fail(e, ESMDIFF_E_INVALID, "null pointer");
   if (ld_logits < e->cfg.vocab_out || (ld_logits & 3)) return fail(e, ESMDIFF_E_INVALID, "ld_logits (%d) must be >= vocab (%d) rounded up to a multiple of 4", ld_logits, e->cfg.vocab_out);
   if (int r = check_bl(e, B, L)) return r;
-  int r = forward(e, seq, x, t_freq, logits_out, ld_logits, B, L, (hipStream_t)stream);
-  if (e->profiling) prof_collect(e);
-  return r;
+  return forward(e, seq, x, t_freq, logits_out, ld_logits, B, L, (hipStream_t)stream);
 }
 
 int esmdiff_ddpm_step(esmdiff_engine* e, int64_t* x_inout, const float* logits, int32_t ld_logits,
@@ -429,7 +427,6 @@ int esmdiff_ddpm_step(esmdiff_engine* e, int64_t* x_inout, const float* logits, 
   HIP_TRY(e, launch_ddpm_step(x_inout, logits, ld_logits, e->cfg.vocab_out, mc_t, mc_s, final_, u, u ? 0 : 1,
                               rng ? rng->seed : 0, rng ? rng->sample_offset : 0, step, B, L, (hipStream_t)stream));
   p.mark(S_SAMPLER);
-  if (e->profiling) prof_collect(e);
   return 0;
 }
 
@@ -452,7 +449,6 @@ int esmdiff_ddpm_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout,
     HIP_TRY(e, launch_ddpm_step(x_inout, e->logits, e->ld_logits, e->cfg.vocab_out, fin ? 0.f : mc_t[i], fin ? 0.f : mc_s[i],
                                 fin, nullptr, 1, rng->seed, rng->sample_offset, i, B, L, st));
     p.mark(S_SAMPLER);
-    if (e->profiling) prof_collect(e);
   }
   return 0;
 }

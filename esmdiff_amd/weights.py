@@ -15,32 +15,39 @@ import torch
 from .config import ModelConfig
 
 
-def _linear(g, out_f, in_f, bias):
-    # nn.Linear default init: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(in), 1/sqrt(in)) for weight and bias
-    bound = 1.0 / math.sqrt(in_f)
-    w = (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound
-    b = (torch.rand(out_f, generator=g) * 2 - 1) * bound if bias else None
-    return w, b
+def random_init_state_dict(cfg: ModelConfig, seed: int = 0, prefix: str = "net.",
+                           device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """ESM3-architecture random weights (PyTorch default initialisers per layer type), float32.
 
-
-def random_init_state_dict(cfg: ModelConfig, seed: int = 0, prefix: str = "net.") -> Dict[str, torch.Tensor]:
-    """ESM3-architecture random weights (PyTorch default initialisers per layer type), float32, CPU.
-
+    `device` selects where the numbers are drawn (the CPU and GPU generators give different streams; tests
+    use "cpu", the full-size benchmark draws its 1.4 B parameters on the GPU to save a minute of host time).
     LayerNorm weights are drawn around 1 (not exactly 1) and biases around 0 so that tests exercise them."""
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator(device=device).manual_seed(seed)
     D, FH, V = cfg.d_model, cfg.ffn_hidden, cfg.n_structure_heads
     sd: Dict[str, torch.Tensor] = {}
 
+    class _R:
+        @staticmethod
+        def randn(*shape, generator=None):
+            return torch.randn(*shape, generator=g, device=device)
+
+    def _linear(_g, out_f, in_f, bias):
+        # nn.Linear default init: kaiming_uniform(a=sqrt(5)) == U(-1/sqrt(in), 1/sqrt(in)) for weight and bias
+        bound = 1.0 / math.sqrt(in_f)
+        w = (torch.rand(out_f, in_f, generator=g, device=device) * 2 - 1) * bound
+        b = (torch.rand(out_f, generator=g, device=device) * 2 - 1) * bound if bias else None
+        return w, b
+
     def ln(name, bias=True):
-        sd[name + ".weight"] = 1.0 + 0.1 * torch.randn(D, generator=g)
+        sd[name + ".weight"] = 1.0 + 0.1 * _R.randn(D)
         if bias:
-            sd[name + ".bias"] = 0.05 * torch.randn(D, generator=g)
+            sd[name + ".bias"] = 0.05 * _R.randn(D)
 
     e = prefix + "encoder."
-    sd[e + "sequence_embed.weight"] = torch.randn(64, D, generator=g)
-    sd[e + "structure_tokens_embed.weight"] = torch.randn(4096 + 5, D, generator=g)
-    sd[e + "ss8_embed.weight"] = torch.randn(8 + 3, D, generator=g)
-    sd[e + "sasa_embed.weight"] = torch.randn(16 + 3, D, generator=g)
+    sd[e + "sequence_embed.weight"] = _R.randn(64, D)
+    sd[e + "structure_tokens_embed.weight"] = _R.randn(4096 + 5, D)
+    sd[e + "ss8_embed.weight"] = _R.randn(8 + 3, D)
+    sd[e + "sasa_embed.weight"] = _R.randn(16 + 3, D)
     for nm in ("plddt_projection", "structure_per_res_plddt_projection"):
         w, b = _linear(g, D, 16, True)
         sd[e + nm + ".weight"], sd[e + nm + ".bias"] = w, b
@@ -48,13 +55,13 @@ def random_init_state_dict(cfg: ModelConfig, seed: int = 0, prefix: str = "net."
         b = f"{prefix}transformer.blocks.{i}."
         ln(b + "attn.layernorm_qkv.0")
         sd[b + "attn.layernorm_qkv.1.weight"] = _linear(g, 3 * D, D, False)[0]
-        sd[b + "attn.q_ln.weight"] = 1.0 + 0.1 * torch.randn(D, generator=g)
-        sd[b + "attn.k_ln.weight"] = 1.0 + 0.1 * torch.randn(D, generator=g)
+        sd[b + "attn.q_ln.weight"] = 1.0 + 0.1 * _R.randn(D)
+        sd[b + "attn.k_ln.weight"] = 1.0 + 0.1 * _R.randn(D)
         sd[b + "attn.out_proj.weight"] = _linear(g, D, D, False)[0]
         ln(b + "ffn.0")
         sd[b + "ffn.1.weight"] = _linear(g, 2 * FH, D, False)[0]
         sd[b + "ffn.3.weight"] = _linear(g, D, FH, False)[0]
-    sd[prefix + "transformer.norm.weight"] = 1.0 + 0.1 * torch.randn(D, generator=g)
+    sd[prefix + "transformer.norm.weight"] = 1.0 + 0.1 * _R.randn(D)
     h = prefix + "output_heads.structure_head."
     sd[h + "0.weight"], sd[h + "0.bias"] = _linear(g, D, D, True)
     ln(h + "2")
