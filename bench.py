@@ -186,7 +186,7 @@ def main():
                        "parallelism": f"sample-sharded x{world}, one RCCL all_gather of int16 ids"},
             "flop_per_sample": f_sample,
             "mfma_frac_whole_job": round(value / world * f_sample / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel<SWIGLU> (FFN-up, M=%d N=%d K=%d)" % (M, 2 * cfg.ffn_hidden, cfg.d_model),
+            "roofline": {"bound": "mfma", "kernel": "g256::gemm256_kernel<SWIGLU> (FFN-up, M=%d N=%d K=%d)" % (M, 2 * cfg.ffn_hidden, cfg.d_model),
                          "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "launch_ms": round(ms_up, 4), "launches": up["launches"],

@@ -23,6 +23,7 @@ INCLUDE = PKG.parent / "include"
 UNITS = {
     "engine": [],
     "gemm": [],
+    "gemm256": [],
     "attention": [],
     "norm": [],
     "embed": [],

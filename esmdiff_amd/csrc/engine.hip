@@ -3,8 +3,8 @@
 // (/root/reference/slm/models/net.py:371-483, model.py:464-492, 543-607).
 //
 // Per forward (B x L tokens, M = B*L rows):
-//   sigma_mlp (2 GEMV)  -> embed -> 48 x [ LN -> QKV GEMM -> q/k LN + rotary + V^T -> attention ->
-//   out-proj GEMM (+= residual/scale) -> LN -> FFN-up GEMM (SwiGLU epilogue) -> FFN-down GEMM (+= residual/scale) ]
+//   sigma_mlp (2 GEMV)  -> embed -> 48 x [ add+LN -> QKV GEMM -> q/k LN + rotary + V^T -> attention ->
+//   out-proj GEMM (bf16 delta / scale) -> add+LN -> FFN-up GEMM (SwiGLU epilogue) -> FFN-down GEMM (bf16 delta) ]
 //   -> final LN -> head GEMM (bias+GELU) -> LN -> head GEMM (bias) -> f32 logits -> fused sampler.
 // Block 0's geometric attention contributes exactly 0 in this path (coordinates are all-NaN ->
 // affine_mask all False, net.py:433-441 with mask_and_zero_frameless=True, net.py:344) and is skipped.
@@ -53,7 +53,7 @@ struct esmdiff_engine {
   // workspace
   float* x = nullptr;
   bf16_t *h = nullptr, *h2 = nullptr, *qkv = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr,
-         *mid = nullptr;
+         *mid = nullptr, *dlt = nullptr;
   float *logits = nullptr, *cond = nullptr, *sig_hidden = nullptr, *tfreq = nullptr;
   int ld_logits = 0, Lp_max = 0, tfreq_rows = 0;
   // profiling
@@ -211,18 +211,23 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
     cond = e->cond;
   }
   RUN(S_EMBED, launch_embed(seq, xtok, e->e_seq, e->e_struct, e->cvec, cond, e->x, B, L, D, st));
+  // The residual stream x stays f32.  Each branch GEMM (out-proj, FFN-down) writes its output, already
+  // divided by the residue scale, as a bf16 delta; the NEXT LayerNorm kernel adds it into x while it
+  // reads x anyway (fused add + LN), so no GEMM epilogue does a read-modify-write.
+  const bf16_t* pending = nullptr;
   for (int i = 0; i < c.n_layers; ++i) {
     const Layer& ly = e->layers[i];
-    RUN(S_LN, launch_layernorm_bf16(e->x, ly.ln1_w, ly.ln1_b, e->h, M, D, st));
+    RUN(S_LN, launch_add_layernorm_bf16(e->x, pending, ly.ln1_w, ly.ln1_b, e->h, M, D, st));
     RUN(S_QKV, launch_gemm_bf16(e->h, ly.w_qkv, e->qkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_EPI_BF16, st));
     RUN(S_QKROPE, launch_qk_norm_rope(e->qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, e->q, e->k, e->vt, B, L, Lp, H, st));
     RUN(S_ATTN, launch_attention(e->q, e->k, e->vt, e->ctx, B, L, Lp, H, st));
-    RUN(S_OUT, launch_gemm_bf16(e->ctx, ly.w_out, e->x, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_RESID_F32, st));
-    RUN(S_LN, launch_layernorm_bf16(e->x, ly.ln2_w, ly.ln2_b, e->h, M, D, st));
+    RUN(S_OUT, launch_gemm_bf16(e->ctx, ly.w_out, e->dlt, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, st));
+    RUN(S_LN, launch_add_layernorm_bf16(e->x, e->dlt, ly.ln2_w, ly.ln2_b, e->h, M, D, st));
     RUN(S_FFN_UP, launch_gemm_bf16(e->h, ly.w_up, e->mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, st));
-    RUN(S_FFN_DOWN, launch_gemm_bf16(e->mid, ly.w_down, e->x, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_RESID_F32, st));
+    RUN(S_FFN_DOWN, launch_gemm_bf16(e->mid, ly.w_down, e->dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, st));
+    pending = e->dlt;
   }
-  RUN(S_LN, launch_layernorm_bf16(e->x, e->final_ln_w, nullptr, e->h, M, D, st));
+  RUN(S_LN, launch_add_layernorm_bf16(e->x, pending, e->final_ln_w, nullptr, e->h, M, D, st));
   RUN(S_HEAD, launch_gemm_bf16(e->h, e->head_w0, e->h2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, st));
   RUN(S_LN, launch_layernorm_bf16_in(e->h2, e->head_ln_w, e->head_ln_b, e->h, M, D, st));
   RUN(S_HEAD, launch_gemm_bf16(e->h, e->head_w3, logits, e->head_b3, M, e->vocab_pad, D, ld, c.vocab_out, 1.f, ESMDIFF_EPI_BIAS_F32, st));
@@ -393,6 +398,7 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
     TRY(dalloc(e, &e->k, hp, true));
     TRY(dalloc(e, &e->vt, hp, true));
     TRY(dalloc(e, &e->ctx, Mx * D));
+    TRY(dalloc(e, &e->dlt, Mx * D));
     TRY(dalloc(e, &e->mid, Mx * FH));
     TRY(dalloc(e, &e->logits, Mx * e->ld_logits));
     TRY(dalloc(e, &e->cond, (size_t)D));

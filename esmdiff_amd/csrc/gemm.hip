@@ -21,6 +21,8 @@
 // Grid: one workgroup per tile, XCD-aware (block b runs on XCD b%8, so each XCD is given a contiguous
 // run of tiles) and rasterised in 8x8 super-tiles so the 64 tiles resident on an XCD share 8 A panels
 // and 8 W panels in that XCD's L2.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace ed {
@@ -178,9 +180,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
     f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * SW + c4);
     const int n = ncol0 + c4;
     if constexpr (EPI == ESMDIFF_EPI_BF16 || EPI == ESMDIFF_EPI_SWIGLU_BF16) {
+      const float sc = (EPI == ESMDIFF_EPI_BF16) ? alpha : 1.0f;
       uint2 p;
-      p.x = pack_bf16x2(v[0], v[1]);
-      p.y = pack_bf16x2(v[2], v[3]);
+      p.x = pack_bf16x2(v[0] * sc, v[1] * sc);
+      p.y = pack_bf16x2(v[2] * sc, v[3] * sc);
       *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = p;
     } else if constexpr (EPI == ESMDIFF_EPI_RESID_F32) {
       float* o = reinterpret_cast<float*>(out) + (int64_t)m * ldc + n;
@@ -209,6 +212,17 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
                             int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream) {
   if (M <= 0) return hipSuccess;
   if (N % BN != 0 || K % BK != 0 || (ldc & 3)) return hipErrorInvalidValue;
+  {
+    // tile selection: the 256x256 counted-vmcnt kernel for large M, this 128x128 kernel otherwise.
+    // ESMDIFF_GEMM_TILE=128|256 forces one (A/B benchmarking and tests).
+    static const int forced = [] {
+      const char* e = getenv("ESMDIFF_GEMM_TILE");
+      return e ? atoi(e) : 0;
+    }();
+    const bool ok256 = (N % 256 == 0);
+    if (ok256 && (forced == 256 || (forced == 0 && M >= 1024)))
+      return launch_gemm256_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
+  }
   const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
   dim3 grid(tiles_m * tiles_n), block(256);
   const size_t lds = 4 * TILE_BYTES;

@@ -1,0 +1,392 @@
+// gemm256.hip — the large-M bf16 MFMA GEMM: 256x256x64 tiles, 8 waves, register-prefetched pipeline (gfx950).
+//
+// Same contract and epilogues as gemm.hip (out = epi(A[M,K] · W[N,K]^T)); used when N % 256 == 0 and M is
+// large (the four per-block linears of the ESM3 stack at B*L = 25 800 rows).  What changes is the schedule:
+//
+//   workgroup  512 threads = 8 waves as 2 (M) x 4 (N); one workgroup per CU (128 KiB LDS, <=256 VGPR/wave,
+//              two waves per SIMD).  Wave tile 128 x 64 = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16.
+//   LDS        2 stages x [A rows 0-127 | A rows 128-255 | W rows 0-127 | W rows 128-255], each 128 rows x 128 B
+//              (16 KiB), filled by LDS-DMA (global_load_lds_dwordx4), source-side XOR swizzle as in gemm.hip.
+//   K-tile     8 groups of 4 MFMAs per wave; a group is one 64x32 quadrant of the wave tile over HALF of the
+//              K-tile (two k-steps of 16), visited in a snake so that consecutive groups share an operand:
+//                g1 C00+=A0h0·B0h0 | g2 C01+=A0h0·B1h0 | g3 C11+=A1h0·B1h0 | g4 C10+=A1h0·B0h0
+//                g5 C10+=A1h1·B0h1 | g6 C11+=A1h1·B1h1 | g7 C01+=A0h1·B1h1 | g8 C00+=A0h1·B0h1
+//              Operand half-sets (4 x ds_read_b128 for A, 2 for B) are read TWO groups before their first use
+//              (<= 64 operand VGPRs live + 128 accumulators at 2 waves/SIMD).  The reads are inline-asm
+//              ds_read_b128 and the waits are counted s_waitcnt lgkmcnt(N): hipcc would turn every wait into
+//              lgkmcnt(0) while an LDS-DMA is pending.
+//              One barrier per K-tile, after g7: every wave has then finished reading this stage and K-tile
+//              t+1 has landed.  The 8 LDS-DMA instructions per wave that refill the stage with K-tile t+2 are
+//              spread over g8, g1', g2', g3' (2 each): measured with s_memtime, the CU's address path takes
+//              ~25-45 cycles per 1-KiB LDS-DMA, and a burst of 64 of them right after the barrier stalled the
+//              younger four waves for 1.2-2k cycles in instruction issue.
+//   raster     XCD-contiguous, 8(M) x 4(N) super-tiles: the 32 tiles resident on one XCD share 8 A panels and
+//              4 W panels in that XCD's L2.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace ed {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace g256 {
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB
+constexpr int STAGE_BYTES = 4 * HALF_BYTES;  // 64 KiB
+constexpr int GROUP_M = 8;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
+}
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
+  ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
+  ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
+  return ua | (ub << 16);
+}
+#define ED_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// -DED_GEMM_DEBUG: ESMDIFF_GEMM_DBG bits (2: no LDS-DMA in the main loop, 4: no stores, 8: no vmcnt wait, 16: no
+// barrier) for ablations, and s_memtime stamps of one workgroup into the `bias` buffer of an EPI_BF16 launch.
+#ifdef ED_GEMM_DEBUG
+#define ED_DBG(bit) (dbg & (bit))
+#else
+#define ED_DBG(bit) 0
+#endif
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                         void* __restrict__ out, const float* __restrict__ bias,
+                                                         int M, int N, int K, int ldc, float alpha, int tiles_m,
+                                                         int tiles_n, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x 64 KiB
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int per_group = GROUP_M * tiles_n;
+  const int grp = lin / per_group, in_grp = lin - grp * per_group;
+  const int gm0 = grp * GROUP_M;
+  const int gsz = min(GROUP_M, tiles_m - gm0);
+  const int mt = gm0 + in_grp % gsz, nt = in_grp / gsz;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // ---- LDS-DMA sources: half-tile = 128 rows = 16 wave-instructions of 8 rows; wave issues i = 0,1 ----
+  const int srow = lane >> 3;
+  const int schunk = (lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  uint32_t a_off[2][2], w_off[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = h * 128 + (i * 8 + wave) * 8 + srow;
+      const int am = min(m0 + r, M - 1);
+      a_off[h][i] = (uint32_t)(((int64_t)am * K + schunk * 8) * 2);
+      w_off[h][i] = (uint32_t)(((int64_t)(n0 + r) * K + schunk * 8) * 2);
+    }
+  const char* Ab = reinterpret_cast<const char*>(A);
+  const char* Wb = reinterpret_cast<const char*>(W);
+  auto issue_Ah = [&](int h, int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      glds16(Ab + (size_t)kt * (BK * 2) + a_off[h][i], smem + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+  };
+  auto issue_Wh = [&](int h, int buf, int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      glds16(Wb + (size_t)kt * (BK * 2) + w_off[h][i],
+             smem + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+  };
+  auto issue_A = [&](int buf, int kt) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        glds16(Ab + (size_t)kt * (BK * 2) + a_off[h][i], smem + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+  };
+  auto issue_W = [&](int buf, int kt) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        glds16(Wb + (size_t)kt * (BK * 2) + w_off[h][i],
+               smem + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+  };
+
+  // ---- fragment read addressing -----------------------------------------------------------------
+  // Fragment reads are inline-asm ds_read_b128 so that the waits can be COUNTED: hipcc turns every
+  // lgkmcnt wait into lgkmcnt(0) while an LDS-DMA is pending (it models global_load_lds as a FLAT access
+  // that may touch LDS), which would make each group wait for the prefetch it has just issued.
+  const int frow = lane & 31, khalf = lane >> 5, fsw = (frow >> 1) & 7;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  uint32_t offA[4], offB[4];  // stage-0 byte addresses of this lane's 16-byte fragment piece, per k-step
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const uint32_t lo = frow * 128 + (((ks * 2 + khalf) ^ fsw) << 4);
+    offA[ks] = lds0 + (wm * 2) * HALF_BYTES + lo;
+    offB[ks] = lds0 + ((2 + (wn >> 1)) * 2) * HALF_BYTES + (wn & 1) * (64 * 128) + lo;
+  }
+#define ED_DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+  // half-sets: A[f][j] = rows (mh*64 + f*32 ..), k-step 2*h + j ; B[j] = cols (nh*32 ..), k-step 2*h + j
+  auto read_A = [&](bf16x8 (&a)[2][2], auto P, auto MH, auto H) {
+    constexpr int mh = decltype(MH)::value, h = decltype(H)::value;
+    constexpr int st = decltype(P)::value * HALF_BYTES;
+    const uint32_t a0_ = offA[2 * h], a1_ = offA[2 * h + 1];
+    ED_DSR(a[0][0], a0_, st + (mh * 64) * 128);
+    ED_DSR(a[0][1], a1_, st + (mh * 64) * 128);
+    ED_DSR(a[1][0], a0_, st + (mh * 64 + 32) * 128);
+    ED_DSR(a[1][1], a1_, st + (mh * 64 + 32) * 128);
+  };
+  auto read_B = [&](bf16x8 (&b)[2], auto P, auto NH, auto H) {
+    constexpr int nh = decltype(NH)::value, h = decltype(H)::value;
+    constexpr int st = decltype(P)::value * HALF_BYTES;
+    const uint32_t b0_ = offB[2 * h], b1_ = offB[2 * h + 1];
+    ED_DSR(b[0], b0_, st + (nh * 32) * 128);
+    ED_DSR(b[1], b1_, st + (nh * 32) * 128);
+  };
+  // counted wait that also makes the retired registers' readiness visible to the compiler ("+v")
+#define ED_WAIT_A(N, a)                                                                                       \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]));   \
+    ED_PHASE_FENCE();                                                                                         \
+  } while (0)
+#define ED_WAIT_B(N, b)                                                   \
+  do {                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]));   \
+    ED_PHASE_FENCE();                                                     \
+  } while (0)
+#define ED_WAIT_AB(N, a, b)                                                                                  \
+  do {                                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                 \
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[0]), "+v"(b[1]));      \
+    ED_PHASE_FENCE();                                                                                        \
+  } while (0)
+
+  f32x16 acc[2][2][2];  // [mh][f][nh]
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) (&acc[0][0][0])[i][r] = 0.0f;
+
+  auto mma = [&](int mh, int nh, const bf16x8 (&a)[2][2], const bf16x8 (&b)[2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+        acc[mh][f][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[f][j], b[j], acc[mh][f][nh], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    ED_PHASE_FENCE();
+  };
+
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  bf16x8 A0a[2][2], A0b[2][2], A1a[2][2], A1b[2][2], B0a[2], B0b[2], B1a[2], B1b[2];
+  const int nk = K / BK;
+
+  issue_A(0, 0);
+  issue_W(0, 0);
+  if (nk > 1) {
+    issue_A(1, 1);
+    issue_W(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  ED_PHASE_FENCE();
+  read_A(A0a, I0{}, I0{}, I0{});
+  read_B(B0a, I0{}, I0{}, I0{});
+  read_B(B1a, I0{}, I1{}, I0{});
+  ED_PHASE_FENCE();
+
+  // One K-tile at stage P.  Read sets are issued two groups ahead of their first use; the LGKM queue holds
+  // only these ds_reads, in order, so each wait is "all but the N youngest".
+  //   queue on entry: [A0a 4][B0a 2][B1a 2]
+#ifdef ED_GEMM_DEBUG
+  unsigned long long* trace = nullptr;
+  if constexpr (EPI == ESMDIFF_EPI_BF16) {
+    if (bias != nullptr && bid == 40) trace = reinterpret_cast<unsigned long long*>(const_cast<float*>(bias));
+  }
+#define ED_STAMP(i)                                                                     \
+  do {                                                                                  \
+    if (trace && t < 32 && lane == 0) trace[(wave * 32 + t) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define ED_STAMP(i) do { } while (0)
+#endif
+  auto ktile = [&](int t, auto P) {
+    using Q = std::integral_constant<int, 1 - decltype(P)::value>;
+    ED_STAMP(0);
+    // g1  C00 += A0h0·B0h0   (+ second quarter of the refill of the other stage with K-tile t+1)
+    if (t >= 1 && t + 1 < nk && !ED_DBG(2)) issue_Wh(1, Q::value, t + 1);
+    read_A(A1a, P, I1{}, I0{});            // queue 12
+    ED_WAIT_AB(6, A0a, B0a);
+    mma(0, 0, A0a, B0a);
+    // g2  C01 += A0h0·B1h0
+    if (t >= 1 && t + 1 < nk && !ED_DBG(2)) issue_Ah(0, Q::value, t + 1);
+    read_A(A1b, P, I1{}, I1{});            // [B1a 2][A1a 4][A1b 4]
+    ED_WAIT_B(8, B1a);
+    mma(0, 1, A0a, B1a);
+    // g3  C11 += A1h0·B1h0
+    if (t >= 1 && t + 1 < nk && !ED_DBG(2)) issue_Ah(1, Q::value, t + 1);
+    read_B(B0b, P, I0{}, I1{});            // [A1a 4][A1b 4][B0b 2]
+    ED_WAIT_A(6, A1a);
+    mma(1, 1, A1a, B1a);
+    // g4  C10 += A1h0·B0h0
+    read_B(B1b, P, I1{}, I1{});            // [A1b 4][B0b 2][B1b 2]
+    mma(1, 0, A1a, B0a);
+    ED_STAMP(1);
+    // g5  C10 += A1h1·B0h1
+    read_A(A0b, P, I0{}, I1{});            // [A1b 4][B0b 2][B1b 2][A0b 4]
+    ED_WAIT_AB(6, A1b, B0b);
+    mma(1, 0, A1b, B0b);
+    // g6  C11 += A1h1·B1h1
+    ED_WAIT_B(4, B1b);                                     // [B1b 2][A0b 4]
+    mma(1, 1, A1b, B1b);
+    // g7  C01 += A0h1·B1h1
+    ED_WAIT_A(0, A0b);
+    mma(0, 1, A0b, B1b);
+    ED_STAMP(2);
+    if (!ED_DBG(8)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // K-tile t+1 (issued one K-tile ago) has landed
+    ED_STAMP(3);
+    if (!ED_DBG(16)) __builtin_amdgcn_s_barrier();    // ... for every wave; and stage P is no longer read
+    ED_STAMP(4);
+    ED_PHASE_FENCE();
+    // g8  C00 += A0h1·B0h1
+    if (t + 2 < nk && !ED_DBG(2)) issue_Wh(0, decltype(P)::value, t + 2);
+    if (t + 1 < nk) {
+      read_A(A0a, Q{}, I0{}, I0{});
+      read_B(B0a, Q{}, I0{}, I0{});
+      read_B(B1a, Q{}, I1{}, I0{});
+    }
+    ED_STAMP(5);
+    ED_PHASE_FENCE();
+    mma(0, 0, A0b, B0b);
+    ED_STAMP(6);
+  };
+
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    ktile(t, I0{});
+    ktile(t + 1, I1{});
+  }
+  if (t < nk) ktile(t, I0{});
+
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue: per wave, two rounds (mh) of 64 rows through a private 16 KiB LDS slab ------------
+  float* slab = reinterpret_cast<float*>(smem) + wave * (64 * 64);
+  constexpr int SW = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? 32 : 64;
+  constexpr int LPR = SW / 4, RPI = 64 / LPR;
+  const int ccol = lane & 31, rhalf = lane >> 5;
+  const int rr_ = lane / LPR, c4 = (lane % LPR) * 4;
+  const int ncol0 = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? (n0 + wn * 64) / 2 : (n0 + wn * 64);
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      if constexpr (EPI == ESMDIFF_EPI_SWIGLU_BF16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+          const float g = acc[mh][f][0][r], u = acc[mh][f][1][r];
+          slab[row * SW + ccol] = (g / (1.0f + __expf(-g))) * u;
+        }
+      } else {
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+            slab[row * SW + nh * 32 + ccol] = acc[mh][f][nh][r];
+          }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int it = 0; it < 64 / RPI; ++it) {
+      const int row = it * RPI + rr_;
+      const int m = m0 + wm * 128 + mh * 64 + row;
+      if (m >= M || ED_DBG(4)) continue;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * SW + c4);
+      const int n = ncol0 + c4;
+      if constexpr (EPI == ESMDIFF_EPI_BF16 || EPI == ESMDIFF_EPI_SWIGLU_BF16) {
+        const float sc = (EPI == ESMDIFF_EPI_BF16) ? alpha : 1.0f;
+        uint2 pk;
+        pk.x = pack_bf16x2(v[0] * sc, v[1] * sc);
+        pk.y = pack_bf16x2(v[2] * sc, v[3] * sc);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = pk;
+      } else if constexpr (EPI == ESMDIFF_EPI_RESID_F32) {
+        float* o = reinterpret_cast<float*>(out) + (int64_t)m * ldc + n;
+        f32x4 x = *reinterpret_cast<const f32x4*>(o);
+        x[0] += v[0] * alpha; x[1] += v[1] * alpha; x[2] += v[2] * alpha; x[3] += v[3] * alpha;
+        *reinterpret_cast<f32x4*>(o) = x;
+      } else if constexpr (EPI == ESMDIFF_EPI_BIAS_GELU_BF16) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
+        uint2 pk;
+        pk.x = pack_bf16x2(gelu_erf(v[0] + bb[0]), gelu_erf(v[1] + bb[1]));
+        pk.y = pack_bf16x2(gelu_erf(v[2] + bb[2]), gelu_erf(v[3] + bb[3]));
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = pk;
+      } else {
+        if (n + 4 <= ldc) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
+          f32x4 x;
+          x[0] = v[0] + bb[0]; x[1] = v[1] + bb[1]; x[2] = v[2] + bb[2]; x[3] = v[3] + bb[3];
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (int64_t)m * ldc + n) = x;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+}  // namespace g256
+
+hipError_t launch_gemm256_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
+                               int K, int ldc, float alpha, int epilogue, hipStream_t stream) {
+  using namespace g256;
+  if (M <= 0) return hipSuccess;
+  if (N % BN != 0 || K % BK != 0 || (ldc & 3)) return hipErrorInvalidValue;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+  dim3 grid(tiles_m * tiles_n), block(512);
+  const size_t lds = 2 * STAGE_BYTES;
+  static const int dbg = [] {
+    const char* e = getenv("ESMDIFF_GEMM_DBG");
+    return e ? atoi(e) : 0;
+  }();
+#define ED_GEMM(E)                                                                                         \
+  do {                                                                                                     \
+    static bool attr_done = false;                                                                         \
+    if (!attr_done) {                                                                                      \
+      hipFuncSetAttribute((const void*)gemm256_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      attr_done = true;                                                                                    \
+    }                                                                                                      \
+    hipLaunchKernelGGL(gemm256_kernel<E>, grid, block, lds, stream, A, W, out, bias, M, N, K, ldc, alpha,   \
+                       tiles_m, tiles_n, dbg);                                                             \
+  } while (0)
+  switch (epilogue) {
+    case ESMDIFF_EPI_BF16: ED_GEMM(ESMDIFF_EPI_BF16); break;
+    case ESMDIFF_EPI_RESID_F32: ED_GEMM(ESMDIFF_EPI_RESID_F32); break;
+    case ESMDIFF_EPI_SWIGLU_BF16: ED_GEMM(ESMDIFF_EPI_SWIGLU_BF16); break;
+    case ESMDIFF_EPI_BIAS_GELU_BF16: ED_GEMM(ESMDIFF_EPI_BIAS_GELU_BF16); break;
+    case ESMDIFF_EPI_BIAS_F32: ED_GEMM(ESMDIFF_EPI_BIAS_F32); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef ED_GEMM
+  return hipGetLastError();
+}
+
+}  // namespace ed

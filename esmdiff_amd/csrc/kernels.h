@@ -20,9 +20,16 @@ hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, floa
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
                             int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream);
 
+// gemm256.hip: 256x256x64 tiles, 8 waves, counted-vmcnt pipeline; needs N % 256 == 0 (large-M path)
+hipError_t launch_gemm256_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
+                               int K, int ldc, float alpha, int epilogue, hipStream_t stream);
+
 // ---- norm.hip --------------------------------------------------------------------------------
 hipError_t launch_layernorm_bf16(const float* x, const float* w, const float* b, bf16_t* y, int M, int D,
                                  hipStream_t stream);
+// x (f32, in place) += delta (bf16 or null); y = LayerNorm(x) * w (+ b)
+hipError_t launch_add_layernorm_bf16(float* x, const bf16_t* delta, const float* w, const float* b, bf16_t* y, int M,
+                                     int D, hipStream_t stream);
 hipError_t launch_layernorm_bf16_in(const bf16_t* x, const float* w, const float* b, bf16_t* y, int M, int D,
                                     hipStream_t stream);
 // qkv bf16 [M,3D] -> q,k bf16 [B,H,Lp,64] (LayerNorm over D, rotary, q pre-scaled), vt bf16 [B,H,64,Lp]

@@ -122,6 +122,87 @@ hipError_t launch_layernorm_bf16_in(const bf16_t* x, const float* w, const float
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused residual add + LayerNorm:  x += delta (bf16, the previous GEMM's scaled output; may be null),
+// x written back (f32 residual stream), y = LayerNorm(x) * w (+ b) as the next GEMM's bf16 operand.
+// This takes the residual read-modify-write out of the out-proj / FFN-down GEMM epilogues (where its
+// loads sat exposed behind the MFMA main loop) and into a pure streaming kernel.  D == NV * 256 exactly.
+template <int NV>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                            const float* __restrict__ w, const float* __restrict__ b,
+                                                            bf16_t* __restrict__ y, int M) {
+  constexpr int D = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float* xr = x + (int64_t)row * D + lane * 4;
+  f32x4 v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const f32x4*>(xr + j * 256);
+  if (delta) {
+    const bf16_t* dr = delta + (int64_t)row * D + lane * 4;
+    uint2 p[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) p[j] = *reinterpret_cast<const uint2*>(dr + j * 256);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      v[j][0] += bf2f(p[j].x & 0xffffu); v[j][1] += bf2f(p[j].x >> 16);
+      v[j][2] += bf2f(p[j].y & 0xffffu); v[j][3] += bf2f(p[j].y >> 16);
+      *reinterpret_cast<f32x4*>(xr + j * 256) = v[j];
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  const float mean = wsum(s) * (1.0f / D);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[j][e] - mean;
+      q += d * d;
+    }
+  const float rstd = rsqrtf(wsum(q) * (1.0f / D) + 1e-5f);
+  bf16_t* yr = y + (int64_t)row * D + lane * 4;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const f32x4 ww = *reinterpret_cast<const f32x4*>(w + j * 256 + lane * 4);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * ww[e];
+    if (b) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(b + j * 256 + lane * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += bb[e];
+    }
+    uint2 pk;
+    pk.x = pack2(o[0], o[1]);
+    pk.y = pack2(o[2], o[3]);
+    *reinterpret_cast<uint2*>(yr + j * 256) = pk;
+  }
+}
+
+hipError_t launch_add_layernorm_bf16(float* x, const bf16_t* delta, const float* w, const float* b, bf16_t* y, int M,
+                                     int D, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  if (D % 256 != 0 || D > 2048) return hipErrorInvalidValue;
+  dim3 grid((M + 3) / 4), block(256);
+#define ED_ALN(N) hipLaunchKernelGGL(add_layernorm_kernel<N>, grid, block, 0, stream, x, delta, w, b, y, M)
+  switch (D / 256) {
+    case 1: ED_ALN(1); break;
+    case 2: ED_ALN(2); break;
+    case 3: ED_ALN(3); break;
+    case 4: ED_ALN(4); break;
+    case 5: ED_ALN(5); break;
+    case 6: ED_ALN(6); break;
+    case 7: ED_ALN(7); break;
+    default: ED_ALN(8); break;
+  }
+#undef ED_ALN
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // q/k LayerNorm + rotary.  One wave per token; lane holds 8 contiguous columns per 512-column slab
 // (16-byte loads), NS = D / 512 slabs.  A head is 64 columns = 8 lanes; the rotate-half partner of
 // column offset o is o +/- 32, i.e. lane ^ 4.
