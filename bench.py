@@ -126,12 +126,12 @@ def main():
     seq1 = torch.cat([torch.tensor([0]), torch.randint(4, 24, (args.residues,), generator=g), torch.tensor([2])])
     seq = seq1[None].repeat(B, 1).to(dev)
     sch = ddpm_schedule(T, freq_dim=cfg.freq_dim)
-    gathered = [torch.empty(B, L, dtype=torch.int16, device=dev) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty(B, L * 2, dtype=torch.uint8, device=dev) for _ in range(world)] if world > 1 else None
 
     def one_step(step_idx):
         ids = eng.ddpm_sample(seq, sch, seed=args.seed + step_idx, sample_offset=rank * B)
         if world > 1:                                            # one exchange at the end: int16 ids over RCCL
-            dist.all_gather(gathered, ids.to(torch.int16))
+            dist.all_gather(gathered, ids.to(torch.int16).view(torch.uint8))
         return ids
 
     def sync():

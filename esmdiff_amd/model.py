@@ -1,0 +1,107 @@
+"""Drop-in for the inference surface of the reference's task module
+(/root/reference/slm/models/model.py:316-607, class MaskedDiffusionLanguageModeling) on top of the HIP engine.
+
+Kept: constructor flags that matter at inference (time_conditioning, noise_removal, noise schedule), the
+attributes the CLI touches (`.net`, `.noise_removal`, `.device`), and
+    ddpm_sample(sequence_tokens, num_steps=None, eps=1e-5, input_prior=None, sample_max_t=1.0) -> (B, L) int64
+with the reference's argument meaning and error behaviour (model.py:543-581).
+Added (keyword-only): `seed`, `sample_offset` (Philox noise, sharding independent) and `noise="torch-cpu"`,
+which draws the uniforms exactly like the reference's CPU path — torch.rand_like on the CPU generator, one
+(B, L, 4101) tensor per update in the same order (model.py:27) — and uploads them (parity mode).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .config import ESM3_OPEN, ModelConfig
+from .constants import STRUCTURE_MASK_TOKEN, STRUCTURE_VOCAB
+from .engine import Engine
+from .schedule import CosineNoise, LogLinearNoise, Noise, ddpm_schedule
+from .weights import load_checkpoint_state_dict, random_init_state_dict
+
+
+class MaskedDiffusionLanguageModeling:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: ModelConfig = ESM3_OPEN,
+                 noise_schedule: Optional[Noise] = None, max_batch: int = 128, max_len: int = 1026,
+                 device: int = 0, noise_removal: bool = True):
+        if noise_schedule is None:
+            print("Using default noise schedule: CosineNoise(eps=1e-3)")    # model.py:345-347
+            noise_schedule = CosineNoise(eps=1e-3)
+        self.cfg = cfg
+        self.noise = noise_schedule
+        self.time_conditioning = cfg.time_conditioning
+        self.noise_removal = noise_removal
+        self.vocab_size = STRUCTURE_VOCAB
+        self.mask_index = STRUCTURE_MASK_TOKEN
+        self.neg_infinity = -1000000.0
+        self.net = Engine(cfg, state_dict, max_batch=max_batch, max_len=max_len, device=device)
+        self.device = self.net.device
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def _sample_prior(self, *batch_dims):
+        return self.mask_index * torch.ones(*batch_dims, dtype=torch.int64)
+
+    @torch.no_grad()
+    def ddpm_sample(self, sequence_tokens, num_steps=None, eps=1e-5, input_prior=None, sample_max_t=1.0, *,
+                    seed: int = 0, sample_offset: int = 0, noise: str = "philox"):
+        if num_steps is None:
+            print("Using by default num_steps: 1000")
+            num_steps = 1000
+        if input_prior is None:
+            assert sample_max_t == 1.0, "sample_max_t has to be 1.0 when input_prior is None"
+        else:
+            print(f"Using input_prior: {input_prior.shape}")
+            assert tuple(input_prior.shape) == tuple(sequence_tokens.shape), \
+                f"Invalid input_prior shape: {input_prior.shape} v.s. (seq) {sequence_tokens.shape}"
+        sch = ddpm_schedule(num_steps, eps, sample_max_t, self.noise, self.cfg.freq_dim)
+        B, L = sequence_tokens.shape
+        if noise == "philox" and self.noise_removal:
+            return self.net.ddpm_sample(sequence_tokens, sch, seed=seed, sample_offset=sample_offset,
+                                        input_prior=input_prior)
+        # step-by-step drive (parity mode / noise_removal off)
+        seq = sequence_tokens.to(self.device)
+        x = (self._sample_prior(B, L) if input_prior is None else input_prior.clone()).to(self.device).contiguous()
+        tf = sch.t_freq if self.time_conditioning else [None] * (num_steps + 1)
+        if noise == "torch-cpu":
+            torch.manual_seed(seed)
+        elif noise != "philox":
+            raise ValueError(f"unknown noise source {noise!r}")
+        for i in range(num_steps):
+            logits = self.net.forward_logits(x, seq, tf[i])
+            if noise == "torch-cpu":
+                u = torch.rand(B, L, STRUCTURE_VOCAB)       # == torch.rand_like(q_xs) on the CPU generator
+                self.net.ddpm_step(x, logits, sch.mc_t[i].item(), sch.mc_s[i].item(), u=u)
+            else:
+                self.net.ddpm_step(x, logits, sch.mc_t[i].item(), sch.mc_s[i].item(), seed=seed,
+                                   sample_offset=sample_offset, step=i)
+        if self.noise_removal:
+            logits = self.net.forward_logits(x, seq, tf[num_steps])
+            self.net.ddpm_step(x, logits, 0.0, 0.0, final=True)
+        return x
+
+
+def load_state_dict_from_lightning_ckpt(ckpt_path, device="cuda", max_batch: int = 128, max_len: int = 1026,
+                                        cfg: ModelConfig = ESM3_OPEN):
+    """/root/reference/slm/utils/checkpoint_utils.py:41-74: a `.pt` whose 'module' dict holds `net.*` and
+    `sigma_embedder.*`; the model is the mdlm.yaml configuration (LogLinearNoise, time conditioning, 4101-way
+    head) with noise_removal forced on (:71)."""
+    print(f"Loading ESMDiff ckpt from {ckpt_path}")
+    sd = load_checkpoint_state_dict(ckpt_path)
+    dev = torch.device(device).index or 0
+    model = MaskedDiffusionLanguageModeling(sd, cfg, LogLinearNoise(), max_batch, max_len, dev, noise_removal=True)
+    print(f"Sucessfully loaded model from {ckpt_path}...")
+    return model
+
+
+def random_init_model(cfg: ModelConfig = ESM3_OPEN, seed: int = 0, max_batch: int = 128, max_len: int = 1026,
+                      device: int = 0):
+    """ESM3-open-sized random weights (no checkpoint can be fetched offline): synthetic benchmarking / tests."""
+    sd = random_init_state_dict(cfg, seed=seed, device=f"cuda:{device}")
+    return MaskedDiffusionLanguageModeling(sd, cfg, LogLinearNoise(), max_batch, max_len, device, noise_removal=True)

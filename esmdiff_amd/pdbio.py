@@ -1,0 +1,121 @@
+"""PDB text I/O used by the sampling CLI.
+
+  read_pdb_backbone   what the CLI needs from ESMProtein.from_pdb (/root/reference/slm/sample_esmdiff.py:278-283):
+                      the one-letter sequence of the first chain and its N/CA/C coordinates
+  merge_pdbfiles      /root/reference/slm/utils/eval_utils.py:437-492 — one multi-MODEL file, 80-column lines
+  timer               /root/reference/slm/utils/eval_utils.py:24-34
+"""
+from __future__ import annotations
+
+import time
+from pathlib import Path
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+THREE_TO_ONE = {
+    "ALA": "A", "ARG": "R", "ASN": "N", "ASP": "D", "CYS": "C", "GLN": "Q", "GLU": "E", "GLY": "G", "HIS": "H",
+    "ILE": "I", "LEU": "L", "LYS": "K", "MET": "M", "PHE": "F", "PRO": "P", "SER": "S", "THR": "T", "TRP": "W",
+    "TYR": "Y", "VAL": "V", "SEC": "U", "PYL": "O",
+}
+ONE_TO_THREE = {v: k for k, v in THREE_TO_ONE.items()}
+
+
+def read_pdb_backbone(path, chain: Optional[str] = None) -> Tuple[str, np.ndarray]:
+    """-> (sequence, coords [L,3,3] for N, CA, C; NaN where an atom is missing).  First MODEL, first chain."""
+    seq: List[str] = []
+    coords: List[np.ndarray] = []
+    index = {}
+    want = {"N": 0, "CA": 1, "C": 2}
+    with open(path) as fh:
+        for line in fh:
+            rec = line[:6]
+            if rec.startswith("ENDMDL"):
+                break
+            if not rec.startswith("ATOM"):
+                if rec.startswith("TER") and seq:
+                    break
+                continue
+            ch = line[21]
+            if chain is None:
+                chain = ch
+            if ch != chain:
+                continue
+            if line[16] not in (" ", "A"):
+                continue
+            key = (line[22:27], line[17:20])
+            if key not in index:
+                index[key] = len(seq)
+                seq.append(THREE_TO_ONE.get(line[17:20].strip(), "X"))
+                coords.append(np.full((3, 3), np.nan, dtype=np.float32))
+            name = line[12:16].strip()
+            if name in want:
+                coords[index[key]][want[name]] = (float(line[30:38]), float(line[38:46]), float(line[46:54]))
+    if not seq:
+        raise ValueError(f"no ATOM records in {path}")
+    return "".join(seq), np.stack(coords)
+
+
+def write_backbone_pdb(path, sequence: str, coords: np.ndarray, bfactor: Optional[np.ndarray] = None) -> None:
+    """N/CA/C backbone as ATOM records (used once a structure decoder supplies coordinates)."""
+    lines, serial = [], 1
+    for i, aa in enumerate(sequence):
+        for j, (name, elem) in enumerate((("N", "N"), ("CA", "C"), ("C", "C"))):
+            x, y, z = (float(v) for v in coords[i, j])
+            if not np.isfinite([x, y, z]).all():
+                continue
+            b = 0.0 if bfactor is None else float(bfactor[i])
+            lines.append(f"ATOM  {serial:5d}  {name:<3s} {ONE_TO_THREE.get(aa, 'UNK'):>3s} A{i + 1:4d}    "
+                         f"{x:8.3f}{y:8.3f}{z:8.3f}{1.0:6.2f}{b:6.2f}          {elem:>2s}  ")
+            serial += 1
+    lines += ["TER", "END"]
+    Path(path).write_text("\n".join(lines) + "\n")
+
+
+def merge_pdbfiles(input, save_to: Path, verbose: bool = True) -> None:
+    """Ordered merge of single- or multi-model PDB files into one multi-MODEL file."""
+    if isinstance(input, Path):
+        pdb_files = [f for f in input.iterdir() if f.suffix == ".pdb"]
+    elif isinstance(input, (list, tuple)):
+        pdb_files = list(input)
+    else:
+        raise ValueError(f"Unrecognized input type: {type(input)}")
+    assert len(pdb_files) > 0
+    save_to = Path(save_to)
+    save_to.parent.mkdir(parents=True, exist_ok=True)
+    n_model, out = 0, []
+    for f in pdb_files:
+        lines = Path(f).read_text().splitlines()
+        if not any(ln.startswith(("MODEL", "ENDMDL")) for ln in lines):
+            n_model += 1
+            out.append(f"MODEL     {n_model}")
+            out.extend(ln.strip() for ln in lines if ln.startswith(("TER", "ATOM")))
+            out.append("ENDMDL")
+            continue
+        for ln in lines:
+            if ln.startswith("MODEL"):
+                n_model += 1
+                if n_model > 1:
+                    out.append("ENDMDL")
+                out.append(f"MODEL     {n_model}")
+            elif ln.startswith("END"):
+                continue
+            elif ln.startswith(("TER", "ATOM")):
+                out.append(ln.strip())
+    out += ["ENDMDL", "END"]
+    save_to.write_text("\n".join(ln.ljust(80) for ln in out) + "\n")
+    if verbose:
+        print(f"Merged {len(pdb_files)} PDB files into {save_to} with {n_model} models.")
+
+
+def timer(func):
+    """Prints the elapsed time and appends it to a tuple result; a None result passes through."""
+    def wrapper(*args, **kwargs):
+        t0 = time.time()
+        result = func(*args, **kwargs)
+        if result is None:
+            return None
+        dt = time.time() - t0
+        print(f"Elapsed time ({func.__name__}): {dt:.2f} sec")
+        return (*result, float(f"{dt:.2f}"))
+    return wrapper

@@ -1,0 +1,178 @@
+"""Sampling CLI with the reference's interface (/root/reference/slm/sample_esmdiff.py:236-294):
+
+    python -m esmdiff_amd.sample_esmdiff --input data/targets/bpti --ckpt release_v0.pt --mode ddpm \\
+           --num_steps 25 --num_samples 100 --output output/inference_esmdiff
+
+Same flags and defaults (--input --ckpt --output --mode{gibbs,ddpm} --num_steps --num_samples --mask_ids).
+Extensions: --seed, --random_init (ESM3-open-sized random weights when no checkpoint is available offline),
+--synthetic_len (a random sequence instead of --input), --n_max_residue_square (the reference's batching
+heuristic, sample_esmdiff.py:146; the default here is larger because an MI355X holds 288 GB), --parity
+(draw uniforms like the reference's CPU path).  Multi-GPU: launch with torch.distributed.run; the samples are
+sharded over ranks and rank 0 writes the output.
+
+Output: the reference decodes tokens to backbone coordinates with ESM3's VQ-VAE decoder and writes a
+multi-MODEL PDB (sample_esmdiff.py:225-231).  That decoder is outside this build, so the
+structure TOKENS are written to `<out>/<name>.tokens.npy` (N, L int16) next to a JSON with the run settings.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+from pathlib import Path
+from time import strftime, time
+
+import numpy as np
+import torch
+
+from . import constants as C
+from .dist import gather_ids, shard_samples
+from .pdbio import timer
+from .sdk import ESMProtein, encode_sequence
+
+DEFAULT_NMAX = 1026 * 1026 * 32
+
+
+def batch_sizes(n_tokens: int, num_samples: int, n_max_residue_square: int = DEFAULT_NMAX):
+    """sample_esmdiff.py:181-193 (the length is the TOKEN count in ddpm mode)."""
+    sq = n_tokens * n_tokens
+    total = sq * num_samples
+    bsz = [n_max_residue_square // sq] * (total // n_max_residue_square)
+    if total % n_max_residue_square > 0:
+        bsz.append(num_samples - sum(bsz))
+    assert sum(bsz) == num_samples, f"{sum(bsz)} != {num_samples}"
+    return bsz
+
+
+@timer
+@torch.no_grad()
+def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: str, num_samples: int = 5,
+                       num_steps: int = 10, eps: float = 1e-5, n_max_residue_square: int = DEFAULT_NMAX,
+                       coordinates=None, mask_ids=None, structure_tokens=None, sample_max_t: float = 1.0,
+                       seed: int = 0, noise: str = "philox", timestamp: bool = True):
+    """sample_esmdiff.py:137-233.  `structure_tokens` (L+2, with BOS/EOS) replaces what the reference gets from
+    ESM3.encode(coordinates) for the inpainting prior (:196-201); without it mask_ids cannot be honoured."""
+    model = pl_model
+    str_time = ("_" + strftime("%Y%m%d-%H%M%S")) if timestamp else ""
+    output_dir = Path(output_dir) / f"step{num_steps}_eps{eps}_N{num_samples}{str_time}"
+    save_to = output_dir / f"{sample_basename}.tokens.npy"
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0:
+        print(f"Results will save to {save_to}")
+    if save_to.exists():
+        print(f"Skip existing {save_to}")
+        return None
+    if mask_ids is not None:
+        assert structure_tokens is not None, "Need structure tokens of the known residues for masking"
+        seq_l = list(sequence)
+        for idx in mask_ids:
+            assert 0 <= idx < len(seq_l), f"Invalid mask index {idx} for sequence of length {len(seq_l)}"
+            seq_l[idx] = C.MASK_RESIDUE
+        sequence = "".join(seq_l)
+    seq_tok = encode_sequence(sequence)
+    start_t = time()
+    offset, count = shard_samples(num_samples, world, rank)
+    outs = []
+    done = 0
+    for bs in batch_sizes(seq_tok.numel(), count, n_max_residue_square) if count else []:
+        batch = seq_tok[None, :].repeat(bs, 1)
+        prior = None
+        if mask_ids is not None:
+            prior = torch.as_tensor(structure_tokens, dtype=torch.int64)[None, :].repeat(bs, 1)
+            for idx in mask_ids:                       # token-space index, exactly like sample_esmdiff.py:200-201
+                prior[:, idx] = C.STRUCTURE_MASK_TOKEN
+        outs.append(model.ddpm_sample(num_steps=num_steps, sequence_tokens=batch, eps=eps, input_prior=prior,
+                                      sample_max_t=sample_max_t, seed=seed, sample_offset=offset + done, noise=noise))
+        done += bs
+    L = seq_tok.numel()
+    local = torch.cat(outs, 0) if outs else torch.empty(0, L, dtype=torch.int64, device=model.device)
+    tokens = gather_ids(local, num_samples)[:, 1:-1]          # remove bos and eos positions (:220-221)
+    torch.cuda.synchronize()
+    if rank == 0:
+        print(f"Sampling token time: {time() - start_t:.2f}s")
+        output_dir.mkdir(parents=True, exist_ok=True)
+        np.save(save_to, tokens.cpu().numpy().astype(np.int16))
+        (output_dir / f"{sample_basename}.json").write_text(json.dumps(
+            {"sequence": sequence, "num_steps": num_steps, "num_samples": num_samples, "eps": eps, "seed": seed,
+             "noise": noise, "world_size": world, "sampling_seconds": round(time() - start_t, 3)}, indent=1))
+        print(f"Total time: {time() - start_t:.2f}s")
+    return []
+
+
+def minibatch_gibbs_by_esm(*a, **k):
+    raise NotImplementedError(
+        "--mode gibbs (esm.utils.generation.iterative_sampling_raw: entropy-ordered unmasking with temperature / "
+        "top-p, sample_esmdiff.py:66-130) is not built yet (SURVEY.md 8f-2); use --mode ddpm")
+
+
+def get_argparser(argv=None):
+    p = argparse.ArgumentParser(description="Evaluate the ensemble of protein structures.")
+    p.add_argument("--input", type=str, default="data/targets/bpti", help="Path to the data directory.")
+    p.add_argument("--ckpt", type=str, default=None, help="Path to the model checkpoint.")
+    p.add_argument("--output", type=str, default="output/inference_esmdiff")
+    p.add_argument("--mode", type=str, default="gibbs", choices=["gibbs", "ddpm"])
+    p.add_argument("--num_steps", type=int, default=25, help="Number of denoising steps.")
+    p.add_argument("--num_samples", type=int, default=10, help="Number of samples to generate.")
+    p.add_argument("--mask_ids", type=str, default=None, help="Comma-separated list of masked indices.")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--random_init", action="store_true", help="ESM3-open-sized random weights instead of --ckpt")
+    p.add_argument("--synthetic_len", type=int, default=0, help="sample a random sequence of this length")
+    p.add_argument("--n_max_residue_square", type=int, default=DEFAULT_NMAX)
+    p.add_argument("--parity", action="store_true", help="uniforms from torch's CPU generator, like the reference")
+    p.add_argument("--no_timestamp", action="store_true")
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = get_argparser(argv)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.mode == "gibbs":
+        minibatch_gibbs_by_esm()
+    if args.ckpt is None and not args.random_init:
+        raise SystemExit("ddpm mode needs --ckpt (or --random_init for synthetic weights)")
+    from .model import load_state_dict_from_lightning_ckpt, random_init_model
+
+    targets = []
+    if args.synthetic_len:
+        g = torch.Generator().manual_seed(args.seed)
+        ids = torch.randint(4, 24, (args.synthetic_len,), generator=g)
+        targets.append((f"synthetic{args.synthetic_len}", "".join(C.SEQUENCE_VOCAB[int(i)] for i in ids)))
+    else:
+        data_path = Path(args.input)
+        assert data_path.is_dir(), f"Invalid directory {data_path} (Currently we only support pdb files in a folder as input)."
+        for p in sorted(q for q in data_path.iterdir() if q.suffix == ".pdb"):
+            targets.append((p.stem, ESMProtein.from_pdb(p).sequence))      # throw away other entities
+    max_len = max(len(s) for _, s in targets) + 2
+    per_rank = -(-args.num_samples // world)
+    max_b = max(1, min(per_rank, args.n_max_residue_square // (max_len * max_len)))
+    if args.random_init:
+        model = random_init_model(seed=args.seed, max_batch=max_b, max_len=max_len, device=local_rank)
+    else:
+        model = load_state_dict_from_lightning_ckpt(args.ckpt, device=f"cuda:{local_rank}", max_batch=max_b,
+                                                    max_len=max_len)
+    if rank == 0:
+        print(f">>> Sampling mode = {args.mode} ...")
+    mask_ids = [int(i) for i in args.mask_ids.split(",")] if args.mask_ids else None
+    if mask_ids is not None:
+        raise SystemExit("--mask_ids needs structure tokens of the known residues, i.e. the VQ-VAE encoder "
+                         "(SURVEY.md 8f-4); call ddpm_sample_by_esm(structure_tokens=...) from Python instead")
+    for name, seq in targets:
+        ddpm_sample_by_esm(seq, model, Path(args.output), name, num_samples=args.num_samples,
+                           num_steps=args.num_steps, n_max_residue_square=args.n_max_residue_square,
+                           seed=args.seed, noise="torch-cpu" if args.parity else "philox",
+                           timestamp=not args.no_timestamp)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,78 @@
+"""The SDK names the sampling CLI uses from `esm.sdk.api` (/root/reference/slm/sample_esmdiff.py:13-18),
+re-created so that the reference's call sites keep working against this engine: ESMProtein,
+ESMProteinTensor, GenerationConfig, and the sequence tokenizer ([ESM-RECALL] vocabulary, constants.py).
+
+Not covered this round: the VQ-VAE structure encoder/decoder, so `ESMProtein.to_pdb` needs
+coordinates that something else supplied, and coordinates are not turned into structure tokens.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import constants as C
+from .pdbio import read_pdb_backbone, write_backbone_pdb
+
+_TOK = {t: i for i, t in enumerate(C.SEQUENCE_VOCAB)}
+
+
+def encode_sequence(sequence: str) -> torch.Tensor:
+    """'<cls>' + residues + '<eos>' (ids 0 … 2); '_' is the mask residue (slm/models/utils.py:121)."""
+    ids = [C.SEQUENCE_BOS_TOKEN]
+    for ch in sequence:
+        ids.append(C.SEQUENCE_MASK_TOKEN if ch == C.MASK_RESIDUE else _TOK.get(ch, _TOK["X"]))
+    ids.append(C.SEQUENCE_EOS_TOKEN)
+    return torch.tensor(ids, dtype=torch.int64)
+
+
+def decode_sequence(tokens) -> str:
+    return "".join(C.MASK_RESIDUE if int(t) == C.SEQUENCE_MASK_TOKEN else C.SEQUENCE_VOCAB[int(t)] for t in tokens)
+
+
+@dataclass
+class ESMProtein:
+    sequence: Optional[str] = None
+    coordinates: Optional[torch.Tensor] = None   # (L, 3 | 37, 3)
+    structure_tokens: Optional[torch.Tensor] = None  # (L,) ids without BOS/EOS (this engine's output)
+    plddt: Optional[torch.Tensor] = None
+
+    @classmethod
+    def from_pdb(cls, path, chain_id: Optional[str] = None) -> "ESMProtein":
+        seq, xyz = read_pdb_backbone(path, chain_id)
+        return cls(sequence=seq, coordinates=torch.from_numpy(xyz))
+
+    def to_pdb(self, path) -> None:
+        if self.coordinates is None:
+            raise NotImplementedError(
+                "to_pdb needs coordinates; this engine emits structure TOKENS and the VQ-VAE decoder "
+                "(esm StructureTokenDecoder) is not part of this build yet (SURVEY.md 8f-1)")
+        write_backbone_pdb(path, self.sequence, np.asarray(self.coordinates)[:, :3, :])
+
+    def __len__(self):
+        return len(self.sequence) if self.sequence is not None else 0
+
+
+@dataclass
+class ESMProteinTensor:
+    sequence: Optional[torch.Tensor] = None    # with BOS/EOS
+    structure: Optional[torch.Tensor] = None   # with BOS/EOS
+    coordinates: Optional[torch.Tensor] = None
+
+    def to(self, device):
+        mv = lambda t: None if t is None else t.to(device)
+        return ESMProteinTensor(mv(self.sequence), mv(self.structure), mv(self.coordinates))
+
+
+@dataclass
+class GenerationConfig:
+    track: str = "structure"
+    num_steps: int = 16
+    temperature: float = 1.0
+    top_p: float = 1.0
+    schedule: str = "cosine"
+    strategy: str = "entropy"
+    invalid_ids: Optional[List[int]] = None
+    condition_on_coordinates_only: bool = True

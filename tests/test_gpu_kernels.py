@@ -324,3 +324,64 @@ def test_ddpm_sample_end_to_end_vs_oracle(tiny):
     o2 = eng.ddpm_sample(seq.cuda(), sch, seed=1, input_prior=prior.cuda()).cpu()
     keep = prior != MASK
     assert torch.equal(o2[keep], prior[keep]) and int((o2 == MASK).sum()) == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# drop-in surface: model wrapper, checkpoint loader, CLI
+def test_model_wrapper_reference_rng_parity(tmp_path):
+    """ddpm_sample(noise="torch-cpu") consumes torch's CPU uniform stream exactly like the reference
+    (model.py:27): driving the ORACLE's torch sampler (restated model.py) around the engine's logits with the same
+    seed gives the same ids at every position; and the checkpoint loader accepts the reference's 'module' layout."""
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.model import load_state_dict_from_lightning_ckpt
+    from esmdiff_amd.schedule import timestep_embedding
+    from esmdiff_amd.weights import random_init_state_dict
+    from oracle import sampler_ref as R
+    from types import SimpleNamespace
+    sd = random_init_state_dict(TINY, seed=4)
+    ck = tmp_path / "run" / "checkpoints" / "tiny.pt"
+    ck.parent.mkdir(parents=True)
+    torch.save({"module": sd}, ck)
+    model = load_state_dict_from_lightning_ckpt(ck, device="cuda:0", max_batch=4, max_len=40, cfg=TINY)
+    assert model.noise_removal is True
+    with pytest.raises(FileNotFoundError):
+        load_state_dict_from_lightning_ckpt(tmp_path / "nope.pt")
+    B, L, T = 2, 20, 4
+    g = torch.Generator().manual_seed(1)
+    seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1)
+    got = model.ddpm_sample(seq, num_steps=T, seed=123, noise="torch-cpu").cpu()
+
+    class EngineNet:                     # the oracle sampler sees the ENGINE's logits (identical inputs)
+        def __call__(self, structure_tokens=None, sequence_tokens=None, auxiliary_embeddings=None, labels=None):
+            lg = model.net.forward_logits(structure_tokens.cuda(), sequence_tokens.cuda(), self.tf)
+            return SimpleNamespace(structure_logits=lg.float().cpu().contiguous())
+
+    net = EngineNet()
+
+    class Emb:                            # records the sinusoid the engine needs; its MLP runs on the device
+        def __call__(self, sigma):
+            net.tf = timestep_embedding(sigma[:1].float(), TINY.freq_dim)[0]
+            return torch.zeros(sigma.shape[0], TINY.d_model)
+
+    ora = R.MDLMSamplerRef(net, Emb(), R.LogLinearNoiseRef(), True, True)
+    torch.manual_seed(123)
+    want = ora.ddpm_sample(seq, T)
+    assert torch.equal(got, want)
+    # error behaviour mirrored from model.py:556,562
+    with pytest.raises(AssertionError):
+        model.ddpm_sample(seq, num_steps=2, sample_max_t=0.5)
+    with pytest.raises(AssertionError):
+        model.ddpm_sample(seq, num_steps=2, input_prior=torch.zeros(B, L + 1, dtype=torch.int64))
+    model.net.close()
+
+
+def test_cli_ddpm_full_size_random_init(tmp_path):
+    """The CLI end to end on ESM3-open-sized random weights: 58-residue synthetic target, 4 samples, 3 steps."""
+    from esmdiff_amd.sample_esmdiff import main
+    main(["--mode", "ddpm", "--random_init", "--synthetic_len", "58", "--num_samples", "4", "--num_steps", "3",
+          "--output", str(tmp_path), "--no_timestamp", "--seed", "3"])
+    out = tmp_path / "step3_eps1e-05_N4" / "synthetic58.tokens.npy"
+    ids = np.load(out)
+    assert ids.shape == (4, 58) and ids.min() >= 0 and ids.max() <= 4100 and (ids != 4096).all()
+    with pytest.raises(NotImplementedError):
+        main(["--random_init", "--synthetic_len", "8"])          # default --mode gibbs, like the reference
