@@ -30,7 +30,8 @@ UNITS = {
     "convert": [],
     "sampler": ["-ffp-contract=off"],
 }
-COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
+EXTRA = os.environ.get("ESMDIFF_EXTRA_CXXFLAGS", "").split()
+COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -47,10 +48,14 @@ def _newest_src() -> float:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    if LIB.exists() and not force and LIB.stat().st_mtime >= _newest_src():
-        return LIB
     LIBDIR.mkdir(exist_ok=True)
     OBJDIR.mkdir(exist_ok=True)
+    stamp = OBJDIR / "flags.txt"
+    flags = " ".join(COMMON)
+    if not stamp.exists() or stamp.read_text() != flags:   # different flags (e.g. -DED_GEMM_DEBUG): rebuild all
+        force = True
+    if LIB.exists() and not force and LIB.stat().st_mtime >= _newest_src():
+        return LIB
     cc = _hipcc()
     headers = [p.stat().st_mtime for p in list(CSRC.glob("*.h")) + [INCLUDE / "esmdiff_hip.h"]]
 
@@ -73,6 +78,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
+    stamp.write_text(flags)
     return LIB
 
 

@@ -17,6 +17,8 @@
 // K and V^T tiles are 64 rows x 128 B, staged by LDS-DMA with the same source-side XOR swizzle as the
 // GEMM (conflict-free ds_read_b128 for K; 2-way for the 8-byte V^T reads), double buffered.
 // q arrives pre-scaled by log2(e)/8 (qk_norm_rope), so the softmax runs on exp2.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace ed {
@@ -33,12 +35,15 @@ __device__ __forceinline__ void glds16a(const void* gsrc, void* lds_dst_wave_uni
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
 }
 
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
-  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-  ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
-  ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
-  return ua | (ub << 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+  const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);
+  uint32_t u;
+  __builtin_memcpy(&u, &v, 4);
+  return u;
 }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // bare v_exp_f32
 
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ q,
                                                            const bf16_t* __restrict__ k,
@@ -99,13 +104,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  for (int kt = 0; kt < nkt; ++kt) {
+  // Rescale threshold (log2 units): the running max is only raised when a tile's max exceeds it by more than
+  // THR, so P <= 2^THR instead of <= 1 (exact in f32 accumulation; bf16 P keeps its relative precision) and the
+  // 32-register O rescale is skipped on almost every tile.  The decision sits between S and P of the SAME tile
+  // and no P·V is pending across it, so everything at the old scale (O and l) is rescaled exactly once.
+  constexpr float THR = 8.0f;
+  auto tile = [&](int kt, auto MASKED) {
     const int cur = kt & 1;
     if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
     if (active) {
       const char* kl = smem + cur * (2 * KV_BYTES);
       const char* vl = kl + KV_BYTES;
-      // ---- S^T = K · Q^T -----------------------------------------------------------------------
       f32x16 s[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -118,40 +127,39 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
           s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[t], 0, 0, 0);
         }
       }
-      // ---- mask keys >= L (last tile only; wave-uniform branch) ---------------------------------
-      if (kt * KV_TILE + KV_TILE > L) {
+      if constexpr (decltype(MASKED)::value) {  // keys >= L exist only in the last tile
+        const int lim = L - kt * KV_TILE - 4 * hi;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kt * KV_TILE + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            if (key >= L) s[t][r] = -1e30f;
-          }
+          for (int r = 0; r < 16; ++r)
+            if (t * 32 + (r & 3) + 8 * (r >> 2) >= lim) s[t][r] = -1e30f;
       }
-      // ---- online softmax (base 2) -------------------------------------------------------------
       float mx = s[0][0];
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f(m_run - m_new);
-      m_run = m_new;
+      if (!__all(mx - m_run <= THR)) {
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = fast_exp2(m_run - m_new);
+        m_run = m_new;
+        l_run *= alpha;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+      }
       float ps = 0.f;
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          s[t][r] = exp2f(s[t][r] - m_new);
+          s[t][r] = fast_exp2(s[t][r] - m_run);
           ps += s[t][r];
         }
-      l_run = l_run * alpha + ps;
-#pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-      // ---- O^T += V^T · P^T ; k-step kk covers keys kk*16 + 4*hi + {0..3, 8..11} ------------------
+      l_run += ps;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int t = kk >> 1, r0 = (kk & 1) * 8;
@@ -170,7 +178,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-  }
+  };
+  for (int kt = 0; kt + 1 < nkt; ++kt) tile(kt, std::false_type{});
+  if (nkt * KV_TILE > L) tile(nkt - 1, std::true_type{});
+  else tile(nkt - 1, std::false_type{});
 
   if (!active) return;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

@@ -93,18 +93,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
       const int am = min(m0 + r, M - 1);
       a_off[h][i] = (uint32_t)(((int64_t)am * K + schunk * 8) * 2);
       w_off[h][i] = (uint32_t)(((int64_t)(n0 + r) * K + schunk * 8) * 2);
+#ifdef ED_GEMM_DEBUG
+      if (ED_DBG(32)) {  // timing experiment only: every DMA reads one contiguous 1-KiB unit (pre-tiled operands)
+        const int rb = (h * 128 + (i * 8 + wave) * 8) >> 3;
+        a_off[h][i] = (uint32_t)((((int64_t)(min(m0, M - 256) >> 3) + rb) * (K / 64)) * 1024 + lane * 16);
+        w_off[h][i] = (uint32_t)((((int64_t)(n0 >> 3) + rb) * (K / 64)) * 1024 + lane * 16);
+      }
+#endif
     }
+#ifdef ED_GEMM_DEBUG
+  const int kstride = ED_DBG(32) ? 1024 : BK * 2;
+#else
+  constexpr int kstride = BK * 2;
+#endif
   const char* Ab = reinterpret_cast<const char*>(A);
   const char* Wb = reinterpret_cast<const char*>(W);
   auto issue_Ah = [&](int h, int buf, int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      glds16(Ab + (size_t)kt * (BK * 2) + a_off[h][i], smem + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+      glds16(Ab + (size_t)kt * kstride + a_off[h][i], smem + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
   };
   auto issue_Wh = [&](int h, int buf, int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      glds16(Wb + (size_t)kt * (BK * 2) + w_off[h][i],
+      glds16(Wb + (size_t)kt * kstride + w_off[h][i],
              smem + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
   };
   auto issue_A = [&](int buf, int kt) {
@@ -112,14 +124,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        glds16(Ab + (size_t)kt * (BK * 2) + a_off[h][i], smem + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+        glds16(Ab + (size_t)kt * kstride + a_off[h][i], smem + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
   };
   auto issue_W = [&](int buf, int kt) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        glds16(Wb + (size_t)kt * (BK * 2) + w_off[h][i],
+        glds16(Wb + (size_t)kt * kstride + w_off[h][i],
                smem + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
   };
 
