@@ -148,7 +148,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     offA[ks] = lds0 + (wm * 2) * HALF_BYTES + lo;
     offB[ks] = lds0 + ((2 + (wn >> 1)) * 2) * HALF_BYTES + (wn & 1) * (64 * 128) + lo;
   }
-#define ED_DSR(dst, addr, imm) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+#define ED_DSR(dst, addr, imm)                                                                       \
+  do {                                                                                               \
+    if (!ED_DBG(1)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm)); \
+  } while (0)
   // half-sets: A[f][j] = rows (mh*64 + f*32 ..), k-step 2*h + j ; B[j] = cols (nh*32 ..), k-step 2*h + j
   auto read_A = [&](bf16x8 (&a)[2][2], auto P, auto MH, auto H) {
     constexpr int mh = decltype(MH)::value, h = decltype(H)::value;
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     for (int r = 0; r < 16; ++r) (&acc[0][0][0])[i][r] = 0.0f;
 
   auto mma = [&](int mh, int nh, const bf16x8 (&a)[2][2], const bf16x8 (&b)[2]) {
+    if (ED_DBG(64)) return;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
