@@ -213,14 +213,15 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
   if (M <= 0) return hipSuccess;
   if (N % BN != 0 || K % BK != 0 || (ldc & 3)) return hipErrorInvalidValue;
   {
-    // tile selection: the 256x256 counted-vmcnt kernel for large M, this 128x128 kernel otherwise.
-    // ESMDIFF_GEMM_TILE=128|256 forces one (A/B benchmarking and tests).
+    // Tile selection: the 256x256 kernel (one workgroup per CU) for large M, this 128x128 kernel (2 workgroups
+    // per CU) otherwise.  ESMDIFF_GEMM_TILE=128|256 forces one (A/B benchmarking and tests).
+    // (Measured and rejected: splitting the rows so that 256-row tiles fill whole 256-CU rounds and the leftover
+    // rows go through this kernel — 93 + 29 us apart, 138 us back to back, vs 132 us unsplit at N = K = 1536.)
     static const int forced = [] {
       const char* e = getenv("ESMDIFF_GEMM_TILE");
       return e ? atoi(e) : 0;
     }();
-    const bool ok256 = (N % 256 == 0);
-    if (ok256 && (forced == 256 || (forced == 0 && M >= 1024)))
+    if (N % 256 == 0 && (forced == 256 || (forced == 0 && M >= 1024)))
       return launch_gemm256_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
   }
   const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
