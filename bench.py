@@ -173,6 +173,12 @@ def main():
                                             + 2 * cfg.ffn_hidden * cfg.d_model)
                             + 2 * cfg.d_model * cfg.d_model + 2 * cfg.d_model * cfg.n_structure_heads)
         n_fwd = (T + 1) * args.steps
+        traffic, traffic_note = None, "no PMC pass on record"
+        tp = ROOT / "profiles" / "r01_gemm_traffic.json"
+        if tp.exists() and not args.tiny and M == 25800:   # separate rocprofv3 --pmc passes of this same kernel/shape
+            tj = json.loads(tp.read_text())
+            traffic, traffic_note = tj["traffic_bytes_per_launch"], ("profiles/r01_gemm_traffic.json: FETCH_SIZE x2 "
+                                                                      "(gfx950 correction) + WRITE_SIZE, fabric-level")
         out = {
             "metric": "conformation samples/sec (256-res, 25 steps)",
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -188,7 +194,9 @@ def main():
             "mfma_frac_whole_job": round(value / world * f_sample / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "g256::gemm256_kernel<SWIGLU> (FFN-up, M=%d N=%d K=%d)" % (M, 2 * cfg.ffn_hidden, cfg.d_model),
                          "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
+                         "algorithmic_flop_per_launch": flop_up,
                          "launch_ms": round(ms_up, 4), "launches": up["launches"],
                          "all_gemm_tflops": round(lin_flop_fwd * n_fwd / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms else None},
             "sections_ms_per_forward": {k: round(v["ms"] / n_fwd, 3) for k, v in prof.items()},
