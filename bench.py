@@ -105,7 +105,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch.distributed as dist
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -126,17 +127,17 @@ def main():
     seq1 = torch.cat([torch.tensor([0]), torch.randint(4, 24, (args.residues,), generator=g), torch.tensor([2])])
     seq = seq1[None].repeat(B, 1).to(dev)
     sch = ddpm_schedule(T, freq_dim=cfg.freq_dim)
-    gathered = [torch.empty(B, L * 2, dtype=torch.uint8, device=dev) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty(B, L * 2, dtype=torch.uint8, device=dev) for _ in range(world)] if use_dist else None
 
     def one_step(step_idx):
         ids = eng.ddpm_sample(seq, sch, seed=args.seed + step_idx, sample_offset=rank * B)
-        if world > 1:                                            # one exchange at the end: int16 ids over RCCL
+        if use_dist:                                             # one exchange at the end: int16 ids over RCCL
             dist.all_gather(gathered, ids.to(torch.int16).view(torch.uint8))
         return ids
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -150,7 +151,7 @@ def main():
     sync()
     t1 = time.perf_counter()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     prof = eng.get_profile()
@@ -209,7 +210,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -385,3 +385,51 @@ def test_cli_ddpm_full_size_random_init(tmp_path):
     assert ids.shape == (4, 58) and ids.min() >= 0 and ids.max() <= 4100 and (ids != 4096).all()
     with pytest.raises(NotImplementedError):
         main(["--random_init", "--synthetic_len", "8"])          # default --mode gibbs, like the reference
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5 at their full token counts (small model): size-independent properties
+def test_config4_long_chain_batch_properties():
+    """config 4: L_tok = 1026, num_samples = 32, 25 steps — the reference would split this into nine batches
+    (sample_esmdiff.py:181-193); here it is one batch of 32 832 token rows through the tiled-key attention."""
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ModelConfig(d_model=512, n_heads=8, v_heads=32, n_layers=2)
+    eng = Engine(cfg, random_init_state_dict(cfg, 5, device="cuda"), max_batch=32, max_len=1026)
+    B, L, T = 32, 1026, 25
+    g = torch.Generator().manual_seed(4)
+    seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1).cuda()
+    sch = ddpm_schedule(T)
+    out = eng.ddpm_sample(seq, sch, seed=9)
+    assert out.shape == (B, L) and int((out == MASK).sum()) == 0 and int(out.max()) <= 4100
+    assert torch.equal(out, eng.ddpm_sample(seq, sch, seed=9))                      # deterministic
+    sub = eng.ddpm_sample(seq[:3], sch, seed=9, sample_offset=7)                    # rows 7..9 alone
+    assert torch.equal(sub, out[7:10])                                             # batch / shard independent
+    assert len({tuple(r.tolist()) for r in out[:, :64].cpu()}) == B                 # samples differ
+    eng.close()
+
+
+def test_config5_inpainting_prior_properties(tiny):
+    """config 5 shape: L_tok = 258, 100 samples, 50 steps, a 64-position mask window (partial-mask resample):
+    known tokens are carried through bit for bit, only the window is drawn."""
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    eng = Engine(TINY, random_init_state_dict(TINY, 6, device="cuda"), max_batch=100, max_len=258)
+    B, L, T = 100, 258, 50
+    g = torch.Generator().manual_seed(5)
+    seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1).cuda()
+    prior = torch.randint(0, 4096, (1, L), generator=g).repeat(B, 1)
+    prior[:, 0], prior[:, -1] = 4098, 4097
+    prior[:, 97:161] = MASK                                   # residues 96..159 (token index = residue + 1)
+    sch = ddpm_schedule(T)
+    out = eng.ddpm_sample(seq, sch, seed=2, input_prior=prior.cuda()).cpu()
+    keep = prior != MASK
+    assert torch.equal(out[keep], prior[keep]) and int((out == MASK).sum()) == 0
+    assert int((out[:, 97:161] < 4096).sum()) > 0.99 * B * 64
+    half = eng.ddpm_sample(seq[:50], sch, seed=2, sample_offset=50, input_prior=prior[:50].cuda()).cpu()
+    assert torch.equal(half, out[50:])
+    eng.close()
