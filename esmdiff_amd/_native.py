@@ -35,7 +35,8 @@ class Rng(ctypes.Structure):
 
 EXPORTS = [
     "esmdiff_abi_version", "esmdiff_engine_create", "esmdiff_engine_destroy", "esmdiff_last_error",
-    "esmdiff_forward_logits", "esmdiff_ddpm_step", "esmdiff_ddpm_sample", "esmdiff_gemm_bf16",
+    "esmdiff_forward_logits", "esmdiff_ddpm_step", "esmdiff_ddpm_sample", "esmdiff_gibbs_step",
+    "esmdiff_gibbs_sample", "esmdiff_gemm_bf16",
     "esmdiff_gemm_bf16_timed", "esmdiff_layernorm_bf16", "esmdiff_attention_bf16", "esmdiff_set_profiling",
     "esmdiff_get_profile",
 ]
@@ -66,6 +67,8 @@ def lib():
     L.esmdiff_forward_logits.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
     L.esmdiff_ddpm_step.argtypes = [vp, vp, vp, i32, f32, f32, i32, vp, ctypes.POINTER(Rng), i32, i32, i32, vp]
     L.esmdiff_ddpm_sample.argtypes = [vp, vp, vp, i32, i32, i32, c_f32p, c_f32p, c_f32p, ctypes.POINTER(Rng), vp]
+    L.esmdiff_gibbs_step.argtypes = [vp, vp, vp, vp, i32, f32, f32, vp, vp, ctypes.POINTER(Rng), i32, i32, i32, vp]
+    L.esmdiff_gibbs_sample.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, ctypes.POINTER(i32), ctypes.POINTER(Rng), vp]
     L.esmdiff_gemm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     L.esmdiff_gemm_bf16_timed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, c_f32p, vp]
     L.esmdiff_layernorm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, vp]

@@ -29,6 +29,7 @@ UNITS = {
     "embed": [],
     "convert": [],
     "sampler": ["-ffp-contract=off"],
+    "gibbs": ["-ffp-contract=off"],
 }
 EXTRA = os.environ.get("ESMDIFF_EXTRA_CXXFLAGS", "").split()
 COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",

@@ -54,7 +54,8 @@ struct esmdiff_engine {
   float* x = nullptr;
   bf16_t *h = nullptr, *h2 = nullptr, *qkv = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr,
          *mid = nullptr, *dlt = nullptr;
-  float *logits = nullptr, *cond = nullptr, *sig_hidden = nullptr, *tfreq = nullptr;
+  float *logits = nullptr, *cond = nullptr, *sig_hidden = nullptr, *tfreq = nullptr, *g_entropy = nullptr;
+  int32_t *g_sampled = nullptr, *g_nunmask = nullptr;
   int ld_logits = 0, Lp_max = 0, tfreq_rows = 0;
   // profiling
   bool profiling = false;
@@ -266,7 +267,7 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
   const int D = cfg->d_model, H = cfg->n_heads, FH = cfg->ffn_hidden, V = cfg->vocab_out, F = cfg->freq_dim;
   if (D != H * 64) return fail(nullptr, ESMDIFF_E_INVALID, "d_model (%d) must be n_heads (%d) x 64", D, H);
   if (D % 512 || D > 2048) return fail(nullptr, ESMDIFF_E_INVALID, "d_model must be a multiple of 512, <= 2048");
-  if (FH % 128 || cfg->n_layers <= 0 || V <= ESMDIFF_MASK_ID || V > 5120 || F <= 0 || cfg->max_batch <= 0 || cfg->max_len <= 0)
+  if (FH % 128 || cfg->n_layers <= 0 || V < ESMDIFF_MASK_ID || V > 5120 || F <= 0 || cfg->max_batch <= 0 || cfg->max_len <= 0)
     return fail(nullptr, ESMDIFF_E_INVALID, "invalid configuration");
 
   esmdiff_engine* e = new esmdiff_engine;
@@ -405,6 +406,9 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
     TRY(dalloc(e, &e->sig_hidden, (size_t)D));
     e->tfreq_rows = 1026;
     TRY(dalloc(e, &e->tfreq, (size_t)e->tfreq_rows * F));
+    TRY(dalloc(e, &e->g_entropy, Mx));
+    TRY(dalloc(e, &e->g_sampled, Mx));
+    TRY(dalloc(e, &e->g_nunmask, (size_t)e->tfreq_rows * cfg->max_batch));
   }
 #undef TRY
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "engine create: %s", hipGetErrorString(hipGetLastError())));
@@ -428,6 +432,7 @@ int esmdiff_ddpm_step(esmdiff_engine* e, int64_t* x_inout, const float* logits, 
   if (!x_inout || !logits) return fail(e, ESMDIFF_E_INVALID, "null pointer");
   if (!final_ && !u && !rng) return fail(e, ESMDIFF_E_INVALID, "need explicit uniforms or an rng");
   if (B <= 0 || L <= 0 || ld_logits < e->cfg.vocab_out) return fail(e, ESMDIFF_E_INVALID, "bad shape");
+  if (e->cfg.vocab_out <= ESMDIFF_MASK_ID) return fail(e, ESMDIFF_E_INVALID, "ddpm needs the 4101-way head (mask column)");
   Prof p{e, (hipStream_t)stream};
   p.mark(S_SAMPLER);
   HIP_TRY(e, launch_ddpm_step(x_inout, logits, ld_logits, e->cfg.vocab_out, mc_t, mc_s, final_, u, u ? 0 : 1,
@@ -455,6 +460,42 @@ int esmdiff_ddpm_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout,
     HIP_TRY(e, launch_ddpm_step(x_inout, e->logits, e->ld_logits, e->cfg.vocab_out, fin ? 0.f : mc_t[i], fin ? 0.f : mc_s[i],
                                 fin, nullptr, 1, rng->seed, rng->sample_offset, i, B, L, st));
     p.mark(S_SAMPLER);
+  }
+  return 0;
+}
+
+int esmdiff_gibbs_step(esmdiff_engine* e, int64_t* x_inout, const int64_t* seq, const float* logits, int32_t ld_logits,
+                       float temperature, float top_p, const int32_t* n_unmask, const float* u, const esmdiff_rng* rng,
+                       int32_t step, int32_t B, int32_t L, void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!x_inout || !seq || !logits || !n_unmask) return fail(e, ESMDIFF_E_INVALID, "null pointer");
+  if (!u && !rng) return fail(e, ESMDIFF_E_INVALID, "need explicit uniforms or an rng");
+  if (!(temperature > 0.f)) return fail(e, ESMDIFF_E_INVALID, "temperature must be > 0 (argmax decoding is not built)");
+  if (!(top_p > 0.f)) return fail(e, ESMDIFF_E_INVALID, "top_p must be in (0, 1]");
+  if (ld_logits < 4096) return fail(e, ESMDIFF_E_INVALID, "bad shape");
+  if (int r = check_bl(e, B, L)) return r;
+  Prof p{e, (hipStream_t)stream};
+  p.mark(S_SAMPLER);
+  HIP_TRY(e, launch_gibbs_step(x_inout, seq, logits, ld_logits, temperature, top_p, n_unmask, u, u ? 0 : 1, rng ? rng->seed : 0,
+                               rng ? rng->sample_offset : 0, step, e->g_sampled, e->g_entropy, B, L, (hipStream_t)stream));
+  p.mark(S_SAMPLER);
+  return 0;
+}
+
+int esmdiff_gibbs_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout, int32_t B, int32_t L, int32_t T,
+                         float temperature, float top_p, const int32_t* n_unmask_table, const esmdiff_rng* rng,
+                         void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!seq || !x_inout || !n_unmask_table || !rng) return fail(e, ESMDIFF_E_INVALID, "null pointer");
+  if (T <= 0 || T > e->tfreq_rows) return fail(e, ESMDIFF_E_INVALID, "num_steps %d out of range (1..%d)", T, e->tfreq_rows);
+  if (int r = check_bl(e, B, L)) return r;
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(e, hipMemcpyAsync(e->g_nunmask, n_unmask_table, (size_t)T * B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  for (int i = 0; i < T; ++i) {
+    if (int r = forward(e, seq, x_inout, nullptr, e->logits, e->ld_logits, B, L, st)) return r;
+    if (int r = esmdiff_gibbs_step(e, x_inout, seq, e->logits, e->ld_logits, temperature, top_p, e->g_nunmask + (size_t)i * B,
+                                   nullptr, rng, i, B, L, stream))
+      return r;
   }
   return 0;
 }

@@ -15,6 +15,14 @@ hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, floa
                             const float* u, int use_philox, uint64_t seed, uint64_t sample_offset, int step,
                             int B, int L, hipStream_t stream);
 
+// ---- gibbs.hip ---------------------------------------------------------------------------------
+// one entropy-ordered unmasking step: per masked row nucleus(top_p) + temperature draw + entropy, then per prompt
+// the n_unmask[b] lowest-entropy masked positions take their token.  u: [B,L,4096] explicit uniforms or null.
+hipError_t launch_gibbs_step(int64_t* x, const int64_t* seq, const float* logits, int ld, float temperature,
+                             float top_p, const int32_t* n_unmask, const float* u, int use_philox, uint64_t seed,
+                             uint64_t sample_offset, int step, int32_t* sampled, float* entropy, int B, int L,
+                             hipStream_t stream);
+
 // ---- gemm.hip --------------------------------------------------------------------------------
 // out = epilogue(A[M,K] · W[N,K]^T); K % 64 == 0, N % 128 == 0 (weights are padded at load time).
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,

@@ -147,6 +147,44 @@ class Engine:
                                                 ctypes.byref(rng), _stream()))
         return x
 
+    def gibbs_step(self, x: torch.Tensor, sequence_tokens: torch.Tensor, logits: torch.Tensor, temperature: float,
+                   top_p: float, n_unmask: torch.Tensor, *, u: Optional[torch.Tensor] = None,
+                   seed: Optional[int] = None, sample_offset: int = 0, step: int = 0) -> torch.Tensor:
+        """One entropy-ordered unmasking step in place (esmdiff_gibbs_step).  n_unmask: (B,) int32."""
+        B, L = x.shape
+        assert x.dtype == torch.int64 and x.is_cuda and x.is_contiguous()
+        assert logits.dtype == torch.float32 and logits.is_cuda and logits.stride(-1) == 1
+        ld = logits.stride(1)
+        seq = self._tok(sequence_tokens, B, L)
+        nu = n_unmask.to(device=self.device, dtype=torch.int32).contiguous()
+        rng = None
+        if u is not None:
+            u = u.to(device=self.device, dtype=torch.float32).contiguous()
+            assert u.shape == (B, L, 4096)
+        elif seed is None:
+            raise ValueError("gibbs_step needs explicit uniforms `u` or a Philox `seed`")
+        if seed is not None:
+            rng = N.Rng(int(seed), int(sample_offset))
+        self._chk(self._lib.esmdiff_gibbs_step(self._h, _ptr(x), _ptr(seq), _ptr(logits), ld, float(temperature),
+                                               float(top_p), _ptr(nu), _ptr(u), ctypes.byref(rng) if rng else None,
+                                               int(step), B, L, _stream()))
+        return x
+
+    def gibbs_sample(self, sequence_tokens: torch.Tensor, x0: torch.Tensor, n_unmask_table: torch.Tensor,
+                     temperature: float, top_p: float, *, seed: int, sample_offset: int = 0) -> torch.Tensor:
+        """Whole iterative-unmasking loop on the device (esmdiff_gibbs_sample).  n_unmask_table: (T,B) int32."""
+        B, L = sequence_tokens.shape
+        seq = self._tok(sequence_tokens, B, L)
+        x = x0.to(device=self.device, dtype=torch.int64).contiguous().clone()
+        tab = n_unmask_table.detach().to("cpu", torch.int32).contiguous()
+        T = tab.shape[0]
+        assert tab.shape == (T, B)
+        rng = N.Rng(int(seed), int(sample_offset))
+        self._chk(self._lib.esmdiff_gibbs_sample(self._h, _ptr(seq), _ptr(x), B, L, T, float(temperature), float(top_p),
+                                                 tab.numpy().ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                                 ctypes.byref(rng), _stream()))
+        return x
+
     # ---- per-kernel entry points (parity tests / roofline bench) ---------------------------------
     def set_profiling(self, on: bool):
         self._chk(self._lib.esmdiff_set_profiling(self._h, int(on)))

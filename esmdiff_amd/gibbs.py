@@ -1,0 +1,79 @@
+"""`iterative_sampling_raw` for the structure track — the call the reference's "gibbs" mode makes
+(/root/reference/slm/sample_esmdiff.py:114-122):
+
+    out_list += iterative_sampling_raw(esm3_model, proteins=prot_list, configs=cfg_list)
+
+[ESM-RECALL] The function belongs to the un-vendored esm==3.0.4 package; semantics per SURVEY.md Appendix B:
+encode every protein, batch them, `num_steps = min(num_steps, #masked)`, and at step t unmask the
+`still_masked - int(cos((t+1)/T * pi/2) * total + 0.1)` lowest-entropy masked positions with tokens drawn from the
+temperature / top-p filtered distribution.  One forward + one fused kernel pair per step, all on the device.
+Not covered: coordinates as conditioning (geometric attention) and decoding tokens to coordinates.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Sequence
+
+import torch
+
+from . import constants as C
+from .sdk import ESMProtein, GenerationConfig, encode_sequence
+
+
+def cosine_schedule(t: float) -> float:
+    return math.cos(t * math.pi / 2)
+
+
+def unmask_schedule(total_to_sample: int, num_steps: int) -> List[int]:
+    T = min(num_steps, total_to_sample)
+    out, still = [], total_to_sample
+    for t in range(T):
+        after = int(cosine_schedule((t + 1) / T) * total_to_sample + 0.1)
+        k = max(still - after, 0)
+        out.append(k)
+        still -= k
+    return out
+
+
+def encode_structure_prior(protein: ESMProtein, n_tokens: int) -> torch.Tensor:
+    """Structure track with BOS/EOS; known tokens where the protein carries them, MASK elsewhere."""
+    x = torch.full((n_tokens,), C.STRUCTURE_MASK_TOKEN, dtype=torch.int64)
+    x[0], x[-1] = C.STRUCTURE_BOS_TOKEN, C.STRUCTURE_EOS_TOKEN
+    if protein.structure_tokens is not None:
+        st = torch.as_tensor(protein.structure_tokens, dtype=torch.int64)
+        assert st.numel() == n_tokens - 2
+        x[1:-1] = st
+    return x
+
+
+@torch.no_grad()
+def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequence[GenerationConfig], *,
+                           seed: int = 0, sample_offset: int = 0) -> List[ESMProtein]:
+    """client: an esmdiff_amd Engine, or an object with a `.net` Engine (the model wrapper)."""
+    eng = getattr(client, "net", client)
+    assert len(proteins) == len(configs) and len(proteins) > 0
+    cfg0 = configs[0]
+    for c in configs:
+        if c.track != "structure":
+            raise NotImplementedError("only the structure track is sampled by this engine")
+        if (c.num_steps, c.temperature, c.top_p) != (cfg0.num_steps, cfg0.temperature, cfg0.top_p):
+            raise NotImplementedError("one batch shares num_steps / temperature / top_p (the reference passes copies)")
+    seqs = [encode_sequence(p.sequence) for p in proteins]
+    L = seqs[0].numel()
+    if any(s.numel() != L for s in seqs):
+        raise ValueError("all proteins of a batch must have the same length")
+    seq = torch.stack(seqs)
+    x0 = torch.stack([encode_structure_prior(p, L) for p in proteins])
+    totals = (x0 == C.STRUCTURE_MASK_TOKEN).sum(1).tolist()
+    T = max(min(cfg0.num_steps, t) for t in totals) if max(totals) > 0 else 0
+    if T == 0:
+        out_x = x0
+    else:
+        table = torch.zeros(T, len(proteins), dtype=torch.int32)
+        for b, tot in enumerate(totals):
+            sch = unmask_schedule(tot, cfg0.num_steps)
+            table[: len(sch), b] = torch.tensor(sch, dtype=torch.int32)
+        out_x = eng.gibbs_sample(seq, x0, table, cfg0.temperature, cfg0.top_p, seed=seed,
+                                 sample_offset=sample_offset).cpu()
+    return [ESMProtein(sequence=p.sequence, coordinates=None, structure_tokens=out_x[b, 1:-1].clone())
+            for b, p in enumerate(proteins)]

@@ -10,6 +10,9 @@ heuristic, sample_esmdiff.py:146; the default here is larger because an MI355X h
 (draw uniforms like the reference's CPU path).  Multi-GPU: launch with torch.distributed.run; the samples are
 sharded over ranks and rank 0 writes the output.
 
+Both sampling modes are built: `--mode ddpm` (MDLM ancestral sampler) and the reference's default `--mode gibbs`
+(entropy-ordered iterative unmasking, temperature 1.4 / top-p 0.9).
+
 Output: the reference decodes tokens to backbone coordinates with ESM3's VQ-VAE decoder and writes a
 multi-MODEL PDB (sample_esmdiff.py:225-231).  That decoder is outside this build, so the
 structure TOKENS are written to `<out>/<name>.tokens.npy` (N, L int16) next to a JSON with the run settings.
@@ -100,10 +103,64 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
     return []
 
 
-def minibatch_gibbs_by_esm(*a, **k):
-    raise NotImplementedError(
-        "--mode gibbs (esm.utils.generation.iterative_sampling_raw: entropy-ordered unmasking with temperature / "
-        "top-p, sample_esmdiff.py:66-130) is not built yet (SURVEY.md 8f-2); use --mode ddpm")
+@timer
+@torch.no_grad()
+def minibatch_gibbs_by_esm(protseq, esm3_model, output_dir: Path, sample_basename: str, num_samples: int = 10,
+                           num_steps: int = 16, temperature: float = 1.4, top_p: float = 0.9,
+                           n_max_residue_square: int = DEFAULT_NMAX, coordinates=None, mask_ids=None,
+                           structure_tokens=None, seed: int = 0, timestamp: bool = True):
+    """sample_esmdiff.py:66-130: batches of ESMProtein copies through iterative_sampling_raw with
+    GenerationConfig(track="structure", num_steps, temperature, top_p).  Coordinates are accepted for interface
+    parity but do not condition the model here (geometric attention is not built); for inpainting
+    pass the known residues' `structure_tokens` (L,) and `mask_ids`."""
+    from .gibbs import iterative_sampling_raw
+    from .sdk import GenerationConfig
+    str_time = ("_" + strftime("%Y%m%d-%H%M%S")) if timestamp else ""
+    output_dir = Path(output_dir) / f"T{temperature}_step{num_steps}_topp{top_p}_N{num_samples}{str_time}"
+    save_to = output_dir / f"{sample_basename}.tokens.npy"
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank == 0:
+        print(f"Results will save to {save_to}")
+    if save_to.exists():
+        print(f"Skip existing {save_to}")
+        return None
+    st = None
+    if mask_ids is not None:
+        print(f"Masking {len(mask_ids)} residues and inpainting...")
+        assert structure_tokens is not None, "Need structure tokens of the known residues for masking"
+        protseq = list(protseq)
+        st = torch.as_tensor(structure_tokens, dtype=torch.int64).clone()
+        for idx in mask_ids:
+            assert 0 <= idx < len(protseq), f"Invalid mask index {idx} for sequence of length {len(protseq)}"
+            protseq[idx] = C.MASK_RESIDUE
+            st[idx] = C.STRUCTURE_MASK_TOKEN
+        protseq = "".join(protseq)
+    start_t = time()
+    offset, count = shard_samples(num_samples, world, rank)
+    out_tokens, done = [], 0
+    for bs in batch_sizes(len(protseq), count, n_max_residue_square) if count else []:
+        prot_list = [ESMProtein(sequence=protseq, coordinates=coordinates, structure_tokens=st) for _ in range(bs)]
+        if rank == 0:
+            print(f"Generating {len(prot_list)} samples for {protseq}...")
+        cfg_list = [GenerationConfig(track="structure", num_steps=num_steps, temperature=temperature, top_p=top_p)
+                    for _ in range(bs)]
+        outs = iterative_sampling_raw(esm3_model, proteins=prot_list, configs=cfg_list, seed=seed,
+                                      sample_offset=offset + done)
+        out_tokens += [o.structure_tokens for o in outs]
+        done += bs
+    dev = getattr(esm3_model, "net", esm3_model).device
+    local = (torch.stack(out_tokens) if out_tokens else torch.empty(0, len(protseq), dtype=torch.int64)).to(dev)
+    tokens = gather_ids(local, num_samples)
+    if rank == 0:
+        print(f"Sampling token time: {time() - start_t:.2f}s")
+        output_dir.mkdir(parents=True, exist_ok=True)
+        np.save(save_to, tokens.cpu().numpy().astype(np.int16))
+        (output_dir / f"{sample_basename}.json").write_text(json.dumps(
+            {"sequence": protseq, "mode": "gibbs", "num_steps": num_steps, "num_samples": num_samples,
+             "temperature": temperature, "top_p": top_p, "seed": seed, "world_size": world,
+             "sampling_seconds": round(time() - start_t, 3)}, indent=1))
+    return []
 
 
 def get_argparser(argv=None):
@@ -134,10 +191,12 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    if args.mode == "gibbs":
-        minibatch_gibbs_by_esm()
     if args.ckpt is None and not args.random_init:
-        raise SystemExit("ddpm mode needs --ckpt (or --random_init for synthetic weights)")
+        # the reference falls back to the stock esm3_sm_open_v1 weights in gibbs mode (sample_esmdiff.py:252-255);
+        # they cannot be fetched offline, so a checkpoint (or --random_init) is required in both modes here
+        assert args.mode == "gibbs" or args.ckpt is not None, \
+            "Only Gibbs sampling is supported for the pre-trained ESM3 model."
+        raise SystemExit("no weights: pass --ckpt <release_v0.pt> or --random_init (synthetic weights)")
     from .model import load_state_dict_from_lightning_ckpt, random_init_model
 
     targets = []
@@ -165,10 +224,15 @@ def main(argv=None):
         raise SystemExit("--mask_ids needs structure tokens of the known residues, i.e. the VQ-VAE encoder "
                          "(SURVEY.md 8f-4); call ddpm_sample_by_esm(structure_tokens=...) from Python instead")
     for name, seq in targets:
-        ddpm_sample_by_esm(seq, model, Path(args.output), name, num_samples=args.num_samples,
-                           num_steps=args.num_steps, n_max_residue_square=args.n_max_residue_square,
-                           seed=args.seed, noise="torch-cpu" if args.parity else "philox",
-                           timestamp=not args.no_timestamp)
+        if args.mode == "gibbs":
+            minibatch_gibbs_by_esm(seq, model, Path(args.output), name, num_samples=args.num_samples,
+                                   num_steps=args.num_steps, n_max_residue_square=args.n_max_residue_square,
+                                   seed=args.seed, timestamp=not args.no_timestamp)
+        else:
+            ddpm_sample_by_esm(seq, model, Path(args.output), name, num_samples=args.num_samples,
+                               num_steps=args.num_steps, n_max_residue_square=args.n_max_residue_square,
+                               seed=args.seed, noise="torch-cpu" if args.parity else "philox",
+                               timestamp=not args.no_timestamp)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

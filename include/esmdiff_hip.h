@@ -129,6 +129,22 @@ int esmdiff_ddpm_sample(esmdiff_engine* eng, const int64_t* seq, int64_t* x_inou
                         int32_t T, const float* mc_t, const float* mc_s, const float* t_freq,
                         const esmdiff_rng* rng, void* stream);
 
+/* Replaces, for ONE step, the per-prompt half of esm.utils.generation.iterative_sampling_raw as the reference calls
+ * it in "gibbs" mode (sample_esmdiff.py:114-122; [ESM-RECALL]): for every still-masked position
+ * entropy of softmax(logits over the 4096 codebook ids), nucleus filter (top_p), temperature, categorical draw; then
+ * per prompt the n_unmask[b] lowest-entropy masked positions (never BOS/EOS/PAD of `seq`) take their token.
+ * n_unmask: [B] int32 DEVICE; u: explicit uniforms [B,L,4096] or NULL with rng; temperature > 0. */
+int esmdiff_gibbs_step(esmdiff_engine* eng, int64_t* x_inout, const int64_t* seq, const float* logits,
+                       int32_t ld_logits, float temperature, float top_p, const int32_t* n_unmask, const float* u,
+                       const esmdiff_rng* rng, int32_t step, int32_t B, int32_t L, void* stream);
+
+/* The whole loop of iterative_sampling_raw for one batch on the device (Philox noise, no time conditioning):
+ * T x (forward, gibbs step).  n_unmask_table: [T,B] int32 [host] = positions to unmask per step and prompt
+ * (cosine schedule, computed by the host: esmdiff_amd/gibbs.py). */
+int esmdiff_gibbs_sample(esmdiff_engine* eng, const int64_t* seq, int64_t* x_inout, int32_t B, int32_t L, int32_t T,
+                         float temperature, float top_p, const int32_t* n_unmask_table, const esmdiff_rng* rng,
+                         void* stream);
+
 /* Per-kernel entry points (used by the parity tests and the bench's roofline leg). */
 
 /* C[M,N] (+)= A[M,K] · W[N,K]^T, bf16 in, f32 accumulate.  epilogue: see esmdiff_gemm_epilogue. */

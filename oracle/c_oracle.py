@@ -50,6 +50,11 @@ def lib():
         _lib.oracle_philox_uniforms.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
                                                 ctypes.c_uint32, ctypes.c_int, _f32p]
         _lib.oracle_philox_uniforms.restype = None
+        _lib.oracle_gibbs_step.argtypes = [_i64p, _i64p, _f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
+                                           ctypes.POINTER(ctypes.c_int32), _f32p, ctypes.c_uint64, ctypes.c_uint64,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p,
+                                           ctypes.POINTER(ctypes.c_int32)]
+        _lib.oracle_gibbs_step.restype = None
     return _lib
 
 
@@ -108,3 +113,25 @@ def philox_uniforms(seed, sample, step, l, vocab=4101):
     out = np.empty(vocab, dtype=np.float32)
     lib().oracle_philox_uniforms(int(seed), int(sample), int(step), int(l), vocab, out.ctypes.data_as(_f32p))
     return out
+
+
+def gibbs_step(x, seq, logits, temperature, top_p, n_unmask, u=None, seed=0, sample_offset=0, step=0,
+               return_aux=False):
+    """One entropy-ordered unmasking step (oracle_gibbs_step).  x, seq [B,L]; logits [B,L,ld>=4096];
+    n_unmask [B]; u [B,L,4096] or None (Philox)."""
+    x = np.array(x, dtype=np.int64, order="C", copy=True)
+    seq = np.ascontiguousarray(seq, dtype=np.int64)
+    B, L = x.shape
+    lg, lgp = _f32(logits)
+    nu = np.ascontiguousarray(n_unmask, dtype=np.int32)
+    up = None
+    if u is not None:
+        ua, up = _f32(u)
+        assert ua.shape == (B, L, 4096)
+    ent = np.full((B, L), np.inf, dtype=np.float32)
+    smp = np.full((B, L), -1, dtype=np.int32)
+    lib().oracle_gibbs_step(x.ctypes.data_as(_i64p), seq.ctypes.data_as(_i64p), lgp, lg.shape[2],
+                            np.float32(temperature), np.float32(top_p), nu.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                            up, int(seed), int(sample_offset), int(step), B, L, ent.ctypes.data_as(_f32p),
+                            smp.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+    return (x, ent, smp) if return_aux else x

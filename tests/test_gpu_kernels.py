@@ -383,8 +383,6 @@ def test_cli_ddpm_full_size_random_init(tmp_path):
     out = tmp_path / "step3_eps1e-05_N4" / "synthetic58.tokens.npy"
     ids = np.load(out)
     assert ids.shape == (4, 58) and ids.min() >= 0 and ids.max() <= 4100 and (ids != 4096).all()
-    with pytest.raises(NotImplementedError):
-        main(["--random_init", "--synthetic_len", "8"])          # default --mode gibbs, like the reference
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -433,3 +431,72 @@ def test_config5_inpainting_prior_properties(tiny):
     half = eng.ddpm_sample(seq[:50], sch, seed=2, sample_offset=50, input_prior=prior[:50].cuda()).cpu()
     assert torch.equal(half, out[50:])
     eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# "gibbs" mode (entropy-ordered iterative unmasking; esm iterative_sampling_raw, parity unpinned vs esm)
+@pytest.mark.parametrize("B,L,temp,top_p", [(2, 9, 1.4, 0.9), (3, 60, 0.7, 0.5), (2, 258, 1.0, 1.0)])
+def test_gibbs_step_bit_exact(tiny, B, L, temp, top_p):
+    from oracle import c_oracle
+    _, _, eng, _, _ = tiny
+    g = torch.Generator().manual_seed(L)
+    logits = torch.randn(B, L, 4104, generator=g) * 3
+    u = torch.rand(B, L, 4096, generator=g)
+    seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1)
+    x = torch.full((B, L), MASK, dtype=torch.int64)
+    x[:, 0], x[:, -1] = 4098, 4097
+    x[0, 2] = 5
+    n_un = torch.tensor([3, 1, 5][:B], dtype=torch.int32)
+    want = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), temp, top_p, n_un.numpy(), u=u.numpy())
+    got = eng.gibbs_step(x.clone().cuda(), seq.cuda(), logits.cuda(), temp, top_p, n_un, u=u.cuda()).cpu().numpy()
+    assert np.array_equal(got, want)
+    want = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), temp, top_p, n_un.numpy(), seed=11,
+                               sample_offset=2 ** 33 + 1, step=4)
+    got = eng.gibbs_step(x.clone().cuda(), seq.cuda(), logits.cuda(), temp, top_p, n_un, seed=11,
+                         sample_offset=2 ** 33 + 1, step=4).cpu().numpy()
+    assert np.array_equal(got, want)
+    assert ((got != x.numpy()).sum(1) == n_un.numpy()).all()
+
+
+def test_gibbs_iterative_sampling_raw_and_cli(tiny, tmp_path):
+    """The reference's gibbs call shape: lists of ESMProtein / GenerationConfig in, list of ESMProtein out."""
+    from esmdiff_amd.gibbs import iterative_sampling_raw, unmask_schedule
+    from esmdiff_amd.sdk import ESMProtein, GenerationConfig
+    from oracle import c_oracle
+    cfg, sd, eng, net, emb = tiny
+    seqs = "RPDFCLEPPYTGPCKARIIRYFYNAKAGLCQTFVYGGCRAKRNNFKSAEDCMRTCGGA"      # BPTI, data/targets/bpti
+    prots = [ESMProtein(sequence=seqs) for _ in range(3)]
+    cfgs = [GenerationConfig(track="structure", num_steps=16, temperature=1.4, top_p=0.9) for _ in range(3)]
+    out = iterative_sampling_raw(eng, prots, cfgs, seed=5)
+    assert len(out) == 3 and all(o.sequence == seqs and o.structure_tokens.shape == (58,) for o in out)
+    toks = torch.stack([o.structure_tokens for o in out])
+    assert int(toks.max()) < 4096 and int(toks.min()) >= 0
+    again = iterative_sampling_raw(eng, prots[1:2], cfgs[1:2], seed=5, sample_offset=1)
+    assert torch.equal(again[0].structure_tokens, toks[1])                  # shard independent
+    # first step against the oracle chain: f32 oracle forward (no time conditioning) + C oracle step
+    from esmdiff_amd.sdk import encode_sequence
+    seq = encode_sequence(seqs)[None]
+    x0 = torch.full((1, 60), MASK, dtype=torch.int64)
+    x0[0, 0], x0[0, -1] = 4098, 4097
+    k0 = unmask_schedule(58, 16)[0]
+    lg = eng.forward_logits(x0.cuda(), seq.cuda(), None)
+    got = eng.gibbs_step(x0.clone().cuda(), seq.cuda(), lg, 1.4, 0.9, torch.tensor([k0], dtype=torch.int32), seed=5).cpu()
+    want = c_oracle.gibbs_step(x0.numpy(), seq.numpy(), lg.float().cpu().numpy(), 1.4, 0.9, np.array([k0], np.int32), seed=5)
+    assert np.array_equal(got.numpy(), want) and int((got != x0).sum()) == k0
+    # inpainting: known tokens stay, only masked residues are sampled; num_steps is clamped to #masked
+    known = torch.randint(0, 4096, (58,))
+    known[10:14] = MASK
+    o2 = iterative_sampling_raw(eng, [ESMProtein(sequence=seqs, structure_tokens=known)],
+                                [GenerationConfig(track="structure", num_steps=50, temperature=1.0, top_p=1.0)], seed=1)
+    keep = known != MASK
+    assert torch.equal(o2[0].structure_tokens[keep], known[keep]) and int((o2[0].structure_tokens == MASK).sum()) == 0
+    with pytest.raises(NotImplementedError):
+        iterative_sampling_raw(eng, prots[:1], [GenerationConfig(track="sequence")])
+
+
+def test_cli_gibbs_default_mode(tmp_path):
+    from esmdiff_amd.sample_esmdiff import main
+    main(["--random_init", "--synthetic_len", "40", "--num_samples", "3", "--num_steps", "8", "--output", str(tmp_path),
+          "--no_timestamp", "--seed", "2"])                                # --mode defaults to gibbs, as in the reference
+    ids = np.load(tmp_path / "T1.4_step8_topp0.9_N3" / "synthetic40.tokens.npy")
+    assert ids.shape == (3, 40) and ids.min() >= 0 and ids.max() < 4096
