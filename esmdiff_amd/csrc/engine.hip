@@ -58,7 +58,7 @@ struct esmdiff_engine {
   int32_t *g_sampled = nullptr, *g_nunmask = nullptr;
   int ld_logits = 0, Lp_max = 0, tfreq_rows = 0;
   // profiling
-  bool profiling = false;
+  int profiling = 0;  // 0 off, 1 every launch, 2 only the dominant kernel (FFN-up GEMM)
   std::vector<hipEvent_t> ev;
   std::vector<int> ev_section;
   size_t ev_used = 0;
@@ -152,7 +152,7 @@ struct Prof {
   esmdiff_engine* e;
   hipStream_t s;
   void mark(int section) {
-    if (!e->profiling) return;
+    if (!e->profiling || (e->profiling == 2 && section != S_FFN_UP)) return;
     if (e->ev_used + 2 > e->ev.size()) {
       for (int i = 0; i < 4096; ++i) {
         hipEvent_t ev;
@@ -551,8 +551,16 @@ int esmdiff_attention_bf16(esmdiff_engine* e, const void* qkv, const float* q_ln
 
 int esmdiff_set_profiling(esmdiff_engine* e, int32_t on) {
   if (!e) return ESMDIFF_E_INVALID;
-  e->profiling = on != 0;
+  e->profiling = on;
   e->ev_used = 0;
+  if (on && e->ev.size() < 8192) {  // pre-create part of the event pool outside any timed region
+    for (int i = 0; i < 8192; ++i) {
+      hipEvent_t ev;
+      hipEventCreate(&ev);
+      e->ev.push_back(ev);
+      e->ev_section.push_back(0);
+    }
+  }
   memset(e->prof_ms, 0, sizeof e->prof_ms);
   memset(e->prof_launches, 0, sizeof e->prof_launches);
   return 0;

@@ -186,8 +186,9 @@ class Engine:
         return x
 
     # ---- per-kernel entry points (parity tests / roofline bench) ---------------------------------
-    def set_profiling(self, on: bool):
-        self._chk(self._lib.esmdiff_set_profiling(self._h, int(on)))
+    def set_profiling(self, mode):
+        """0/False off; 1/True HIP events around every launch; 2 only around the dominant kernel (FFN-up GEMM)."""
+        self._chk(self._lib.esmdiff_set_profiling(self._h, int(mode)))
 
     def get_profile(self) -> Dict[str, Dict[str, float]]:
         ms = (ctypes.c_float * 16)()

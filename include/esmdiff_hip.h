@@ -174,8 +174,9 @@ int esmdiff_layernorm_bf16(const float* x, const float* w, const float* b, void*
 int esmdiff_attention_bf16(esmdiff_engine* eng, const void* qkv, const float* q_ln_w, const float* k_ln_w,
                            void* ctx, int32_t B, int32_t L, void* stream);
 
-/* Accumulated per-section device time of the last esmdiff_forward_logits/ddpm_sample calls when
- * profiling is enabled (esmdiff_set_profiling(eng,1)); sections: 0 embed, 1 layernorm, 2 gemm_qkv,
+/* Accumulated per-section device time of the esmdiff_forward_logits/ddpm_sample calls since profiling was
+ * enabled: esmdiff_set_profiling(eng, 1) brackets every launch with HIP events on the launch stream (no sync);
+ * mode 2 brackets only the dominant kernel (FFN-up GEMM, section 6), cheap enough for a timed region; 0 = off. sections: 0 embed, 1 layernorm, 2 gemm_qkv,
  * 3 qk_norm_rope, 4 attention, 5 gemm_out, 6 gemm_ffn_up, 7 gemm_ffn_down, 8 head, 9 sampler.
  * ms_out: [16] floats, launches_out: [16] ints [host].  Synchronises the device. */
 int esmdiff_set_profiling(esmdiff_engine* eng, int32_t on);
