@@ -108,16 +108,28 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 #endif
   const char* Ab = reinterpret_cast<const char*>(A);
   const char* Wb = reinterpret_cast<const char*>(W);
+  // main-loop LDS-DMA: scalar base (operand + K-tile offset) + 32-bit per-lane offset, M0 = wave-uniform LDS
+  // destination.  Written as inline asm because hipcc otherwise materialises a 64-bit per-lane address
+  // (v_lshl_add_u64 + a VGPR pair) for every instruction.
+  const uint32_t lds_base = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+  auto glds16s = [&](const char* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_dst), "v"(voff), "s"(sbase)
+                 : "memory");
+  };
   auto issue_Ah = [&](int h, int buf, int kt) {
+    const char* sb = Ab + (size_t)kt * kstride;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      glds16(Ab + (size_t)kt * kstride + a_off[h][i], smem + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+      glds16s(sb, a_off[h][i], lds_base + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
   };
   auto issue_Wh = [&](int h, int buf, int kt) {
+    const char* sb = Wb + (size_t)kt * kstride;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      glds16(Wb + (size_t)kt * kstride + w_off[h][i],
-             smem + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+      glds16s(sb, w_off[h][i], lds_base + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
   };
   auto issue_A = [&](int buf, int kt) {
 #pragma unroll
@@ -172,17 +184,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   // counted wait that also makes the retired registers' readiness visible to the compiler ("+v")
 #define ED_WAIT_A(N, a)                                                                                       \
   do {                                                                                                        \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]));   \
+    if (!ED_DBG(128)) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]));   \
     ED_PHASE_FENCE();                                                                                         \
   } while (0)
 #define ED_WAIT_B(N, b)                                                   \
   do {                                                                    \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]));   \
+    if (!ED_DBG(128)) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]));   \
     ED_PHASE_FENCE();                                                     \
   } while (0)
 #define ED_WAIT_AB(N, a, b)                                                                                  \
   do {                                                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                 \
+    if (!ED_DBG(128)) asm volatile("s_waitcnt lgkmcnt(" #N ")"                                               \
                  : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[0]), "+v"(b[1]));      \
     ED_PHASE_FENCE();                                                                                        \
   } while (0)
