@@ -500,3 +500,38 @@ def test_cli_gibbs_default_mode(tmp_path):
           "--no_timestamp", "--seed", "2"])                                # --mode defaults to gibbs, as in the reference
     ids = np.load(tmp_path / "T1.4_step8_topp0.9_N3" / "synthetic40.tokens.npy")
     assert ids.shape == (3, 40) and ids.min() >= 0 and ids.max() < 4096
+
+
+# ---------------------------------------------------------------------------------------------------
+# error behaviour of the boundary (status codes -> RuntimeError; the reference: assert / strict load_state_dict)
+def test_engine_error_behaviour(tiny):
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg, sd, eng, _, _ = tiny
+    # strict weight table (checkpoint_utils.py:64 load_state_dict): a missing or mis-shaped tensor is an error
+    bad = dict(sd)
+    del bad["net.transformer.blocks.1.ffn.3.weight"]
+    with pytest.raises(RuntimeError, match="missing weight 'transformer.blocks.1.ffn.3.weight'"):
+        Engine(TINY, bad, 2, 16)
+    bad = dict(sd)
+    bad["net.transformer.norm.weight"] = torch.ones(7)
+    with pytest.raises(RuntimeError, match="transformer.norm.weight"):
+        Engine(TINY, bad, 2, 16)
+    # capacity: engine was created for max_batch=8, max_len=300
+    seq = torch.zeros(9, 20, dtype=torch.int64).cuda()
+    with pytest.raises(RuntimeError, match="capacity"):
+        eng.ddpm_sample(seq, ddpm_schedule(2), seed=0)
+    with pytest.raises(RuntimeError, match="capacity"):
+        eng.forward_logits(torch.zeros(1, 301, dtype=torch.int64).cuda(), torch.zeros(1, 301, dtype=torch.int64).cuda(), None)
+    # noise source is mandatory for a sampling step
+    lg = torch.zeros(1, 4, 4104, device="cuda")
+    with pytest.raises(ValueError):
+        eng.ddpm_step(torch.full((1, 4), MASK, dtype=torch.int64).cuda(), lg, 0.5, 0.4)
+    with pytest.raises(RuntimeError, match="temperature"):
+        eng.gibbs_step(torch.full((1, 4), MASK, dtype=torch.int64).cuda(), torch.zeros(1, 4, dtype=torch.int64), lg, 0.0, 0.9,
+                       torch.ones(1, dtype=torch.int32), seed=1)
+    # the engine keeps working after errors
+    out = eng.ddpm_sample(torch.tensor([[0, 5, 6, 7, 2]]).cuda(), ddpm_schedule(2), seed=0)
+    assert out.shape == (1, 5) and int((out == MASK).sum()) == 0
