@@ -20,6 +20,10 @@
 //              spread over g8, g1', g2', g3' (2 each): measured with s_memtime, the CU's address path takes
 //              ~25-45 cycles per 1-KiB LDS-DMA, and a burst of 64 of them right after the barrier stalled the
 //              younger four waves for 1.2-2k cycles in instruction issue.
+//   tiles      persistent workgroups (one per CU) walk tiles b, b+G, ...; the K-tile LDS-DMA stream runs across the
+//              tile boundary (K-tile 0 of the next tile lands in stage 0 during the last K-tile and the epilogue,
+//              which therefore stages its output through the stage-1 regions only), so a tile pays neither the
+//              DMA latency of its first K-tile nor a workgroup relaunch.
 //   raster     XCD-contiguous, 8(M) x 4(N) super-tiles: the 32 tiles resident on one XCD share 8 A panels and
 //              4 W panels in that XCD's L2.
 #include <stdlib.h>
@@ -67,15 +71,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
                                                          int tiles_n, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x 64 KiB
 
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  const int per_group = GROUP_M * tiles_n;
-  const int grp = lin / per_group, in_grp = lin - grp * per_group;
-  const int gm0 = grp * GROUP_M;
-  const int gsz = min(GROUP_M, tiles_m - gm0);
-  const int mt = gm0 + in_grp % gsz, nt = in_grp / gsz;
-  const int m0 = mt * BM, n0 = nt * BN;
+  // Persistent workgroups: workgroup b (on XCD b % 8) walks the virtual tile indices b, b + G, b + 2G, ... (G = grid
+  // size, a multiple of 8, so every index it visits maps to its own XCD's contiguous run of tiles).
+  const int n_tiles = tiles_m * tiles_n, bid = blockIdx.x;
+  auto tile_origin = [&](int vt, int& m0_, int& n0_) {
+    const int xcd = vt & 7, qq = n_tiles >> 3, rr = n_tiles & 7;
+    const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (vt >> 3);
+    const int per_group = GROUP_M * tiles_n;
+    const int grp = lin / per_group, in_grp = lin - grp * per_group;
+    const int gm0 = grp * GROUP_M;
+    const int gsz = min(GROUP_M, tiles_m - gm0);
+    m0_ = (gm0 + in_grp % gsz) * BM;
+    n0_ = (in_grp / gsz) * BN;
+  };
+  int m0, n0;
+  tile_origin(bid, m0, n0);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,28 +94,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   // ---- LDS-DMA sources: half-tile = 128 rows = 16 wave-instructions of 8 rows; wave issues i = 0,1 ----
   const int srow = lane >> 3;
   const int schunk = (lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
-  uint32_t a_off[2][2], w_off[2][2];
+  uint32_t a_off[2][2], w_off[2][2];      // this tile
+  uint32_t a_offn[2][2], w_offn[2][2];    // next tile of this workgroup (its K-tile 0 is prefetched across the boundary)
+  auto set_offsets = [&](uint32_t (&ao)[2][2], uint32_t (&wo)[2][2], int m0_, int n0_) {
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = h * 128 + (i * 8 + wave) * 8 + srow;
-      const int am = min(m0 + r, M - 1);
-      a_off[h][i] = (uint32_t)(((int64_t)am * K + schunk * 8) * 2);
-      w_off[h][i] = (uint32_t)(((int64_t)(n0 + r) * K + schunk * 8) * 2);
-#ifdef ED_GEMM_DEBUG
-      if (ED_DBG(32)) {  // timing experiment only: every DMA reads one contiguous 1-KiB unit (pre-tiled operands)
-        const int rb = (h * 128 + (i * 8 + wave) * 8) >> 3;
-        a_off[h][i] = (uint32_t)((((int64_t)(min(m0, M - 256) >> 3) + rb) * (K / 64)) * 1024 + lane * 16);
-        w_off[h][i] = (uint32_t)((((int64_t)(n0 >> 3) + rb) * (K / 64)) * 1024 + lane * 16);
+      for (int i = 0; i < 2; ++i) {
+        const int r = h * 128 + (i * 8 + wave) * 8 + srow;
+        const int am = min(m0_ + r, M - 1);
+        ao[h][i] = (uint32_t)(((int64_t)am * K + schunk * 8) * 2);
+        wo[h][i] = (uint32_t)(((int64_t)(n0_ + r) * K + schunk * 8) * 2);
       }
-#endif
-    }
-#ifdef ED_GEMM_DEBUG
-  const int kstride = ED_DBG(32) ? 1024 : BK * 2;
-#else
+  };
+  set_offsets(a_off, w_off, m0, n0);
   constexpr int kstride = BK * 2;
-#endif
   const char* Ab = reinterpret_cast<const char*>(A);
   const char* Wb = reinterpret_cast<const char*>(W);
   // main-loop LDS-DMA: scalar base (operand + K-tile offset) + 32-bit per-lane offset, M0 = wave-uniform LDS
@@ -119,17 +122,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
                  : "s"(lds_dst), "v"(voff), "s"(sbase)
                  : "memory");
   };
-  auto issue_Ah = [&](int h, int buf, int kt) {
-    const char* sb = Ab + (size_t)kt * kstride;
+  // piece = 128 rows of one operand (2 instructions per wave).  v is a K-tile index of the CURRENT tile, or nk + 0 for
+  // K-tile 0 of the NEXT tile (xnext), which keeps the DMA stream running across the tile boundary.
+  bool xnext = false;
+  int nk_ = K / BK;
+  auto issue_Ah = [&](int h, int buf, int v) {
+    if (v < nk_) {
+      const char* sb = Ab + (size_t)v * kstride;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      glds16s(sb, a_off[h][i], lds_base + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+      for (int i = 0; i < 2; ++i) glds16s(sb, a_off[h][i], lds_base + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+    } else if (xnext && v == nk_) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) glds16s(Ab, a_offn[h][i], lds_base + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+    }
   };
-  auto issue_Wh = [&](int h, int buf, int kt) {
-    const char* sb = Wb + (size_t)kt * kstride;
+  auto issue_Wh = [&](int h, int buf, int v) {
+    if (v < nk_) {
+      const char* sb = Wb + (size_t)v * kstride;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      glds16s(sb, w_off[h][i], lds_base + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+      for (int i = 0; i < 2; ++i)
+        glds16s(sb, w_off[h][i], lds_base + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+    } else if (xnext && v == nk_) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        glds16s(Wb, w_offn[h][i], lds_base + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+    }
   };
   auto issue_A = [&](int buf, int kt) {
 #pragma unroll
@@ -200,10 +217,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   } while (0)
 
   f32x16 acc[2][2][2];  // [mh][f][nh]
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) (&acc[0][0][0])[i][r] = 0.0f;
 
   auto mma = [&](int mh, int nh, const bf16x8 (&a)[2][2], const bf16x8 (&b)[2]) {
     if (ED_DBG(64)) return;
@@ -220,23 +233,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
   bf16x8 A0a[2][2], A0b[2][2], A1a[2][2], A1b[2][2], B0a[2], B0b[2], B1a[2], B1b[2];
-  const int nk = K / BK;
-
-  issue_A(0, 0);
-  issue_W(0, 0);
-  if (nk > 1) {
-    issue_A(1, 1);
-    issue_W(1, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();
-  ED_PHASE_FENCE();
-  read_A(A0a, I0{}, I0{}, I0{});
-  read_B(B0a, I0{}, I0{}, I0{});
-  read_B(B1a, I0{}, I1{}, I0{});
-  ED_PHASE_FENCE();
+  const int nk = nk_;
 
   // One K-tile at stage P.  Read sets are issued two groups ahead of their first use; the LGKM queue holds
   // only these ds_reads, in order, so each wait is "all but the N youngest".
@@ -244,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 #ifdef ED_GEMM_DEBUG
   unsigned long long* trace = nullptr;
   if constexpr (EPI == ESMDIFF_EPI_BF16) {
-    if (bias != nullptr && bid == 40) trace = reinterpret_cast<unsigned long long*>(const_cast<float*>(bias));
+    if (bias != nullptr && blockIdx.x == 40) trace = reinterpret_cast<unsigned long long*>(const_cast<float*>(bias));
   }
 #define ED_STAMP(i)                                                                     \
   do {                                                                                  \
@@ -257,17 +254,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     using Q = std::integral_constant<int, 1 - decltype(P)::value>;
     ED_STAMP(0);
     // g1  C00 += A0h0·B0h0   (+ second quarter of the refill of the other stage with K-tile t+1)
-    if (t >= 1 && t + 1 < nk && !ED_DBG(2)) issue_Wh(1, Q::value, t + 1);
+    if (t >= 1 && !ED_DBG(2)) issue_Wh(1, Q::value, t + 1);
     read_A(A1a, P, I1{}, I0{});            // queue 12
     ED_WAIT_AB(6, A0a, B0a);
     mma(0, 0, A0a, B0a);
     // g2  C01 += A0h0·B1h0
-    if (t >= 1 && t + 1 < nk && !ED_DBG(2)) issue_Ah(0, Q::value, t + 1);
+    if (t >= 1 && !ED_DBG(2)) issue_Ah(0, Q::value, t + 1);
     read_A(A1b, P, I1{}, I1{});            // [B1a 2][A1a 4][A1b 4]
     ED_WAIT_B(8, B1a);
     mma(0, 1, A0a, B1a);
     // g3  C11 += A1h0·B1h0
-    if (t >= 1 && t + 1 < nk && !ED_DBG(2)) issue_Ah(1, Q::value, t + 1);
+    if (t >= 1 && !ED_DBG(2)) issue_Ah(1, Q::value, t + 1);
     read_B(B0b, P, I0{}, I1{});            // [A1a 4][A1b 4][B0b 2]
     ED_WAIT_A(6, A1a);
     mma(1, 1, A1a, B1a);
@@ -292,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     ED_STAMP(4);
     ED_PHASE_FENCE();
     // g8  C00 += A0h1·B0h1
-    if (t + 2 < nk && !ED_DBG(2)) issue_Wh(0, decltype(P)::value, t + 2);
+    if (!ED_DBG(2)) issue_Wh(0, decltype(P)::value, t + 2);
     if (t + 1 < nk) {
       read_A(A0a, Q{}, I0{}, I0{});
       read_B(B0a, Q{}, I0{}, I0{});
@@ -304,81 +301,155 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     ED_STAMP(6);
   };
 
-  int t = 0;
-  for (; t + 1 < nk; t += 2) {
-    ktile(t, I0{});
-    ktile(t + 1, I1{});
-  }
-  if (t < nk) ktile(t, I0{});
-
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  // ---- epilogue: per wave, two rounds (mh) of 64 rows through a private 16 KiB LDS slab ------------
-  float* slab = reinterpret_cast<float*>(smem) + wave * (64 * 64);
-  constexpr int SW = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? 32 : 64;
-  constexpr int LPR = SW / 4, RPI = 64 / LPR;
-  const int ccol = lane & 31, rhalf = lane >> 5;
-  const int rr_ = lane / LPR, c4 = (lane % LPR) * 4;
-  const int ncol0 = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? (n0 + wn * 64) / 2 : (n0 + wn * 64);
-#pragma unroll
-  for (int mh = 0; mh < 2; ++mh) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      if constexpr (EPI == ESMDIFF_EPI_SWIGLU_BF16) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-          const float g = acc[mh][f][0][r], u = acc[mh][f][1][r];
-          slab[row * SW + ccol] = (g / (1.0f + __expf(-g))) * u;
-        }
+  // ---- tile loop -----------------------------------------------------------------------------------------
+  const bool can_xprefetch = (nk % 2 == 0);  // the last K-tile must sit in stage 1 so that stage 0 can take the next tile
+  bool have_k0 = false;                      // K-tile 0 of the current tile already landed in stage 0
+#ifdef ED_GEMM_DEBUG
+  int tileno = 0;
+#define ED_TSTAMP(i)                                                                                              \
+  do {                                                                                                            \
+    if (trace && tileno < 8 && lane == 0) trace[2048 + (wave * 8 + tileno) * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define ED_TSTAMP(i) do { } while (0)
+#endif
+  // All tiles take the same time, so without a nudge every CU reaches its epilogue at once and the chip sees a
+  // 16-32 MB store burst per round (s_memtime: epilogue = 10-12 % of a tile).  A start skew of 0..3 x ~2k cycles
+  // between neighbouring workgroups of an XCD spreads the bursts (+1 % measured; 2x the skew: same).
+  for (int i = 0; i < ((bid >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(32);
+  for (int vt = bid; vt < n_tiles; vt += gridDim.x) {
+    const int vtn = vt + gridDim.x;
+    ED_TSTAMP(0);
+    xnext = can_xprefetch && vtn < n_tiles;
+    int m0n = 0, n0n = 0;
+    if (xnext) {
+      tile_origin(vtn, m0n, n0n);
+      set_offsets(a_offn, w_offn, m0n, n0n);
+    }
+    if (!have_k0) {
+      issue_A(0, 0);
+      issue_W(0, 0);
+      if (nk > 1) {
+        issue_A(1, 1);
+        issue_W(1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    } else {
+      issue_A(1, 1);  // stage 1 was the previous tile's epilogue slab; the barrier after that epilogue freed it
+      issue_W(1, 1);
+    }
+    ED_PHASE_FENCE();
+    read_A(A0a, I0{}, I0{}, I0{});
+    read_B(B0a, I0{}, I0{}, I0{});
+    read_B(B1a, I0{}, I1{}, I0{});
 #pragma unroll
-        for (int nh = 0; nh < 2; ++nh)
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) (&acc[0][0][0])[i][r] = 0.0f;
+    ED_PHASE_FENCE();
+    ED_TSTAMP(1);
+
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+      ktile(t, I0{});
+      ktile(t + 1, I1{});
+    }
+    if (t < nk) ktile(t, I0{});
+    ED_TSTAMP(2);
+
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    ED_TSTAMP(3);
+
+    // ---- epilogue: accumulators -> private 8 KiB LDS slab (64 rows x 32 floats) -> whole-row global stores.
+    // The slabs live in the four STAGE-1 regions only: with cross-tile prefetch stage 0 already holds K-tile 0 of
+    // the next tile.  Rounds: (mh, nh) quadrants; SwiGLU pairs nh = 0 (gate) with nh = 1 (up) in registers.
+    float* slab = reinterpret_cast<float*>(smem + ((wave >> 1) * 2 + 1) * HALF_BYTES + (wave & 1) * 8192);
+    constexpr int NROUND_N = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? 1 : 2;
+    const int ccol = lane & 31, rhalf = lane >> 5;
+    const int rr_ = lane >> 3, c4 = (lane & 7) * 4;  // 8 lanes per 32-float row, 8 rows per iteration
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+      for (int nr = 0; nr < NROUND_N; ++nr) {
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-            slab[row * SW + nh * 32 + ccol] = acc[mh][f][nh][r];
+            if constexpr (EPI == ESMDIFF_EPI_SWIGLU_BF16) {
+              const float g = acc[mh][f][0][r], u = acc[mh][f][1][r];
+              slab[row * 32 + ccol] = (g / (1.0f + __expf(-g))) * u;
+            } else {
+              slab[row * 32 + ccol] = acc[mh][f][nr][r];
+            }
           }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int ncol0 = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? (n0 + wn * 64) / 2 : (n0 + wn * 64 + nr * 32);
 #pragma unroll 4
-    for (int it = 0; it < 64 / RPI; ++it) {
-      const int row = it * RPI + rr_;
-      const int m = m0 + wm * 128 + mh * 64 + row;
-      if (m >= M || ED_DBG(4)) continue;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * SW + c4);
-      const int n = ncol0 + c4;
-      if constexpr (EPI == ESMDIFF_EPI_BF16 || EPI == ESMDIFF_EPI_SWIGLU_BF16) {
-        const float sc = (EPI == ESMDIFF_EPI_BF16) ? alpha : 1.0f;
-        uint2 pk;
-        pk.x = pack_bf16x2(v[0] * sc, v[1] * sc);
-        pk.y = pack_bf16x2(v[2] * sc, v[3] * sc);
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = pk;
-      } else if constexpr (EPI == ESMDIFF_EPI_RESID_F32) {
-        float* o = reinterpret_cast<float*>(out) + (int64_t)m * ldc + n;
-        f32x4 x = *reinterpret_cast<const f32x4*>(o);
-        x[0] += v[0] * alpha; x[1] += v[1] * alpha; x[2] += v[2] * alpha; x[3] += v[3] * alpha;
-        *reinterpret_cast<f32x4*>(o) = x;
-      } else if constexpr (EPI == ESMDIFF_EPI_BIAS_GELU_BF16) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
-        uint2 pk;
-        pk.x = pack_bf16x2(gelu_erf(v[0] + bb[0]), gelu_erf(v[1] + bb[1]));
-        pk.y = pack_bf16x2(gelu_erf(v[2] + bb[2]), gelu_erf(v[3] + bb[3]));
-        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = pk;
-      } else {
-        if (n + 4 <= ldc) {
-          const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
-          f32x4 x;
-          x[0] = v[0] + bb[0]; x[1] = v[1] + bb[1]; x[2] = v[2] + bb[2]; x[3] = v[3] + bb[3];
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (int64_t)m * ldc + n) = x;
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 8 + rr_;
+          const int m = m0 + wm * 128 + mh * 64 + row;
+          if (m >= M || ED_DBG(4)) continue;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 32 + c4);
+          const int n = ncol0 + c4;
+          if constexpr (EPI == ESMDIFF_EPI_BF16 || EPI == ESMDIFF_EPI_SWIGLU_BF16) {
+            const float sc = (EPI == ESMDIFF_EPI_BF16) ? alpha : 1.0f;
+            uint2 pk;
+            pk.x = pack_bf16x2(v[0] * sc, v[1] * sc);
+            pk.y = pack_bf16x2(v[2] * sc, v[3] * sc);
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = pk;
+          } else if constexpr (EPI == ESMDIFF_EPI_RESID_F32) {
+            float* o = reinterpret_cast<float*>(out) + (int64_t)m * ldc + n;
+            f32x4 x = *reinterpret_cast<const f32x4*>(o);
+            x[0] += v[0] * alpha; x[1] += v[1] * alpha; x[2] += v[2] * alpha; x[3] += v[3] * alpha;
+            *reinterpret_cast<f32x4*>(o) = x;
+          } else if constexpr (EPI == ESMDIFF_EPI_BIAS_GELU_BF16) {
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
+            uint2 pk;
+            pk.x = pack_bf16x2(gelu_erf(v[0] + bb[0]), gelu_erf(v[1] + bb[1]));
+            pk.y = pack_bf16x2(gelu_erf(v[2] + bb[2]), gelu_erf(v[3] + bb[3]));
+            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = pk;
+          } else {
+            if (n + 4 <= ldc) {
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
+              f32x4 x;
+              x[0] = v[0] + bb[0]; x[1] = v[1] + bb[1]; x[2] = v[2] + bb[2]; x[3] = v[3] + bb[3];
+              *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (int64_t)m * ldc + n) = x;
+            }
+          }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+      }
+
+    ED_TSTAMP(4);
+#ifdef ED_GEMM_DEBUG
+    ++tileno;
+#endif
+    // ---- next tile of this workgroup ---------------------------------------------------------------
+    if (vtn < n_tiles) {
+      __builtin_amdgcn_s_barrier();  // every wave is done with its slab: stage 1 (and, without prefetch, stage 0) is free
+      have_k0 = xnext;
+      if (xnext) {
+        m0 = m0n;
+        n0 = n0n;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            a_off[h][i] = a_offn[h][i];
+            w_off[h][i] = w_offn[h][i];
+          }
+      } else {
+        tile_origin(vtn, m0, n0);
+        set_offsets(a_off, w_off, m0, n0);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
   }
 }
 }  // namespace g256
@@ -389,7 +460,19 @@ hipError_t launch_gemm256_bf16(const bf16_t* A, const bf16_t* W, void* out, cons
   if (M <= 0) return hipSuccess;
   if (N % BN != 0 || K % BK != 0 || (ldc & 3)) return hipErrorInvalidValue;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
-  dim3 grid(tiles_m * tiles_n), block(512);
+  // persistent grid: one workgroup per CU (LDS allows no more), each walking tiles b, b + G, ...  G must be a
+  // multiple of 8 (XCD-contiguous tile runs).  ESMDIFF_GEMM_PERSIST=0 launches one workgroup per tile instead.
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n >= 8 ? (n / 8) * 8 : 8;
+  }();
+  static const int persist = [] {
+    const char* e = getenv("ESMDIFF_GEMM_PERSIST");
+    return e ? atoi(e) : 1;
+  }();
+  const int n_tiles = tiles_m * tiles_n;
+  dim3 grid(persist ? (n_tiles < n_cu ? n_tiles : n_cu) : n_tiles), block(512);
   const size_t lds = 2 * STAGE_BYTES;
   static const int dbg = [] {
     const char* e = getenv("ESMDIFF_GEMM_DBG");
