@@ -49,11 +49,13 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_unif
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
 }
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-  uint32_t ua = __float_as_uint(a), ub = __float_as_uint(b);
-  ua = (ua + 0x7fffu + ((ua >> 16) & 1u)) >> 16;
-  ub = (ub + 0x7fffu + ((ub >> 16) & 1u)) >> 16;
-  return ua | (ub << 16);
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // v_cvt_pk_bf16_f32, round to nearest even
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  const bf16x2_t v = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+  uint32_t u;
+  __builtin_memcpy(&u, &v, 4);
+  return u;
 }
 #define ED_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
 // -DED_GEMM_DEBUG: ESMDIFF_GEMM_DBG bits (2: no LDS-DMA in the main loop, 4: no stores, 8: no vmcnt wait, 16: no

@@ -22,11 +22,14 @@ __device__ __forceinline__ float wsum(float v) {
   return v;
 }
 __device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
-__device__ __forceinline__ uint32_t f2bf(float a) {
-  uint32_t u = __float_as_uint(a);
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+__device__ __forceinline__ uint32_t pack2(float a, float b) {  // v_cvt_pk_bf16_f32, round to nearest even
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+  const bf16x2_t v = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
+  uint32_t u;
+  __builtin_memcpy(&u, &v, 4);
+  return u;
 }
-__device__ __forceinline__ uint32_t pack2(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: NV = ceil(D / 256) float4 per lane; D % 4 == 0.
