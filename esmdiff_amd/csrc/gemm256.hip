@@ -21,9 +21,12 @@
 //              ~25-45 cycles per 1-KiB LDS-DMA, and a burst of 64 of them right after the barrier stalled the
 //              younger four waves for 1.2-2k cycles in instruction issue.
 //   tiles      persistent workgroups (one per CU) walk tiles b, b+G, ...; the K-tile LDS-DMA stream runs across the
-//              tile boundary (K-tile 0 of the next tile lands in stage 0 during the last K-tile and the epilogue,
-//              which therefore stages its output through the stage-1 regions only), so a tile pays neither the
-//              DMA latency of its first K-tile nor a workgroup relaunch.
+//              tile boundary (K-tile 0 of the next tile lands in stage 0 during the last K-tile, K-tile 1 is issued
+//              into stage 1 right after the K loop, under the epilogue), so a tile pays neither the DMA latency of
+//              its first K-tiles nor a workgroup relaunch, and there is no barrier between two tiles.
+//   epilogue   register-direct: the MFMAs compute the TRANSPOSED 32x32 blocks (W fragment as first operand), which
+//              gives every lane 4 consecutive output columns per register group; v_permlane32_swap widens that to 8
+//              (one 16-byte bf16 store per lane, 32 contiguous bytes per row).  No LDS staging, no barriers.
 //   raster     XCD-contiguous, 8(M) x 4(N) super-tiles: the 32 tiles resident on one XCD share 8 A panels and
 //              4 W panels in that XCD's L2.
 #include <stdlib.h>
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int f = 0; f < 2; ++f)
-        acc[mh][f][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[f][j], b[j], acc[mh][f][nh], 0, 0, 0);
+        acc[mh][f][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[f][j], acc[mh][f][nh], 0, 0, 0);  // C^T: see epilogue
     __builtin_amdgcn_s_setprio(0);
     ED_PHASE_FENCE();
   };
@@ -339,10 +342,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();
-    } else {
-      issue_A(1, 1);  // stage 1 was the previous tile's epilogue slab; the barrier after that epilogue freed it
-      issue_W(1, 1);
-    }
+    }  // else: K-tiles 0 and 1 were issued by the previous tile of this workgroup (see its epilogue)
     ED_PHASE_FENCE();
     read_A(A0a, I0{}, I0{}, I0{});
     read_B(B0a, I0{}, I0{}, I0{});
@@ -362,71 +362,107 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     if (t < nk) ktile(t, I0{});
     ED_TSTAMP(2);
 
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
     ED_TSTAMP(3);
+    // Every wave is past the barrier of the last K-tile and reads no more LDS for this tile: stage 1 is free, so
+    // K-tile 1 of the next tile starts streaming now, under the epilogue.
+    if (xnext && nk > 1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          glds16s(Ab + kstride, a_offn[h][i], lds_base + (h * 2 + 1) * HALF_BYTES + (i * 8 + wave) * 1024);
+          glds16s(Wb + kstride, w_offn[h][i], lds_base + ((2 + h) * 2 + 1) * HALF_BYTES + (i * 8 + wave) * 1024);
+        }
+    }
 
-    // ---- epilogue: accumulators -> private 8 KiB LDS slab (64 rows x 32 floats) -> whole-row global stores.
-    // The slabs live in the four STAGE-1 regions only: with cross-tile prefetch stage 0 already holds K-tile 0 of
-    // the next tile.  Rounds: (mh, nh) quadrants; SwiGLU pairs nh = 0 (gate) with nh = 1 (up) in registers.
-    float* slab = reinterpret_cast<float*>(smem + ((wave >> 1) * 2 + 1) * HALF_BYTES + (wave & 1) * 8192);
-    constexpr int NROUND_N = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? 1 : 2;
-    const int ccol = lane & 31, rhalf = lane >> 5;
-    const int rr_ = lane >> 3, c4 = (lane & 7) * 4;  // 8 lanes per 32-float row, 8 rows per iteration
+    // ---- epilogue: straight from the accumulators, no LDS.  The MFMAs take the W fragment as their first operand,
+    // so each 32x32 accumulator is the TRANSPOSED output block: a lane holds one output row (m = lane & 31) and
+    // every group of four registers is four consecutive columns, n = 8*(r>>2) + 4*(lane>>5) + (r&3).  For the bf16
+    // outputs v_permlane32_swap trades packed register groups between lane l and l+32 so that a lane owns 8
+    // consecutive columns = one 16-byte store; lanes l / l+32 then cover 32 contiguous bytes of a row.
+    const int lrow = lane & 31, lhi = lane >> 5;
+    auto swap_halves = [](uint32_t& lo_keep, uint32_t& hi_keep) {  // lo_keep[32:63] <-> hi_keep[0:31]
+      const auto r = __builtin_amdgcn_permlane32_swap(lo_keep, hi_keep, false, false);
+      lo_keep = r[0];
+      hi_keep = r[1];
+    };
 #pragma unroll
     for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-      for (int nr = 0; nr < NROUND_N; ++nr) {
+      for (int f = 0; f < 2; ++f) {
+        const int m = m0 + wm * 128 + mh * 64 + f * 32 + lrow;
+        const bool live = m < M && !ED_DBG(4);
+        if constexpr (EPI == ESMDIFF_EPI_SWIGLU_BF16) {
+          bf16_t* orow = reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + (n0 + wn * 64) / 2 + lhi * 8;
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+          for (int gp = 0; gp < 2; ++gp) {
+            float h[8];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = f * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
-            if constexpr (EPI == ESMDIFF_EPI_SWIGLU_BF16) {
-              const float g = acc[mh][f][0][r], u = acc[mh][f][1][r];
-              slab[row * 32 + ccol] = (g / (1.0f + __expf(-g))) * u;
-            } else {
-              slab[row * 32 + ccol] = acc[mh][f][nr][r];
+            for (int i = 0; i < 8; ++i) {
+              const float g = acc[mh][f][0][gp * 8 + i], u = acc[mh][f][1][gp * 8 + i];
+              h[i] = (g / (1.0f + __expf(-g))) * u;
+            }
+            uint32_t p0 = pack_bf16x2(h[0], h[1]), p1 = pack_bf16x2(h[2], h[3]);
+            uint32_t q0 = pack_bf16x2(h[4], h[5]), q1 = pack_bf16x2(h[6], h[7]);
+            swap_halves(p0, q0);
+            swap_halves(p1, q1);
+            if (live) *reinterpret_cast<uint4*>(orow + gp * 16) = make_uint4(p0, p1, q0, q1);
+          }
+        } else if constexpr (EPI == ESMDIFF_EPI_BF16 || EPI == ESMDIFF_EPI_BIAS_GELU_BF16) {
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh) {
+            const int nb = n0 + wn * 64 + nh * 32;
+            bf16_t* orow = reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + nb + lhi * 8;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+              float h[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) h[i] = acc[mh][f][nh][gp * 8 + i];
+              if constexpr (EPI == ESMDIFF_EPI_BF16) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) h[i] *= alpha;
+              } else {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + nb + gp * 16 + lhi * 4);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + nb + gp * 16 + 8 + lhi * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  h[i] = gelu_erf(h[i] + b0[i]);
+                  h[4 + i] = gelu_erf(h[4 + i] + b1[i]);
+                }
+              }
+              uint32_t p0 = pack_bf16x2(h[0], h[1]), p1 = pack_bf16x2(h[2], h[3]);
+              uint32_t q0 = pack_bf16x2(h[4], h[5]), q1 = pack_bf16x2(h[6], h[7]);
+              swap_halves(p0, q0);
+              swap_halves(p1, q1);
+              if (live) *reinterpret_cast<uint4*>(orow + gp * 16) = make_uint4(p0, p1, q0, q1);
             }
           }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        const int ncol0 = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? (n0 + wn * 64) / 2 : (n0 + wn * 64 + nr * 32);
-#pragma unroll 4
-        for (int it = 0; it < 8; ++it) {
-          const int row = it * 8 + rr_;
-          const int m = m0 + wm * 128 + mh * 64 + row;
-          if (m >= M || ED_DBG(4)) continue;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * 32 + c4);
-          const int n = ncol0 + c4;
-          if constexpr (EPI == ESMDIFF_EPI_BF16 || EPI == ESMDIFF_EPI_SWIGLU_BF16) {
-            const float sc = (EPI == ESMDIFF_EPI_BF16) ? alpha : 1.0f;
-            uint2 pk;
-            pk.x = pack_bf16x2(v[0] * sc, v[1] * sc);
-            pk.y = pack_bf16x2(v[2] * sc, v[3] * sc);
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = pk;
-          } else if constexpr (EPI == ESMDIFF_EPI_RESID_F32) {
-            float* o = reinterpret_cast<float*>(out) + (int64_t)m * ldc + n;
-            f32x4 x = *reinterpret_cast<const f32x4*>(o);
-            x[0] += v[0] * alpha; x[1] += v[1] * alpha; x[2] += v[2] * alpha; x[3] += v[3] * alpha;
-            *reinterpret_cast<f32x4*>(o) = x;
-          } else if constexpr (EPI == ESMDIFF_EPI_BIAS_GELU_BF16) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
-            uint2 pk;
-            pk.x = pack_bf16x2(gelu_erf(v[0] + bb[0]), gelu_erf(v[1] + bb[1]));
-            pk.y = pack_bf16x2(gelu_erf(v[2] + bb[2]), gelu_erf(v[3] + bb[3]));
-            *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = pk;
-          } else {
-            if (n + 4 <= ldc) {
-              const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
-              f32x4 x;
-              x[0] = v[0] + bb[0]; x[1] = v[1] + bb[1]; x[2] = v[2] + bb[2]; x[3] = v[3] + bb[3];
-              *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (int64_t)m * ldc + n) = x;
+        } else {  // f32 outputs: 16 bytes per lane per register group, 32 contiguous bytes per row per store
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int n = n0 + wn * 64 + nh * 32 + g * 8 + lhi * 4;
+              f32x4 v;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[i] = acc[mh][f][nh][g * 4 + i];
+              if (!live) continue;
+              float* o = reinterpret_cast<float*>(out) + (int64_t)m * ldc + n;
+              if constexpr (EPI == ESMDIFF_EPI_RESID_F32) {
+                f32x4 x = *reinterpret_cast<const f32x4*>(o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] += v[i] * alpha;
+                *reinterpret_cast<f32x4*>(o) = x;
+              } else {
+                if (n + 4 <= ldc) {
+                  const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) v[i] += bb[i];
+                  *reinterpret_cast<f32x4*>(o) = v;
+                }
+              }
             }
-          }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
       }
 
     ED_TSTAMP(4);
@@ -435,7 +471,6 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 #endif
     // ---- next tile of this workgroup ---------------------------------------------------------------
     if (vtn < n_tiles) {
-      __builtin_amdgcn_s_barrier();  // every wave is done with its slab: stage 1 (and, without prefetch, stage 0) is free
       have_k0 = xnext;
       if (xnext) {
         m0 = m0n;
