@@ -148,6 +148,29 @@ def test_gemm_bf16_store(M, N, K):
     assert float((err - ref.abs() * 2 ** -8).max()) < 2e-3, float(err.max())
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(12900, 4608, 1536, "bf16"), (25800, 1536, 4096, "bf16"), (12900, 8192, 1536, "swiglu")])
+def test_gemm256_persistent_multi_tile(M, N, K, epi):
+    """The full-size block linears: more tiles than CUs, so every workgroup of the 256x256 kernel walks several tiles
+    (cross-tile prefetch, register-direct epilogue, ragged last row tile)."""
+    from esmdiff_amd import _native as Nn
+    from esmdiff_amd.engine import gemm_bf16
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    A = _bf(torch.randn(M, K, generator=g, device="cuda"))
+    W = _bf(torch.randn(N, K, generator=g, device="cuda") / K ** 0.5)
+    for _ in range(2):
+        if epi == "bf16":
+            out = gemm_bf16(A, W, Nn.EPI_BF16)
+            ref = A.float() @ W.float().t()
+            err = (out.float() - ref).abs()
+            assert float((err - ref.abs() * 2 ** -8).max()) < 4e-3, float(err.max())
+        else:
+            out = gemm_bf16(A, W, Nn.EPI_SWIGLU_BF16)
+            r = (A.float() @ W.float().t()).view(M, N // 64, 2, 32)
+            ref = (torch.nn.functional.silu(r[:, :, 0]) * r[:, :, 1]).reshape(M, N // 2)
+            err = (out.float() - ref).abs()
+            assert float((err - ref.abs() * 2 ** -7).max()) < 1e-2, float(err.max())
+
+
 def test_gemm_asymmetric_identity():
     """A = I picks rows of W^T: catches transposed / permuted C layouts (asymmetric B)."""
     from esmdiff_amd import _native as Nn
