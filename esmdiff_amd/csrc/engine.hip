@@ -64,6 +64,7 @@ struct esmdiff_engine {
   std::vector<hipEvent_t> ev_join;
   hipEvent_t ev_fork = nullptr;
   int64_t dual_min_tokens = 12288;
+  ed::GemmWorkspace gemm_ws[4] = {};  // split-K partials of the small-M GEMM path, one per launch queue
   // profiling
   int profiling = 0;  // 0 off, 1 every launch, 2 only the dominant kernel (FFN-up GEMM)
   std::vector<hipEvent_t> ev;
@@ -204,15 +205,17 @@ struct Part {
   bf16_t *h, *h2, *qkv, *q, *k, *vt, *ctx, *mid, *dlt;
   int B;
   hipStream_t st;
+  const ed::GemmWorkspace* gws;
 };
 
 Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float* logits, int ld, int b0, int nb, int L,
-               hipStream_t st) {
+               hipStream_t st, int queue) {
   const esmdiff_config& c = e->cfg;
   const int64_t t0 = (int64_t)b0 * L, D = c.d_model;
   const int64_t hb = (int64_t)b0 * c.n_heads * round_up(L, 128) * (D / c.n_heads);
   return Part{seq + t0, xtok + t0, e->x + t0 * D, logits + t0 * ld, e->h + t0 * D, e->h2 + t0 * D, e->qkv + t0 * 3 * D,
-              e->q + hb, e->k + hb, e->vt + hb, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, nb, st};
+              e->q + hb, e->k + hb, e->vt + hb, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, nb, st,
+              e->gemm_ws[queue].partial ? &e->gemm_ws[queue] : nullptr};
 }
 
 // The whole network: tokens -> f32 logits [M, ld].
@@ -249,7 +252,7 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
     np = std::min<int>({(int)e->side.size() + 1, B, 4});
   for (int pi = 0; pi < np; ++pi) {
     const int b0 = (int)((int64_t)B * pi / np), b1 = (int)((int64_t)B * (pi + 1) / np);
-    parts[pi] = make_part(e, seq, xtok, logits, ld, b0, b1 - b0, L, pi == 0 ? st : e->side[pi - 1]);
+    parts[pi] = make_part(e, seq, xtok, logits, ld, b0, b1 - b0, L, pi == 0 ? st : e->side[pi - 1], pi);
   }
   if (np > 1) {
     HIP_TRY(e, hipEventRecord(e->ev_fork, st));
@@ -272,19 +275,19 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   for (int i = 0; i < c.n_layers; ++i) {
     const Layer& ly = e->layers[i];
     EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
-    EACH(S_QKV, launch_gemm_bf16(w.h, ly.w_qkv, w.qkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_EPI_BF16, w.st));
+    EACH(S_QKV, launch_gemm_bf16(w.h, ly.w_qkv, w.qkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
     EACH(S_QKROPE, launch_qk_norm_rope(w.qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.q, w.k, w.vt, w.B, L, Lp, H, w.st));
     EACH(S_ATTN, launch_attention(w.q, w.k, w.vt, w.ctx, w.B, L, Lp, H, w.st));
-    EACH(S_OUT, launch_gemm_bf16(w.ctx, ly.w_out, w.dlt, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st));
+    EACH(S_OUT, launch_gemm_bf16(w.ctx, ly.w_out, w.dlt, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
     EACH(S_LN, launch_add_layernorm_bf16(w.x, w.dlt, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
-    EACH(S_FFN_UP, launch_gemm_bf16(w.h, ly.w_up, w.mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, w.st));
-    EACH(S_FFN_DOWN, launch_gemm_bf16(w.mid, ly.w_down, w.dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st));
+    EACH(S_FFN_UP, launch_gemm_bf16(w.h, ly.w_up, w.mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, w.st, w.gws));
+    EACH(S_FFN_DOWN, launch_gemm_bf16(w.mid, ly.w_down, w.dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
     pending = true;
   }
   EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, e->final_ln_w, nullptr, w.h, M, D, w.st));
-  EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w0, w.h2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, w.st));
+  EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w0, w.h2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, w.st, w.gws));
   EACH(S_LN, launch_layernorm_bf16_in(w.h2, e->head_ln_w, e->head_ln_b, w.h, M, D, w.st));
-  EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w3, w.logits, e->head_b3, M, e->vocab_pad, D, ld, c.vocab_out, 1.f, ESMDIFF_EPI_BIAS_F32, w.st));
+  EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w3, w.logits, e->head_b3, M, e->vocab_pad, D, ld, c.vocab_out, 1.f, ESMDIFF_EPI_BIAS_F32, w.st, w.gws));
   for (int pi = 1; pi < np; ++pi) {
     HIP_TRY(e, hipEventRecord(e->ev_join[pi - 1], e->side[pi - 1]));
     HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[pi - 1], 0));
@@ -470,6 +473,16 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
     TRY(dalloc(e, &e->g_entropy, Mx));
     TRY(dalloc(e, &e->g_sampled, Mx));
     TRY(dalloc(e, &e->g_nunmask, (size_t)e->tfreq_rows * cfg->max_batch));
+    {  // split-K workspaces: S * N <= 12288 for every shape the launcher splits; rows up to the 1024-row switch
+      const char* sk = getenv("ESMDIFF_GEMM_SPLITK");
+      if (!(sk && sk[0] == '0')) {
+        const size_t rows = (size_t)round_up((int)std::min<size_t>(Mx, 1024), 128);
+        for (int q = 0; q < 4; ++q) {
+          e->gemm_ws[q].partial_floats = rows * 12288;
+          TRY(dalloc(e, &e->gemm_ws[q].partial, e->gemm_ws[q].partial_floats));
+        }
+      }
+    }
   }
 #undef TRY
   // second launch queue for the two-stream forward (ESMDIFF_DUAL_STREAM=0 disables, ESMDIFF_DUAL_STREAM_MIN_TOKENS tunes)

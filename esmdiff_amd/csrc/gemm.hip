@@ -21,6 +21,17 @@
 // Grid: one workgroup per tile, XCD-aware (block b runs on XCD b%8, so each XCD is given a contiguous
 // run of tiles) and rasterised in 8x8 super-tiles so the 64 tiles resident on an XCD share 8 A panels
 // and 8 W panels in that XCD's L2.
+//
+// Small M (< 1024 rows: a handful of short sequences).  There are then only tiles_n..8*tiles_n tiles, so most CUs
+// idle while a few stream whole weight matrices, and with two stages each workgroup waits one full HBM latency per
+// K-tile (M = 240, N = 1536, K = 4096: 24 workgroups, 63 us for 12.6 MB).  Two changes on this path:
+//   NST = 4  four LDS stages (128 KiB, one workgroup per CU), three K-tiles in flight, counted vmcnt waits;
+//   split-K  when the caller provides a workspace, the K range is cut into S slices (S is a function of N and K only,
+//            never of M, so a sample's logits do not depend on the batch it is in).  Slice s writes its raw f32
+//            tile to partial[s]; `splitk_reduce_kernel` adds the slices in the fixed order s = 0..S-1 and applies
+//            the epilogue.  Deterministic, no atomics.  (A single-kernel variant with per-tile tickets and
+//            __threadfence() — "last arriver reduces" — was 2.7x SLOWER than no split at all: the agent-scope
+//            release/acquire costs an L2 write-back/invalidate per workgroup on this multi-XCD part.)
 #include <stdlib.h>
 
 #include "kernels.h"
@@ -51,18 +62,20 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // v_cvt_pk
   return u;
 }
 
-template <int EPI>
+template <int EPI, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
                                                            const bf16_t* __restrict__ W, void* __restrict__ out,
                                                            const float* __restrict__ bias, int M, int N, int K,
                                                            int ldc, int n_valid, float alpha, int tiles_m,
-                                                           int tiles_n) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
+                                                           int tiles_n, int ksplit, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST stages][A 16K | B 16K]
 
-  // ---- tile assignment: XCD-contiguous, 8x8 super-tile raster --------------------------------
+  // ---- tile assignment: XCD-contiguous, 8x8 super-tile raster; K slices are the slow index ------
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int lin_all = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int n_tiles = tiles_m * tiles_n;
+  const int ks_id = lin_all / n_tiles, lin = lin_all - ks_id * n_tiles;
   const int per_group = GROUP_M * tiles_n;
   const int grp = lin / per_group, in_grp = lin - grp * per_group;
   const int gm0 = grp * GROUP_M;
@@ -115,15 +128,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int nk = K / BK;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-    const char* base = smem + cur * (2 * TILE_BYTES);
+  const int nk_per = (K / BK) / ksplit;  // the launcher guarantees divisibility
+  const int kt0 = ks_id * nk_per;
+  auto compute = [&](int buf) {
+    const char* base = smem + buf * (2 * TILE_BYTES);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int coff = ((ks * 2 + khalf) ^ fsw) << 4;
@@ -139,14 +147,65 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+  };
+  if constexpr (NST == 2) {
+    stage(0, kt0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    for (int i = 0; i < nk_per; ++i) {
+      const int cur = i & 1;
+      if (i + 1 < nk_per) stage(cur ^ 1, kt0 + i + 1);
+      compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  } else {
+    // NST - 1 K-tiles in flight; every tile is 8 LDS-DMA instructions per wave, so "tile i has landed" is
+    // vmcnt(8 * tiles issued after it).  One barrier per K-tile: it publishes tile i and retires buffer (i-1) % NST,
+    // which the refill issued right after it overwrites.
+    static_assert(NST == 4, "stage ring is written for 4 stages");
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+      if (p < nk_per) stage(p, kt0 + p);
+    for (int i = 0; i < nk_per; ++i) {
+      const int after = min(NST - 2, nk_per - 1 - i);
+      if (after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if (after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would add vmcnt(0) and drain the ring
+      if (i + NST - 1 < nk_per) stage((i + NST - 1) & (NST - 1), kt0 + i + NST - 1);
+      compute(i & (NST - 1));
+    }
+    __syncthreads();  // the epilogue slabs alias the stages
   }
 
   // ---- epilogue: registers -> this wave's LDS slab -> whole-row global stores -------------------
   float* slab = reinterpret_cast<float*>(smem) + wave * (64 * 64);
-  constexpr int SW = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? 32 : 64;  // slab width in floats
   const int ccol = lane & 31, rhalf = lane >> 5;
+  if (partial != nullptr) {
+    // split-K slice: raw f32 tile -> partial[ks_id][m][n] (row stride N; rows >= M are never written or read)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
+          slab[row * 64 + j * 32 + ccol] = acc[i][j][r];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int prow = lane >> 4, pc4 = (lane & 15) * 4;  // 16 lanes per 64-float row, 4 rows per iteration
+    float* pbase = partial + (int64_t)ks_id * ((int64_t)tiles_m * BM * N) + (int64_t)(m0 + wm * 64) * N + n0 + wn * 64;
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int row = it * 4 + prow;
+      if (m0 + wm * 64 + row < M)
+        *reinterpret_cast<f32x4*>(pbase + (int64_t)row * N + pc4) = *reinterpret_cast<const f32x4*>(slab + row * 64 + pc4);
+    }
+    return;
+  }
+  constexpr int SW = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? 32 : 64;  // slab width in floats
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     if constexpr (EPI == ESMDIFF_EPI_SWIGLU_BF16) {
@@ -209,28 +268,115 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
   (void)n_valid;
 }
 
+// split-K second pass: out = epi(sum_s partial[s]) ; one thread = 4 consecutive output columns of one row
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, int64_t pstride,
+                                                            void* __restrict__ out, const float* __restrict__ bias,
+                                                            int M, int N, int ldc, float alpha) {
+  constexpr bool SWIGLU = EPI == ESMDIFF_EPI_SWIGLU_BF16;
+  const int ow4 = (SWIGLU ? N / 2 : N) / 4;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * ow4) return;
+  const int m = (int)(idx / ow4), c = (int)(idx - (int64_t)m * ow4) * 4;
+  const int n_in = SWIGLU ? (c >> 5) * 64 + (c & 31) : c;  // gate columns of the interleaved [32 gate | 32 up] blocks
+  const float* p = partial + (int64_t)m * N + n_in;
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  for (int s2 = 1; s2 < S; ++s2) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p + s2 * pstride);
+    v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+  }
+  if constexpr (SWIGLU) {
+    f32x4 u = *reinterpret_cast<const f32x4*>(p + 32);
+    for (int s2 = 1; s2 < S; ++s2) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(p + 32 + s2 * pstride);
+      u[0] += t[0]; u[1] += t[1]; u[2] += t[2]; u[3] += t[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] / (1.0f + __expf(-v[e]))) * u[e];
+  }
+  const int n = c;
+  if constexpr (EPI == ESMDIFF_EPI_BF16 || SWIGLU) {
+    const float sc = (EPI == ESMDIFF_EPI_BF16) ? alpha : 1.0f;
+    uint2 pk;
+    pk.x = pack_bf16x2(v[0] * sc, v[1] * sc);
+    pk.y = pack_bf16x2(v[2] * sc, v[3] * sc);
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = pk;
+  } else if constexpr (EPI == ESMDIFF_EPI_RESID_F32) {
+    float* o = reinterpret_cast<float*>(out) + (int64_t)m * ldc + n;
+    f32x4 x = *reinterpret_cast<const f32x4*>(o);
+    x[0] += v[0] * alpha; x[1] += v[1] * alpha; x[2] += v[2] * alpha; x[3] += v[3] * alpha;
+    *reinterpret_cast<f32x4*>(o) = x;
+  } else if constexpr (EPI == ESMDIFF_EPI_BIAS_GELU_BF16) {
+    const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
+    uint2 pk;
+    pk.x = pack_bf16x2(gelu_erf(v[0] + bb[0]), gelu_erf(v[1] + bb[1]));
+    pk.y = pack_bf16x2(gelu_erf(v[2] + bb[2]), gelu_erf(v[3] + bb[3]));
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + n) = pk;
+  } else {  // ESMDIFF_EPI_BIAS_F32
+    if (n + 4 <= ldc) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
+      f32x4 x;
+      x[0] = v[0] + bb[0]; x[1] = v[1] + bb[1]; x[2] = v[2] + bb[2]; x[3] = v[3] + bb[3];
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (int64_t)m * ldc + n) = x;
+    }
+  }
+}
+
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
-                            int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream) {
+                            int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream,
+                            const GemmWorkspace* ws) {
   if (M <= 0) return hipSuccess;
   if (N % BN != 0 || K % BK != 0 || (ldc & 3)) return hipErrorInvalidValue;
-  {
-    // Tile selection: the 256x256 kernel (one workgroup per CU) for large M, this 128x128 kernel (2 workgroups
-    // per CU) otherwise.  ESMDIFF_GEMM_TILE=128|256 forces one (A/B benchmarking and tests).
-    // (Measured and rejected: splitting the rows so that 256-row tiles fill whole 256-CU rounds and the leftover
-    // rows go through this kernel — 93 + 29 us apart, 138 us back to back, vs 132 us unsplit at N = K = 1536.)
-    static const int forced = [] {
-      const char* e = getenv("ESMDIFF_GEMM_TILE");
-      return e ? atoi(e) : 0;
-    }();
-    if (N % 256 == 0 && (forced == 256 || (forced == 0 && M >= 1024)))
-      return launch_gemm256_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
-  }
+  // Tile selection: the 256x256 kernel (one workgroup per CU) for large M, this 128x128 kernel otherwise.
+  // ESMDIFF_GEMM_TILE=128|256 forces one (A/B benchmarking and tests).
+  // (Measured and rejected: splitting the rows so that 256-row tiles fill whole 256-CU rounds and the leftover
+  // rows go through this kernel — 93 + 29 us apart, 138 us back to back, vs 132 us unsplit at N = K = 1536.)
+  static const int forced = [] {
+    const char* e = getenv("ESMDIFF_GEMM_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  if (N % 256 == 0 && (forced == 256 || (forced == 0 && M >= 1024)))
+    return launch_gemm256_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
-  dim3 grid(tiles_m * tiles_n), block(256);
-  const size_t lds = 4 * TILE_BYTES;
-#define ED_GEMM(E)                                                                                          \
-  hipLaunchKernelGGL(gemm_bf16_kernel<E>, grid, block, lds, stream, A, W, out, bias, M, N, K, ldc, n_valid, \
-                     alpha, tiles_m, tiles_n)
+  const bool small = M < 1024;  // four-stage ring, one workgroup per CU, optional split-K
+  // split-K factor, a function of (N, K) only: for K >= 2048 (FFN-down) the largest divisor of K/64 that is <= 8 and
+  // keeps tiles_n * S <= 96.  Measured (us per launch, M = 240 / 774): FFN-down K = 4096 S = 8: 42 -> 17 / 41 -> 35;
+  // but K = 1536 shapes lose at the larger M (out-proj S = 8: 21 -> 16 / 20 -> 27; QKV S = 2: 21 -> 20 / 22 -> 33) —
+  // the f32 partials (S x M x N x 4 B, written and re-read) outweigh the shorter K loop — so they are not split.
+  int S = 1;
+  if (small && ws && ws->partial && K >= 2048) {
+    const int nk = K / BK;
+    for (int c = 8; c >= 2; --c)
+      if (nk % c == 0 && tiles_n * c <= 96) {
+        S = c;
+        break;
+      }
+    if ((size_t)S * tiles_m * BM * N > ws->partial_floats) S = 1;
+  }
+  float* partial = S > 1 ? ws->partial : nullptr;
+  const int64_t pstride = (int64_t)tiles_m * BM * N;
+  dim3 grid(tiles_m * tiles_n * S), block(256);
+#define ED_GEMM(E)                                                                                                  \
+  do {                                                                                                              \
+    if (small) {                                                                                                    \
+      static bool attr_done = false;                                                                                \
+      if (!attr_done) {                                                                                             \
+        hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                            8 * TILE_BYTES);                                                                        \
+        attr_done = true;                                                                                           \
+      }                                                                                                             \
+      hipLaunchKernelGGL((gemm_bf16_kernel<E, 4>), grid, block, 8 * TILE_BYTES, stream, A, W, out, bias, M, N, K,   \
+                         ldc, n_valid, alpha, tiles_m, tiles_n, S, partial);                                        \
+      if (S > 1) {                                                                                                  \
+        const int64_t n_thr = (int64_t)M * ((E == ESMDIFF_EPI_SWIGLU_BF16 ? N / 2 : N) / 4);                        \
+        hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,    \
+                           partial, S, pstride, out, bias, M, N, ldc, alpha);                                       \
+      }                                                                                                             \
+    } else {                                                                                                        \
+      hipLaunchKernelGGL((gemm_bf16_kernel<E, 2>), grid, block, 4 * TILE_BYTES, stream, A, W, out, bias, M, N, K,   \
+                         ldc, n_valid, alpha, tiles_m, tiles_n, 1, (float*)nullptr);                                \
+    }                                                                                                               \
+  } while (0)
   switch (epilogue) {
     case ESMDIFF_EPI_BF16: ED_GEMM(ESMDIFF_EPI_BF16); break;
     case ESMDIFF_EPI_RESID_F32: ED_GEMM(ESMDIFF_EPI_RESID_F32); break;

@@ -25,8 +25,15 @@ hipError_t launch_gibbs_step(int64_t* x, const int64_t* seq, const float* logits
 
 // ---- gemm.hip --------------------------------------------------------------------------------
 // out = epilogue(A[M,K] · W[N,K]^T); K % 64 == 0, N % 128 == 0 (weights are padded at load time).
+// ws (optional): split-K workspace for the small-M path — room for f32 partial tiles, owned by ONE launch queue
+// (concurrent launches need their own).  Without it every tile runs its whole K range.
+struct GemmWorkspace {
+  float* partial;
+  size_t partial_floats;
+};
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
-                            int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream);
+                            int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream,
+                            const GemmWorkspace* ws = nullptr);
 
 // gemm256.hip: 256x256x64 tiles, 8 waves, counted-vmcnt pipeline; needs N % 256 == 0 (large-M path)
 hipError_t launch_gemm256_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
