@@ -327,7 +327,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
                             const GemmWorkspace* ws) {
   if (M <= 0) return hipSuccess;
   if (N % BN != 0 || K % BK != 0 || (ldc & 3)) return hipErrorInvalidValue;
-  // Tile selection: the 256x256 kernel (one workgroup per CU) for large M, this 128x128 kernel otherwise.
+  // Tile selection: the 256x256 kernel (one persistent workgroup per CU) once it has >= 128 tiles to hand out, this
+  // 128x128 kernel otherwise.  Measured crossovers (us, 128 vs 256): N = 1536, K = 4096: M = 4128 67 / 81, M = 6192
+  // 109 / 87; N = 4608: M = 1032 28 / 37, M = 2064 48 / 42; N = 8192: M = 1032 47 / 40.
   // ESMDIFF_GEMM_TILE=128|256 forces one (A/B benchmarking and tests).
   // (Measured and rejected: splitting the rows so that 256-row tiles fill whole 256-CU rounds and the leftover
   // rows go through this kernel — 93 + 29 us apart, 138 us back to back, vs 132 us unsplit at N = K = 1536.)
@@ -335,16 +337,15 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
     const char* e = getenv("ESMDIFF_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
-  if (N % 256 == 0 && (forced == 256 || (forced == 0 && M >= 1024)))
+  if (N % 256 == 0 && (forced == 256 || (forced == 0 && ((M + 255) / 256) * (N / 256) >= 128)))
     return launch_gemm256_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
-  const bool small = M < 1024;  // four-stage ring, one workgroup per CU, optional split-K
   // split-K factor, a function of (N, K) only: for K >= 2048 (FFN-down) the largest divisor of K/64 that is <= 8 and
   // keeps tiles_n * S <= 96.  Measured (us per launch, M = 240 / 774): FFN-down K = 4096 S = 8: 42 -> 17 / 41 -> 35;
   // but K = 1536 shapes lose at the larger M (out-proj S = 8: 21 -> 16 / 20 -> 27; QKV S = 2: 21 -> 20 / 22 -> 33) —
   // the f32 partials (S x M x N x 4 B, written and re-read) outweigh the shorter K loop — so they are not split.
   int S = 1;
-  if (small && ws && ws->partial && K >= 2048) {
+  if (M < 1024 && ws && ws->partial && K >= 2048) {
     const int nk = K / BK;
     for (int c = 8; c >= 2; --c)
       if (nk % c == 0 && tiles_n * c <= 96) {
@@ -353,6 +354,9 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
       }
     if ((size_t)S * tiles_m * BM * N > ws->partial_floats) S = 1;
   }
+  // four-stage ring with one workgroup per CU while everything is resident at once; two stages x two workgroups
+  // per CU beyond that
+  const bool small = tiles_m * tiles_n * S <= 256;
   float* partial = S > 1 ? ws->partial : nullptr;
   const int64_t pstride = (int64_t)tiles_m * BM * N;
   dim3 grid(tiles_m * tiles_n * S), block(256);
@@ -367,14 +371,14 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
       }                                                                                                             \
       hipLaunchKernelGGL((gemm_bf16_kernel<E, 4>), grid, block, 8 * TILE_BYTES, stream, A, W, out, bias, M, N, K,   \
                          ldc, n_valid, alpha, tiles_m, tiles_n, S, partial);                                        \
-      if (S > 1) {                                                                                                  \
-        const int64_t n_thr = (int64_t)M * ((E == ESMDIFF_EPI_SWIGLU_BF16 ? N / 2 : N) / 4);                        \
-        hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,    \
-                           partial, S, pstride, out, bias, M, N, ldc, alpha);                                       \
-      }                                                                                                             \
     } else {                                                                                                        \
       hipLaunchKernelGGL((gemm_bf16_kernel<E, 2>), grid, block, 4 * TILE_BYTES, stream, A, W, out, bias, M, N, K,   \
-                         ldc, n_valid, alpha, tiles_m, tiles_n, 1, (float*)nullptr);                                \
+                         ldc, n_valid, alpha, tiles_m, tiles_n, S, partial);                                        \
+    }                                                                                                               \
+    if (S > 1) {                                                                                                    \
+      const int64_t n_thr = (int64_t)M * ((E == ESMDIFF_EPI_SWIGLU_BF16 ? N / 2 : N) / 4);                          \
+      hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,      \
+                         partial, S, pstride, out, bias, M, N, ldc, alpha);                                         \
     }                                                                                                               \
   } while (0)
   switch (epilogue) {
