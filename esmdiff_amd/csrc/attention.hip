@@ -11,11 +11,16 @@
 //     "swapped" product: C[key][query] puts a query in a LANE (col = lane & 31) and its 64 scores in
 //     that lane's registers (+ the partner lane ^ 32), so row max / row sum are register reductions
 //     plus one cross-lane exchange, and the running rescale factor is a per-lane scalar.
-//   O^T += V^T · P^T   2 x 4 MFMAs (A = V^T rows from LDS — vt is stored keys-contiguous by
-//     v_transpose — B = P^T taken directly from the S^T accumulators: the key order inside a
-//     16-key MFMA k-step is permuted identically on both operands, so no lane shuffles are needed).
-// K and V^T tiles are 64 rows x 128 B, staged by LDS-DMA with the same source-side XOR swizzle as the
-// GEMM (conflict-free ds_read_b128 for K; 2-way for the 8-byte V^T reads), double buffered.
+//   O^T += V^T · P^T   2 x 4 MFMAs (A = V^T fragments, B = P^T taken directly from the S^T accumulators: the key
+//     order inside a 16-key MFMA k-step is permuted identically on both operands, so no lane shuffles are needed).
+//     V is read where the QKV GEMM left it (token-major rows of qkv, 128 B per key and head): the LDS tile is
+//     [key][d] and the A fragment (a lane = one d, 4 consecutive keys per 8 bytes) comes out of
+//     ds_read_b64_tr_b16, the hardware transpose read: within a 16-lane group lane i supplies the address of
+//     V[key0 + i/4][d0 + 4*(i%4) ..+3] and receives V[key0 .. key0+3][d0 + i].  There is no V^T tensor in HBM
+//     and no transpose kernel (r01a-e had both: 33 us and 158 MB of traffic per layer at config 2).
+// K and V tiles are 64 rows x 128 B, staged by LDS-DMA with a source-side XOR swizzle of the 16-byte chunks
+// (K: chunk ^= (row>>1)&7, conflict-free for ds_read_b128 as in the GEMM; V: chunk ^= 2*(row&3), which spreads
+// the 4 rows x 32 B of a transpose-read group over distinct banks), double buffered.
 // q arrives pre-scaled by log2(e)/8 (qk_norm_rope), so the softmax runs on exp2.
 #include <type_traits>
 
@@ -45,11 +50,19 @@ __device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // v_cvt_pk_bf1
 }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // bare v_exp_f32
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {  // ds_read_b64_tr_b16
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  bf16x4 r;
+  __builtin_memcpy(&r, &v, 8);
+  return r;
+}
+
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ q,
                                                            const bf16_t* __restrict__ k,
-                                                           const bf16_t* __restrict__ vt, bf16_t* __restrict__ ctx,
+                                                           const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                            int L, int Lp, int H) {
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_BYTES];  // [stage][K 8K | Vt 8K]
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_BYTES];  // [stage][K 8K | V 8K]
 
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -59,19 +72,21 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
   const int qi = lane & 31, hi = lane >> 5;
 
   const bf16_t* kbase = k + ((int64_t)bh * Lp) * 64;
-  const bf16_t* vbase = vt + ((int64_t)bh * 64) * Lp;
+  const int ldq = 3 * H * 64;                                            // qkv row stride (elements)
+  const bf16_t* vbase = qkv + (int64_t)b * L * ldq + 2 * H * 64 + h * 64;  // V of this (batch, head), token 0
 
   // ---- LDS-DMA: per tile 8 instructions for K (64 rows x 128 B) + 8 for Vt; 2 + 2 per wave ------
   // instruction i of this wave covers rows (i*4 + wave)*8 + (lane>>3), 16-byte slot lane&7
   const int srow = lane >> 3;
   const int schunk = (lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
+  const int vchunk = (lane & 7) ^ (2 * (srow & 3));  // V: logical chunk stored at slot lane&7 of row r (r & 3 == srow & 3)
   const bf16_t* k_src[2];
-  const bf16_t* v_src[2];
+  int v_row[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int r = (i * 4 + wave) * 8 + srow;
     k_src[i] = kbase + (int64_t)r * 64 + schunk * 8;      // + kt*64 rows
-    v_src[i] = vbase + (int64_t)r * Lp + schunk * 8;      // + kt*64 columns
+    v_row[i] = r;
   }
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * (2 * KV_BYTES);
@@ -79,7 +94,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     for (int i = 0; i < 2; ++i) {
       char* d = base + (i * 4 + wave) * 1024;
       glds16a(k_src[i] + (int64_t)kt * KV_TILE * 64, d);
-      glds16a(v_src[i] + kt * KV_TILE, d + KV_BYTES);
+      const int tok = min(kt * KV_TILE + v_row[i], L - 1);  // keys >= L get weight 0; any finite row will do
+      glds16a(vbase + (int64_t)tok * ldq + vchunk * 8, d + KV_BYTES);
     }
   };
 
@@ -99,6 +115,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
   float m_run = -1e30f, l_run = 0.f;
 
   const int fsw = (qi >> 1) & 7;
+  // transpose-read addressing: lane (g = lane>>4, i = lane&15) supplies V[key0 + 4*(g>>1) + (i>>2)][d0 + 16*(g&1) +
+  // 4*(i&3) ..+3] and receives d = d0 + (lane&31), keys key0 + 4*hi + 0..3 (key0 a multiple of 8, so row&3 = i>>2)
+  const int tg = lane >> 4, ti = lane & 15;
+  const int tr_row = 4 * (tg >> 1) + (ti >> 2);                    // + key0
+  const int tr_c = 2 * (tg & 1) + ((ti & 3) >> 1);                 // 16-byte chunk within the 32-d half
+  const int tr_swz = 2 * (ti >> 2);                                // 2 * (row & 3)
+  int tr_off[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) tr_off[d] = tr_row * 128 + (((d * 4 + tr_c) ^ tr_swz) << 4) + (ti & 1) * 8;
   const int nkt = (L + KV_TILE - 1) / KV_TILE;
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -168,10 +193,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         for (int e = 0; e < 4; ++e) pb.u[e] = pk_bf16(s[t][r0 + 2 * e], s[t][r0 + 2 * e + 1]);
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
-          const char* vrow = vl + (d * 32 + qi) * 128 + 8 * hi;
           union { bf16x4 h[2]; bf16x8 v; } va;
-          va.h[0] = *reinterpret_cast<const bf16x4*>(vrow + (((kk * 2) ^ fsw) << 4));
-          va.h[1] = *reinterpret_cast<const bf16x4*>(vrow + (((kk * 2 + 1) ^ fsw) << 4));
+          va.h[0] = lds_read_tr16(vl + kk * 16 * 128 + tr_off[d]);        // keys kk*16 + 4*hi + 0..3
+          va.h[1] = lds_read_tr16(vl + (kk * 16 + 8) * 128 + tr_off[d]);  // keys kk*16 + 8 + 4*hi + 0..3
           o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pb.v, o[d], 0, 0, 0);
         }
       }
@@ -201,12 +225,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
   }
 }
 
-hipError_t launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* ctx, int B, int L,
+hipError_t launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* qkv, bf16_t* ctx, int B, int L,
                             int Lp, int H, hipStream_t stream) {
   if (B <= 0 || L <= 0) return hipSuccess;
   if (Lp % 128 != 0 || Lp < L) return hipErrorInvalidValue;
   dim3 grid((L + 127) / 128, B * H), block(256);
-  hipLaunchKernelGGL(attention_kernel, grid, block, 0, stream, q, k, vt, ctx, L, Lp, H);
+  hipLaunchKernelGGL(attention_kernel, grid, block, 0, stream, q, k, qkv, ctx, L, Lp, H);
   return hipGetLastError();
 }
 

@@ -54,7 +54,7 @@ struct esmdiff_engine {
   int vocab_pad = 0;
   // workspace
   float* x = nullptr;
-  bf16_t *h = nullptr, *h2 = nullptr, *qkv = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *ctx = nullptr,
+  bf16_t *h = nullptr, *h2 = nullptr, *qkv = nullptr, *q = nullptr, *k = nullptr, *ctx = nullptr,
          *mid = nullptr, *dlt = nullptr;
   float *logits = nullptr, *cond = nullptr, *sig_hidden = nullptr, *tfreq = nullptr, *g_entropy = nullptr;
   int32_t *g_sampled = nullptr, *g_nunmask = nullptr;
@@ -202,7 +202,7 @@ int check_bl(esmdiff_engine* e, int B, int L) {
 struct Part {
   const int64_t *seq, *xtok;
   float *x, *logits;
-  bf16_t *h, *h2, *qkv, *q, *k, *vt, *ctx, *mid, *dlt;
+  bf16_t *h, *h2, *qkv, *q, *k, *ctx, *mid, *dlt;
   int B;
   hipStream_t st;
   const ed::GemmWorkspace* gws;
@@ -214,7 +214,7 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
   const int64_t t0 = (int64_t)b0 * L, D = c.d_model;
   const int64_t hb = (int64_t)b0 * c.n_heads * round_up(L, 128) * (D / c.n_heads);
   return Part{seq + t0, xtok + t0, e->x + t0 * D, logits + t0 * ld, e->h + t0 * D, e->h2 + t0 * D, e->qkv + t0 * 3 * D,
-              e->q + hb, e->k + hb, e->vt + hb, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, nb, st,
+              e->q + hb, e->k + hb, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, nb, st,
               e->gemm_ws[queue].partial ? &e->gemm_ws[queue] : nullptr};
 }
 
@@ -276,8 +276,8 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
     const Layer& ly = e->layers[i];
     EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
     EACH(S_QKV, launch_gemm_bf16(w.h, ly.w_qkv, w.qkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
-    EACH(S_QKROPE, launch_qk_norm_rope(w.qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.q, w.k, w.vt, w.B, L, Lp, H, w.st));
-    EACH(S_ATTN, launch_attention(w.q, w.k, w.vt, w.ctx, w.B, L, Lp, H, w.st));
+    EACH(S_QKROPE, launch_qk_norm_rope(w.qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.q, w.k, w.B, L, Lp, H, w.st));
+    EACH(S_ATTN, launch_attention(w.q, w.k, w.qkv, w.ctx, w.B, L, Lp, H, w.st));
     EACH(S_OUT, launch_gemm_bf16(w.ctx, ly.w_out, w.dlt, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
     EACH(S_LN, launch_add_layernorm_bf16(w.x, w.dlt, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
     EACH(S_FFN_UP, launch_gemm_bf16(w.h, ly.w_up, w.mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, w.st, w.gws));
@@ -461,7 +461,6 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
     TRY(dalloc(e, &e->qkv, Mx * 3 * D));
     TRY(dalloc(e, &e->q, hp, true));
     TRY(dalloc(e, &e->k, hp, true));
-    TRY(dalloc(e, &e->vt, hp, true));
     TRY(dalloc(e, &e->ctx, Mx * D));
     TRY(dalloc(e, &e->dlt, Mx * D));
     TRY(dalloc(e, &e->mid, Mx * FH));
@@ -634,9 +633,9 @@ int esmdiff_attention_bf16(esmdiff_engine* e, const void* qkv, const float* q_ln
   if (!qkv || !q_ln_w || !k_ln_w || !ctx) return fail(e, ESMDIFF_E_INVALID, "null pointer");
   if (int r = check_bl(e, B, L)) return r;
   const int Lp = round_up(L, 128);
-  HIP_TRY(e, launch_qk_norm_rope((const bf16_t*)qkv, q_ln_w, k_ln_w, e->rope_cos, e->rope_sin, e->q, e->k, e->vt, B, L, Lp,
+  HIP_TRY(e, launch_qk_norm_rope((const bf16_t*)qkv, q_ln_w, k_ln_w, e->rope_cos, e->rope_sin, e->q, e->k, B, L, Lp,
                                  e->cfg.n_heads, (hipStream_t)stream));
-  HIP_TRY(e, launch_attention(e->q, e->k, e->vt, (bf16_t*)ctx, B, L, Lp, e->cfg.n_heads, (hipStream_t)stream));
+  HIP_TRY(e, launch_attention(e->q, e->k, (const bf16_t*)qkv, (bf16_t*)ctx, B, L, Lp, e->cfg.n_heads, (hipStream_t)stream));
   return 0;
 }
 

@@ -8,8 +8,7 @@
 //   qk_norm_rope          full-width (D) LayerNorm of q and of k (attn.q_ln / attn.k_ln, no bias), rotary
 //                         (rotate-half, base 10000) per 64-wide head, q pre-scaled by log2(e)/sqrt(64);
 //                         writes head-major q,k [B,H,Lp,64]
-//   v_transpose           v part of the QKV GEMM output -> vt [B,H,64,Lp] (keys contiguous) so that the
-//                         attention kernel's PV MFMA A-operand is a straight 8-byte LDS read
+//                         (v is not touched: attention.hip reads it in place and transposes in its LDS reads)
 #include "kernels.h"
 
 namespace ed {
@@ -277,44 +276,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
   }
 }
 
-// vt[b,h,d,l] = qkv[b*L + l, 2D + h*64 + d];  block = one (b,h) x 64 tokens, 64x64 transpose through LDS.
-__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt,
-                                                          int L, int Lp, int H) {
-  __shared__ bf16_t tile[64][72];  // [token][d], +8 pad
-  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
-  const int l0 = blockIdx.x * 64;
-  const int D = H * 64;
-  const int tid = threadIdx.x;
-  // load: 64 tokens x 128 B; thread -> token tid>>2, 32-byte piece tid&3
-  {
-    const int t = tid >> 2, piece = tid & 3;
-    uint4 a = {0, 0, 0, 0}, c = {0, 0, 0, 0};
-    if (l0 + t < L) {
-      const bf16_t* src = qkv + ((int64_t)b * L + l0 + t) * (3 * D) + 2 * D + h * 64 + piece * 16;
-      a = *reinterpret_cast<const uint4*>(src);
-      c = *reinterpret_cast<const uint4*>(src + 8);
-    }
-    *reinterpret_cast<uint4*>(&tile[t][piece * 16]) = a;
-    *reinterpret_cast<uint4*>(&tile[t][piece * 16 + 8]) = c;
-  }
-  __syncthreads();
-  // store: 64 d-rows x 128 B; thread -> d = tid>>2, 16 tokens tid&3
-  {
-    const int d = tid >> 2, piece = tid & 3;
-    uint32_t o[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const uint32_t lo = tile[piece * 16 + 2 * e][d], hi = tile[piece * 16 + 2 * e + 1][d];
-      o[e] = lo | (hi << 16);
-    }
-    bf16_t* dst = vt + (((int64_t)b * H + h) * 64 + d) * Lp + l0 + piece * 16;
-    *reinterpret_cast<uint4*>(dst) = uint4{o[0], o[1], o[2], o[3]};
-    *reinterpret_cast<uint4*>(dst + 8) = uint4{o[4], o[5], o[6], o[7]};
-  }
-}
-
 hipError_t launch_qk_norm_rope(const bf16_t* qkv, const float* q_ln_w, const float* k_ln_w,
-                               const float* rope_cos, const float* rope_sin, bf16_t* q, bf16_t* k, bf16_t* vt,
+                               const float* rope_cos, const float* rope_sin, bf16_t* q, bf16_t* k,
                                int B, int L, int Lp, int H, hipStream_t stream) {
   const int D = H * 64, M = B * L;
   if (M <= 0) return hipSuccess;
@@ -329,10 +292,6 @@ hipError_t launch_qk_norm_rope(const bf16_t* qkv, const float* q_ln_w, const flo
     default: ED_QK(4); break;
   }
 #undef ED_QK
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  dim3 g2((L + 63) / 64, B * H);
-  hipLaunchKernelGGL(v_transpose_kernel, g2, block, 0, stream, qkv, vt, L, Lp, H);
   return hipGetLastError();
 }
 
