@@ -61,7 +61,7 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {  // ds_read_b64
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ q,
                                                            const bf16_t* __restrict__ k,
                                                            const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                           int L, int Lp, int H) {
+                                                           int L, int H) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KV_BYTES];  // [stage][K 8K | V 8K]
 
   const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
   const bool active = q0 < L;  // wave-uniform
   const int qi = lane & 31, hi = lane >> 5;
 
-  const bf16_t* kbase = k + ((int64_t)bh * Lp) * 64;
-  const int ldq = 3 * H * 64;                                            // qkv row stride (elements)
+  const int D = H * 64;
+  const bf16_t* kbase = k + (int64_t)b * L * D + h * 64;                 // K of this (batch, head), token 0; row stride D
+  const int ldq = 3 * D;                                                 // qkv row stride (elements)
   const bf16_t* vbase = qkv + (int64_t)b * L * ldq + 2 * H * 64 + h * 64;  // V of this (batch, head), token 0
 
   // ---- LDS-DMA: per tile 8 instructions for K (64 rows x 128 B) + 8 for Vt; 2 + 2 per wave ------
@@ -80,21 +81,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
   const int srow = lane >> 3;
   const int schunk = (lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7);
   const int vchunk = (lane & 7) ^ (2 * (srow & 3));  // V: logical chunk stored at slot lane&7 of row r (r & 3 == srow & 3)
-  const bf16_t* k_src[2];
   int v_row[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = (i * 4 + wave) * 8 + srow;
-    k_src[i] = kbase + (int64_t)r * 64 + schunk * 8;      // + kt*64 rows
-    v_row[i] = r;
-  }
+  for (int i = 0; i < 2; ++i) v_row[i] = (i * 4 + wave) * 8 + srow;
   auto stage = [&](int buf, int kt) {
     char* base = smem + buf * (2 * KV_BYTES);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       char* d = base + (i * 4 + wave) * 1024;
-      glds16a(k_src[i] + (int64_t)kt * KV_TILE * 64, d);
-      const int tok = min(kt * KV_TILE + v_row[i], L - 1);  // keys >= L get weight 0; any finite row will do
+      const int tok = min(kt * KV_TILE + v_row[i], L - 1);  // keys >= L are masked / get weight 0; any finite row will do
+      glds16a(kbase + (int64_t)tok * D + schunk * 8, d);
       glds16a(vbase + (int64_t)tok * ldq + vchunk * 8, d + KV_BYTES);
     }
   };
@@ -102,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
   // ---- Q^T fragments (B operand): lane -> query qi, d chunk ks*2 + hi -------------------------
   bf16x8 qf[4];
   {
-    const bf16_t* qrow = q + ((int64_t)bh * Lp + q0 + qi) * 64;  // rows < Lp always readable
+    const bf16_t* qrow = q + ((int64_t)b * L + min(q0 + qi, L - 1)) * D + h * 64;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + (ks * 2 + hi) * 8);
   }
@@ -226,11 +222,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 }
 
 hipError_t launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* qkv, bf16_t* ctx, int B, int L,
-                            int Lp, int H, hipStream_t stream) {
+                            int H, hipStream_t stream) {
   if (B <= 0 || L <= 0) return hipSuccess;
-  if (Lp % 128 != 0 || Lp < L) return hipErrorInvalidValue;
   dim3 grid((L + 127) / 128, B * H), block(256);
-  hipLaunchKernelGGL(attention_kernel, grid, block, 0, stream, q, k, qkv, ctx, L, Lp, H);
+  hipLaunchKernelGGL(attention_kernel, grid, block, 0, stream, q, k, qkv, ctx, L, H);
   return hipGetLastError();
 }
 

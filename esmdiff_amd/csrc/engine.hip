@@ -58,7 +58,7 @@ struct esmdiff_engine {
          *mid = nullptr, *dlt = nullptr;
   float *logits = nullptr, *cond = nullptr, *sig_hidden = nullptr, *tfreq = nullptr, *g_entropy = nullptr;
   int32_t *g_sampled = nullptr, *g_nunmask = nullptr;
-  int ld_logits = 0, Lp_max = 0, tfreq_rows = 0;
+  int ld_logits = 0, tfreq_rows = 0;
   // two-stream forward: the second half of a large batch runs on `side`, forked/joined with events
   std::vector<hipStream_t> side;
   std::vector<hipEvent_t> ev_join;
@@ -193,7 +193,7 @@ int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 int check_bl(esmdiff_engine* e, int B, int L) {
   if (B <= 0 || L <= 0) return fail(e, ESMDIFF_E_INVALID, "B=%d L=%d must be positive", B, L);
-  if (B > e->cfg.max_batch || L > e->cfg.max_len || (int64_t)B * round_up(L, 128) > (int64_t)e->cfg.max_batch * e->Lp_max)
+  if (B > e->cfg.max_batch || L > e->cfg.max_len)
     return fail(e, ESMDIFF_E_CAPACITY, "B=%d L=%d exceeds the engine capacity (max_batch=%d, max_len=%d)", B, L, e->cfg.max_batch, e->cfg.max_len);
   return 0;
 }
@@ -212,9 +212,8 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
                hipStream_t st, int queue) {
   const esmdiff_config& c = e->cfg;
   const int64_t t0 = (int64_t)b0 * L, D = c.d_model;
-  const int64_t hb = (int64_t)b0 * c.n_heads * round_up(L, 128) * (D / c.n_heads);
   return Part{seq + t0, xtok + t0, e->x + t0 * D, logits + t0 * ld, e->h + t0 * D, e->h2 + t0 * D, e->qkv + t0 * 3 * D,
-              e->q + hb, e->k + hb, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, nb, st,
+              e->q + t0 * D, e->k + t0 * D, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, nb, st,
               e->gemm_ws[queue].partial ? &e->gemm_ws[queue] : nullptr};
 }
 
@@ -229,7 +228,6 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
             int ld, int B, int L, hipStream_t st) {
   const esmdiff_config& c = e->cfg;
   const int D = c.d_model, H = c.n_heads, FH = c.ffn_hidden;
-  const int Lp = round_up(L, 128);
   const float inv_scale = 1.0f / c.residue_scale;
   Prof p{e, st};
 #define RUN(section, call)   \
@@ -276,8 +274,8 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
     const Layer& ly = e->layers[i];
     EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
     EACH(S_QKV, launch_gemm_bf16(w.h, ly.w_qkv, w.qkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
-    EACH(S_QKROPE, launch_qk_norm_rope(w.qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.q, w.k, w.B, L, Lp, H, w.st));
-    EACH(S_ATTN, launch_attention(w.q, w.k, w.qkv, w.ctx, w.B, L, Lp, H, w.st));
+    EACH(S_QKROPE, launch_qk_norm_rope(w.qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.q, w.k, w.B, L, H, w.st));
+    EACH(S_ATTN, launch_attention(w.q, w.k, w.qkv, w.ctx, w.B, L, H, w.st));
     EACH(S_OUT, launch_gemm_bf16(w.ctx, ly.w_out, w.dlt, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
     EACH(S_LN, launch_add_layernorm_bf16(w.x, w.dlt, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
     EACH(S_FFN_UP, launch_gemm_bf16(w.h, ly.w_up, w.mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, w.st, w.gws));
@@ -452,15 +450,13 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
   // workspace
   {
     const size_t Mx = (size_t)cfg->max_batch * cfg->max_len;
-    e->Lp_max = round_up(cfg->max_len, 128);
-    const size_t hp = (size_t)cfg->max_batch * H * e->Lp_max * 64;
     e->ld_logits = round_up(V, 4);
     TRY(dalloc(e, &e->x, Mx * D));
     TRY(dalloc(e, &e->h, Mx * D));
     TRY(dalloc(e, &e->h2, Mx * D));
     TRY(dalloc(e, &e->qkv, Mx * 3 * D));
-    TRY(dalloc(e, &e->q, hp, true));
-    TRY(dalloc(e, &e->k, hp, true));
+    TRY(dalloc(e, &e->q, Mx * D));
+    TRY(dalloc(e, &e->k, Mx * D));
     TRY(dalloc(e, &e->ctx, Mx * D));
     TRY(dalloc(e, &e->dlt, Mx * D));
     TRY(dalloc(e, &e->mid, Mx * FH));
@@ -632,10 +628,9 @@ int esmdiff_attention_bf16(esmdiff_engine* e, const void* qkv, const float* q_ln
   if (!e) return ESMDIFF_E_INVALID;
   if (!qkv || !q_ln_w || !k_ln_w || !ctx) return fail(e, ESMDIFF_E_INVALID, "null pointer");
   if (int r = check_bl(e, B, L)) return r;
-  const int Lp = round_up(L, 128);
-  HIP_TRY(e, launch_qk_norm_rope((const bf16_t*)qkv, q_ln_w, k_ln_w, e->rope_cos, e->rope_sin, e->q, e->k, B, L, Lp,
+  HIP_TRY(e, launch_qk_norm_rope((const bf16_t*)qkv, q_ln_w, k_ln_w, e->rope_cos, e->rope_sin, e->q, e->k, B, L,
                                  e->cfg.n_heads, (hipStream_t)stream));
-  HIP_TRY(e, launch_attention(e->q, e->k, (const bf16_t*)qkv, (bf16_t*)ctx, B, L, Lp, e->cfg.n_heads, (hipStream_t)stream));
+  HIP_TRY(e, launch_attention(e->q, e->k, (const bf16_t*)qkv, (bf16_t*)ctx, B, L, e->cfg.n_heads, (hipStream_t)stream));
   return 0;
 }
 

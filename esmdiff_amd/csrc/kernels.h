@@ -47,15 +47,15 @@ hipError_t launch_add_layernorm_bf16(float* x, const bf16_t* delta, const float*
                                      int D, hipStream_t stream);
 hipError_t launch_layernorm_bf16_in(const bf16_t* x, const float* w, const float* b, bf16_t* y, int M, int D,
                                     hipStream_t stream);
-// qkv bf16 [M,3D] -> q,k bf16 [B,H,Lp,64] (LayerNorm over D, rotary, q pre-scaled); v stays in qkv
+// qkv bf16 [M,3D] -> q,k bf16 [M,D] token-major (LayerNorm over D, rotary, q pre-scaled); v stays in qkv
 hipError_t launch_qk_norm_rope(const bf16_t* qkv, const float* q_ln_w, const float* k_ln_w,
                                const float* rope_cos, const float* rope_sin, bf16_t* q, bf16_t* k,
-                               int B, int L, int Lp, int H, hipStream_t stream);
+                               int B, int L, int H, hipStream_t stream);
 
 // ---- attention.hip ---------------------------------------------------------------------------
-// q,k [B,H,Lp,64], v read in place from qkv [B*L, 3*H*64] (columns 2*H*64 ..) -> ctx bf16 [B*L, H*64]
+// q,k [B*L, H*64] token-major, v read in place from qkv [B*L, 3*H*64] (columns 2*H*64 ..) -> ctx bf16 [B*L, H*64]
 hipError_t launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* qkv, bf16_t* ctx, int B, int L,
-                            int Lp, int H, hipStream_t stream);
+                            int H, hipStream_t stream);
 
 // ---- embed.hip -------------------------------------------------------------------------------
 // x[b,l,:] = E_seq[seq] + E_struct[struct'] + c + cond   (net.py:445-466)

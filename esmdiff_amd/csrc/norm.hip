@@ -7,7 +7,7 @@
 //   layernorm_bf16_in     same on a bf16 input (RegressionHead's LayerNorm after GELU, net.py:301)
 //   qk_norm_rope          full-width (D) LayerNorm of q and of k (attn.q_ln / attn.k_ln, no bias), rotary
 //                         (rotate-half, base 10000) per 64-wide head, q pre-scaled by log2(e)/sqrt(64);
-//                         writes head-major q,k [B,H,Lp,64]
+//                         writes token-major q,k [M, D] (same row layout as qkv, contiguous 1 KiB stores)
 //                         (v is not touched: attention.hip reads it in place and transposes in its LDS reads)
 #include "kernels.h"
 
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
                                                            const float* __restrict__ rope_cos,
                                                            const float* __restrict__ rope_sin,
                                                            bf16_t* __restrict__ qo, bf16_t* __restrict__ ko, int B,
-                                                           int L, int Lp, int H) {
+                                                           int L, int H) {
   const int lane = threadIdx.x & 63;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= B * L) return;
@@ -257,7 +257,6 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
       const int c0 = j * 512 + lane * 8;
-      const int h = c0 >> 6;
       float n[8], r[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) n[e] = (v[j][e] - mean) * rstd * w[c0 + e];
@@ -271,20 +270,20 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
       }
       uint4 p;
       p.x = pack2(r[0], r[1]); p.y = pack2(r[2], r[3]); p.z = pack2(r[4], r[5]); p.w = pack2(r[6], r[7]);
-      *reinterpret_cast<uint4*>(dst + (((int64_t)b * H + h) * Lp + l) * 64 + o) = p;
+      *reinterpret_cast<uint4*>(dst + (int64_t)tok * D + c0) = p;  // token-major: 1 KiB contiguous per wave store
     }
   }
 }
 
 hipError_t launch_qk_norm_rope(const bf16_t* qkv, const float* q_ln_w, const float* k_ln_w,
                                const float* rope_cos, const float* rope_sin, bf16_t* q, bf16_t* k,
-                               int B, int L, int Lp, int H, hipStream_t stream) {
+                               int B, int L, int H, hipStream_t stream) {
   const int D = H * 64, M = B * L;
   if (M <= 0) return hipSuccess;
-  if (D % 512 != 0 || D > 2048 || Lp % 64 != 0) return hipErrorInvalidValue;
+  if (D % 512 != 0 || D > 2048) return hipErrorInvalidValue;
   dim3 grid((M + 3) / 4), block(256);
 #define ED_QK(N) \
-  hipLaunchKernelGGL(qk_norm_rope_kernel<N>, grid, block, 0, stream, qkv, q_ln_w, k_ln_w, rope_cos, rope_sin, q, k, B, L, Lp, H)
+  hipLaunchKernelGGL(qk_norm_rope_kernel<N>, grid, block, 0, stream, qkv, q_ln_w, k_ln_w, rope_cos, rope_sin, q, k, B, L, H)
   switch (D / 512) {
     case 1: ED_QK(1); break;
     case 2: ED_QK(2); break;
