@@ -53,6 +53,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_unif
 
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
 
+// silu(g) * u with v_exp_f32 + v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division sequence: the result is
+// rounded to bf16 (8 bits) right after
+__device__ __forceinline__ float silu_mul(float g, float u) {
+  return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896341f)) * u;
+}
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // v_cvt_pk_bf16_f32, round to nearest even
   typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
   typedef __attribute__((ext_vector_type(2))) float f32x2_t;
@@ -213,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
       for (int r = 0; r < 16; ++r) {
         const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * rhalf;
         const float g = acc[i][0][r], u = acc[i][1][r];
-        slab[row * SW + ccol] = (g / (1.0f + __expf(-g))) * u;  // silu(gate) * up
+        slab[row * SW + ccol] = silu_mul(g, u);  // silu(gate) * up
       }
     } else {
 #pragma unroll
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
       u[0] += t[0]; u[1] += t[1]; u[2] += t[2]; u[3] += t[3];
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (v[e] / (1.0f + __expf(-v[e]))) * u[e];
+    for (int e = 0; e < 4; ++e) v[e] = silu_mul(v[e], u[e]);
   }
   const int n = c;
   if constexpr (EPI == ESMDIFF_EPI_BF16 || SWIGLU) {
