@@ -55,7 +55,7 @@ struct esmdiff_engine {
   // workspace
   float* x = nullptr;
   bf16_t *h = nullptr, *h2 = nullptr, *qkv = nullptr, *q = nullptr, *k = nullptr, *ctx = nullptr,
-         *mid = nullptr, *dlt = nullptr;
+         *mid = nullptr, *dlt = nullptr, *dlt2 = nullptr;
   float *logits = nullptr, *cond = nullptr, *sig_hidden = nullptr, *tfreq = nullptr, *g_entropy = nullptr;
   int32_t *g_sampled = nullptr, *g_nunmask = nullptr;
   int ld_logits = 0, tfreq_rows = 0;
@@ -202,7 +202,7 @@ int check_bl(esmdiff_engine* e, int B, int L) {
 struct Part {
   const int64_t *seq, *xtok;
   float *x, *logits;
-  bf16_t *h, *h2, *qkv, *q, *k, *ctx, *mid, *dlt;
+  bf16_t *h, *h2, *qkv, *q, *k, *ctx, *mid, *dlt, *dlt2;
   int B;
   hipStream_t st;
   const ed::GemmWorkspace* gws;
@@ -213,7 +213,7 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
   const esmdiff_config& c = e->cfg;
   const int64_t t0 = (int64_t)b0 * L, D = c.d_model;
   return Part{seq + t0, xtok + t0, e->x + t0 * D, logits + t0 * ld, e->h + t0 * D, e->h2 + t0 * D, e->qkv + t0 * 3 * D,
-              e->q + t0 * D, e->k + t0 * D, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, nb, st,
+              e->q + t0 * D, e->k + t0 * D, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, e->dlt2 + t0 * D, nb, st,
               e->gemm_ws[queue].partial ? &e->gemm_ws[queue] : nullptr};
 }
 
@@ -266,23 +266,25 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   }
 
   EACH(S_EMBED, launch_embed(w.seq, w.xtok, e->e_seq, e->e_struct, e->cvec, cond, w.x, w.B, L, D, w.st));
-  // The residual stream x stays f32.  Each branch GEMM (out-proj, FFN-down) writes its output, already
-  // divided by the residue scale, as a bf16 delta; the NEXT LayerNorm kernel adds it into x while it
-  // reads x anyway (fused add + LN), so no GEMM epilogue does a read-modify-write.
+  // The residual stream x stays f32.  Each branch GEMM (out-proj -> dlt2, FFN-down -> dlt) writes its output, already
+  // divided by the residue scale, as a bf16 delta; the LayerNorm kernels add the deltas while they read x anyway, so no
+  // GEMM epilogue does a read-modify-write.  x is written back once per block: the attention-side LayerNorm only
+  // forms x + dF(previous block) in registers, the FFN-side one forms (x + dF) + dA — the same two f32 additions in the
+  // same order as adding them one LayerNorm apart — and stores it.
   bool pending = false;
   for (int i = 0; i < c.n_layers; ++i) {
     const Layer& ly = e->layers[i];
-    EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
+    EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
     EACH(S_QKV, launch_gemm_bf16(w.h, ly.w_qkv, w.qkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
     EACH(S_QKROPE, launch_qk_norm_rope(w.qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.q, w.k, w.B, L, H, w.st));
     EACH(S_ATTN, launch_attention(w.q, w.k, w.qkv, w.ctx, w.B, L, H, w.st));
-    EACH(S_OUT, launch_gemm_bf16(w.ctx, ly.w_out, w.dlt, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
-    EACH(S_LN, launch_add_layernorm_bf16(w.x, w.dlt, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
+    EACH(S_OUT, launch_gemm_bf16(w.ctx, ly.w_out, w.dlt2, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
+    EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, w.dlt2, 1, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
     EACH(S_FFN_UP, launch_gemm_bf16(w.h, ly.w_up, w.mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, w.st, w.gws));
     EACH(S_FFN_DOWN, launch_gemm_bf16(w.mid, ly.w_down, w.dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
     pending = true;
   }
-  EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, e->final_ln_w, nullptr, w.h, M, D, w.st));
+  EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, e->final_ln_w, nullptr, w.h, M, D, w.st));
   EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w0, w.h2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, w.st, w.gws));
   EACH(S_LN, launch_layernorm_bf16_in(w.h2, e->head_ln_w, e->head_ln_b, w.h, M, D, w.st));
   EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w3, w.logits, e->head_b3, M, e->vocab_pad, D, ld, c.vocab_out, 1.f, ESMDIFF_EPI_BIAS_F32, w.st, w.gws));
@@ -459,6 +461,7 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
     TRY(dalloc(e, &e->k, Mx * D));
     TRY(dalloc(e, &e->ctx, Mx * D));
     TRY(dalloc(e, &e->dlt, Mx * D));
+    TRY(dalloc(e, &e->dlt2, Mx * D));
     TRY(dalloc(e, &e->mid, Mx * FH));
     TRY(dalloc(e, &e->logits, Mx * e->ld_logits));
     TRY(dalloc(e, &e->cond, (size_t)D));

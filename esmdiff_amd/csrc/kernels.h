@@ -42,9 +42,9 @@ hipError_t launch_gemm256_bf16(const bf16_t* A, const bf16_t* W, void* out, cons
 // ---- norm.hip --------------------------------------------------------------------------------
 hipError_t launch_layernorm_bf16(const float* x, const float* w, const float* b, bf16_t* y, int M, int D,
                                  hipStream_t stream);
-// x (f32, in place) += delta (bf16 or null); y = LayerNorm(x) * w (+ b)
-hipError_t launch_add_layernorm_bf16(float* x, const bf16_t* delta, const float* w, const float* b, bf16_t* y, int M,
-                                     int D, hipStream_t stream);
+// v = (x + delta) + delta2 (bf16 or null each); x = v if write_x; y = LayerNorm(v) * w (+ b)
+hipError_t launch_add_layernorm_bf16(float* x, const bf16_t* delta, const bf16_t* delta2, int write_x, const float* w,
+                                     const float* b, bf16_t* y, int M, int D, hipStream_t stream);
 hipError_t launch_layernorm_bf16_in(const bf16_t* x, const float* w, const float* b, bf16_t* y, int M, int D,
                                     hipStream_t stream);
 // qkv bf16 [M,3D] -> q,k bf16 [M,D] token-major (LayerNorm over D, rotary, q pre-scaled); v stays in qkv

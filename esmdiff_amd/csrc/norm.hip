@@ -130,8 +130,9 @@ hipError_t launch_layernorm_bf16_in(const bf16_t* x, const float* w, const float
 // loads sat exposed behind the MFMA main loop) and into a pure streaming kernel.  D == NV * 256 exactly.
 template <int NV>
 __global__ __launch_bounds__(256) void add_layernorm_kernel(float* __restrict__ x, const bf16_t* __restrict__ delta,
+                                                            const bf16_t* __restrict__ delta2,
                                                             const float* __restrict__ w, const float* __restrict__ b,
-                                                            bf16_t* __restrict__ y, int M) {
+                                                            bf16_t* __restrict__ y, int M, int write_x) {
   constexpr int D = NV * 256;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -140,8 +141,9 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(float* __restrict__ 
   f32x4 v[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) v[j] = *reinterpret_cast<const f32x4*>(xr + j * 256);
-  if (delta) {
-    const bf16_t* dr = delta + (int64_t)row * D + lane * 4;
+  // v = (x + delta) + delta2, in that order: the same f32 sums as adding the two branch outputs one LayerNorm apart
+  auto add_bf16 = [&](const bf16_t* dptr) {
+    const bf16_t* dr = dptr + (int64_t)row * D + lane * 4;
     uint2 p[NV];
 #pragma unroll
     for (int j = 0; j < NV; ++j) p[j] = *reinterpret_cast<const uint2*>(dr + j * 256);
@@ -149,8 +151,13 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(float* __restrict__ 
     for (int j = 0; j < NV; ++j) {
       v[j][0] += bf2f(p[j].x & 0xffffu); v[j][1] += bf2f(p[j].x >> 16);
       v[j][2] += bf2f(p[j].y & 0xffffu); v[j][3] += bf2f(p[j].y >> 16);
-      *reinterpret_cast<f32x4*>(xr + j * 256) = v[j];
     }
+  };
+  if (delta) add_bf16(delta);
+  if (delta2) add_bf16(delta2);
+  if (write_x && (delta || delta2)) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) *reinterpret_cast<f32x4*>(xr + j * 256) = v[j];
   }
   float s = 0.f;
 #pragma unroll
@@ -184,12 +191,13 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(float* __restrict__ 
   }
 }
 
-hipError_t launch_add_layernorm_bf16(float* x, const bf16_t* delta, const float* w, const float* b, bf16_t* y, int M,
-                                     int D, hipStream_t stream) {
+hipError_t launch_add_layernorm_bf16(float* x, const bf16_t* delta, const bf16_t* delta2, int write_x, const float* w,
+                                     const float* b, bf16_t* y, int M, int D, hipStream_t stream) {
   if (M <= 0) return hipSuccess;
   if (D % 256 != 0 || D > 2048) return hipErrorInvalidValue;
   dim3 grid((M + 3) / 4), block(256);
-#define ED_ALN(N) hipLaunchKernelGGL(add_layernorm_kernel<N>, grid, block, 0, stream, x, delta, w, b, y, M)
+#define ED_ALN(N) \
+  hipLaunchKernelGGL(add_layernorm_kernel<N>, grid, block, 0, stream, x, delta, delta2, w, b, y, M, write_x)
   switch (D / 256) {
     case 1: ED_ALN(1); break;
     case 2: ED_ALN(2); break;
