@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
   // 32-register O rescale is skipped on almost every tile.  The decision sits between S and P of the SAME tile
   // and no P·V is pending across it, so everything at the old scale (O and l) is rescaled exactly once.
   constexpr float THR = 8.0f;
-  auto tile = [&](int kt, auto MASKED) {
+  auto tile = [&](int kt, auto MASKED, auto HALF) {  // HALF: at most 32 valid keys left (e.g. L = 258: keys 256, 257)
+    constexpr int NT = decltype(HALF)::value ? 1 : 2;
     const int cur = kt & 1;
     if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
     if (active) {
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
       const char* vl = kl + KV_BYTES;
       f32x16 s[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
@@ -151,14 +152,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
       if constexpr (decltype(MASKED)::value) {  // keys >= L exist only in the last tile
         const int lim = L - kt * KV_TILE - 4 * hi;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (t * 32 + (r & 3) + 8 * (r >> 2) >= lim) s[t][r] = -1e30f;
       }
       float mx = s[0][0];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
       }
       float ps = 0.f;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           s[t][r] = fast_exp2(s[t][r] - m_run);
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         }
       l_run += ps;
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+      for (int kk = 0; kk < 2 * NT; ++kk) {
         const int t = kk >> 1, r0 = (kk & 1) * 8;
         union { uint32_t u[4]; bf16x8 v; } pb;
 #pragma unroll
@@ -199,9 +200,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
-  for (int kt = 0; kt + 1 < nkt; ++kt) tile(kt, std::false_type{});
-  if (nkt * KV_TILE > L) tile(nkt - 1, std::true_type{});
-  else tile(nkt - 1, std::false_type{});
+  for (int kt = 0; kt + 1 < nkt; ++kt) tile(kt, std::false_type{}, std::false_type{});
+  const int tail = L - (nkt - 1) * KV_TILE;  // valid keys of the last tile, 1..64
+  if (tail <= 32) tile(nkt - 1, std::true_type{}, std::true_type{});
+  else if (tail < KV_TILE) tile(nkt - 1, std::true_type{}, std::false_type{});
+  else tile(nkt - 1, std::false_type{}, std::false_type{});
 
   if (!active) return;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
