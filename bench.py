@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="debug: timed region without the in-stream HIP events")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--inpaint", type=str, default=None, metavar="A:B",
+                    help="BASELINE configs[4]: residues A..B-1 start as MASK, all others carry fixed (synthetic) structure "
+                         "tokens through input_prior (sample_esmdiff.py:196-209); use with --num-steps 50")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,8 +133,15 @@ def main():
     sch = ddpm_schedule(T, freq_dim=cfg.freq_dim)
     gathered = [torch.empty(B, L * 2, dtype=torch.uint8, device=dev) for _ in range(world)] if use_dist else None
 
+    prior = None
+    if args.inpaint:
+        a, b = (int(v) for v in args.inpaint.split(":"))
+        prior = torch.randint(0, 4096, (1, L), generator=g).repeat(B, 1)
+        prior[:, a:b] = 4096                                     # token-space indices, as the reference uses them (:200-201)
+        prior = prior.to(dev)
+
     def one_step(step_idx):
-        ids = eng.ddpm_sample(seq, sch, seed=args.seed + step_idx, sample_offset=rank * B)
+        ids = eng.ddpm_sample(seq, sch, seed=args.seed + step_idx, sample_offset=rank * B, input_prior=prior)
         if use_dist:                                             # one exchange at the end: int16 ids over RCCL
             dist.all_gather(gathered, ids.to(torch.int16).view(torch.uint8))
         return ids
@@ -204,8 +214,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic" if not args.tiny else "debug-tiny-model",
-            "config": {"workload": f"BASELINE configs[1]: single MI355X, {args.residues}-residue synthetic sequence, "
-                                   f"num_steps={T}, num_samples={B}/GPU, ESM3-open-sized random-init weights, bf16 MFMA",
+            "config": {"workload": f"BASELINE configs[{4 if args.inpaint else 1}]: single MI355X, {args.residues}-residue synthetic sequence, "
+                                   f"num_steps={T}, num_samples={B}/GPU, ESM3-open-sized random-init weights, bf16 MFMA"
+                                   + (f", inpainting prior with residues {args.inpaint} masked" if args.inpaint else ""),
                        "samples_per_gpu": B, "L_tok": L, "num_steps": T, "forwards_per_sample": T + 1,
                        "layers": cfg.n_layers, "d_model": cfg.d_model, "noise": "philox4x32-10",
                        "parallelism": f"sample-sharded x{world}, one RCCL all_gather of int16 ids"},
