@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="debug: timed region without the in-stream HIP events")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--mode", choices=["ddpm", "gibbs"], default="ddpm",
+                    help="gibbs: the CLI's default mode (entropy-ordered unmasking, temperature 1.4, top-p 0.9: "
+                         "sample_esmdiff.py:66-130) — num_steps forwards instead of num_steps + 1; not the headline metric")
     ap.add_argument("--inpaint", type=str, default=None, metavar="A:B",
                     help="BASELINE configs[4]: residues A..B-1 start as MASK, all others carry fixed (synthetic) structure "
                          "tokens through input_prior (sample_esmdiff.py:196-209); use with --num-steps 50")
@@ -140,8 +143,18 @@ def main():
         prior[:, a:b] = 4096                                     # token-space indices, as the reference uses them (:200-201)
         prior = prior.to(dev)
 
+    if args.mode == "gibbs":
+        from esmdiff_amd.gibbs import unmask_schedule
+        x0 = torch.full((B, L), 4096, dtype=torch.int64)
+        x0[:, 0], x0[:, -1] = 4098, 4097                          # structure BOS / EOS
+        table = torch.tensor(unmask_schedule(L - 2, T), dtype=torch.int32)[:, None].repeat(1, B)
+        x0 = x0.to(dev)
+
     def one_step(step_idx):
-        ids = eng.ddpm_sample(seq, sch, seed=args.seed + step_idx, sample_offset=rank * B, input_prior=prior)
+        if args.mode == "gibbs":
+            ids = eng.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=args.seed + step_idx, sample_offset=rank * B)
+        else:
+            ids = eng.ddpm_sample(seq, sch, seed=args.seed + step_idx, sample_offset=rank * B, input_prior=prior)
         if use_dist:                                             # one exchange at the end: int16 ids over RCCL
             dist.all_gather(gathered, ids.to(torch.int16).view(torch.uint8))
         return ids
@@ -178,14 +191,15 @@ def main():
     if rank == 0:
         total_samples = B * world * args.steps
         value = total_samples / elapsed
-        f_sample = flops_forward_per_sample(L, cfg) * (T + 1)
+        n_fwd_sample = T + 1 if args.mode == "ddpm" else int(table.shape[0])
+        f_sample = flops_forward_per_sample(L, cfg) * n_fwd_sample
         # dominant kernel: FFN-up GEMM  [M,1536] x [8192,1536]^T with the SwiGLU epilogue
         M = B * L
         # The engine runs a large batch as sub-batches on separate HIP streams, so a launch covers M / parts rows and
         # overlaps with the other stream's kernels.  roofline.* is the spec'd live figure (events on the launch stream,
         # timed region); "exclusive" is the same kernel alone on the GPU at full M (the single-stream breakdown pass).
         up = prof_dom["gemm_ffn_up"] if prof_dom["gemm_ffn_up"]["launches"] else prof["gemm_ffn_up"]
-        expect = args.steps * (T + 1) * cfg.n_layers if prof_dom["gemm_ffn_up"]["launches"] else (T + 1) * cfg.n_layers
+        expect = args.steps * n_fwd_sample * cfg.n_layers if prof_dom["gemm_ffn_up"]["launches"] else n_fwd_sample * cfg.n_layers
         parts = max(1, round(up["launches"] / expect))
         flop_up_full = 2.0 * M * cfg.d_model * 2 * cfg.ffn_hidden
         flop_up = flop_up_full / parts
@@ -199,7 +213,7 @@ def main():
         lin_flop_fwd = M * (cfg.n_layers * (2 * cfg.d_model * (3 * cfg.d_model + cfg.d_model + 2 * cfg.ffn_hidden)
                                             + 2 * cfg.ffn_hidden * cfg.d_model)
                             + 2 * cfg.d_model * cfg.d_model + 2 * cfg.d_model * cfg.n_structure_heads)
-        n_fwd = T + 1                                            # the breakdown pass is one step
+        n_fwd = n_fwd_sample                                     # the breakdown pass is one step
         traffic, traffic_note = None, "no PMC pass on record"
         tp = ROOT / "profiles" / "r01_gemm_traffic.json"
         if tp.exists() and not args.tiny:   # separate rocprofv3 --pmc passes of this same kernel at this M
@@ -209,7 +223,7 @@ def main():
                 traffic, traffic_note = rec["traffic_bytes_per_launch"], ("profiles/r01_gemm_traffic.json: FETCH_SIZE x2 "
                                                                            "(gfx950 correction) + WRITE_SIZE, fabric-level")
         out = {
-            "metric": "conformation samples/sec (256-res, 25 steps)",
+            "metric": "conformation samples/sec (256-res, 25 steps)" if args.mode == "ddpm" else "conformation samples/sec (gibbs mode)",
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
@@ -217,7 +231,7 @@ def main():
             "config": {"workload": f"BASELINE configs[{4 if args.inpaint else 1}]: single MI355X, {args.residues}-residue synthetic sequence, "
                                    f"num_steps={T}, num_samples={B}/GPU, ESM3-open-sized random-init weights, bf16 MFMA"
                                    + (f", inpainting prior with residues {args.inpaint} masked" if args.inpaint else ""),
-                       "samples_per_gpu": B, "L_tok": L, "num_steps": T, "forwards_per_sample": T + 1,
+                       "samples_per_gpu": B, "L_tok": L, "num_steps": T, "forwards_per_sample": n_fwd_sample, "mode": args.mode,
                        "layers": cfg.n_layers, "d_model": cfg.d_model, "noise": "philox4x32-10",
                        "parallelism": f"sample-sharded x{world}, one RCCL all_gather of int16 ids"},
             "flop_per_sample": f_sample,
