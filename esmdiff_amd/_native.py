@@ -38,7 +38,7 @@ EXPORTS = [
     "esmdiff_forward_logits", "esmdiff_ddpm_step", "esmdiff_ddpm_sample", "esmdiff_gibbs_step",
     "esmdiff_gibbs_sample", "esmdiff_gemm_bf16",
     "esmdiff_gemm_bf16_timed", "esmdiff_layernorm_bf16", "esmdiff_attention_bf16", "esmdiff_set_profiling",
-    "esmdiff_get_profile",
+    "esmdiff_get_profile", "esmdiff_set_frames",
 ]
 
 

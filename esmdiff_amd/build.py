@@ -24,6 +24,7 @@ UNITS = {
     "engine": [],
     "gemm": [],
     "gemm256": [],
+    "geom": [],
     "attention": [],
     "norm": [],
     "embed": [],

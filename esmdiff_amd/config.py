@@ -11,7 +11,7 @@ from dataclasses import dataclass
 class ModelConfig:
     d_model: int = 1536            # net.py:325
     n_heads: int = 24              # net.py:326
-    v_heads: int = 256             # net.py:327 (geometric attention; unused without coordinates)
+    v_heads: int = 256             # net.py:327 (block 0 geometric attention; live only with coordinates)
     n_layers: int = 48             # net.py:328
     n_structure_heads: int = 4101  # mdlm.yaml:57
     freq_dim: int = 256            # TimestepEmbedder.frequency_embedding_size, net.py:487
@@ -30,4 +30,4 @@ class ModelConfig:
 
 ESM3_OPEN = ModelConfig()
 # small configuration with the same structure, for tests (d_model must be a multiple of 512)
-TINY = ModelConfig(d_model=512, n_heads=8, v_heads=32, n_layers=2)
+TINY = ModelConfig(d_model=512, n_heads=8, v_heads=128, n_layers=2)  # v_heads: the engine needs a multiple of 128

@@ -52,6 +52,15 @@ struct esmdiff_engine {
   float *sig_w1 = nullptr, *sig_b1 = nullptr, *sig_w2 = nullptr, *sig_b2 = nullptr;
   float *rope_cos = nullptr, *rope_sin = nullptr;
   int vocab_pad = 0;
+  // block 0 geometric attention (optional weights; live only while frames are set)
+  bool has_geom = false;
+  int v_heads = 0;  // rows of geom_attn.proj.weight / 15
+  float *g_snorm_w = nullptr, *g_wrot = nullptr, *g_wdist = nullptr;
+  bf16_t *g_proj = nullptr, *g_out = nullptr;
+  bf16_t *gp = nullptr, *gctx = nullptr;
+  float *f_rot = nullptr, *f_trans = nullptr;
+  uint8_t* f_mask = nullptr;
+  int frames_B = 0, frames_L = 0;
   // workspace
   float* x = nullptr;
   bf16_t *h = nullptr, *h2 = nullptr, *qkv = nullptr, *q = nullptr, *k = nullptr, *ctx = nullptr,
@@ -203,6 +212,9 @@ struct Part {
   const int64_t *seq, *xtok;
   float *x, *logits;
   bf16_t *h, *h2, *qkv, *q, *k, *ctx, *mid, *dlt, *dlt2;
+  bf16_t *gp, *gctx;
+  const float *f_rot, *f_trans;
+  const uint8_t* f_mask;
   int B;
   hipStream_t st;
   const ed::GemmWorkspace* gws;
@@ -213,7 +225,10 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
   const esmdiff_config& c = e->cfg;
   const int64_t t0 = (int64_t)b0 * L, D = c.d_model;
   return Part{seq + t0, xtok + t0, e->x + t0 * D, logits + t0 * ld, e->h + t0 * D, e->h2 + t0 * D, e->qkv + t0 * 3 * D,
-              e->q + t0 * D, e->k + t0 * D, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, e->dlt2 + t0 * D, nb, st,
+              e->q + t0 * D, e->k + t0 * D, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, e->dlt2 + t0 * D,
+              e->gp ? e->gp + t0 * 15 * e->v_heads : nullptr, e->gctx ? e->gctx + t0 * 3 * e->v_heads : nullptr,
+              e->f_rot ? e->f_rot + t0 * 9 : nullptr, e->f_trans ? e->f_trans + t0 * 3 : nullptr,
+              e->f_mask ? e->f_mask + t0 : nullptr, nb, st,
               e->gemm_ws[queue].partial ? &e->gemm_ws[queue] : nullptr};
 }
 
@@ -271,6 +286,10 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   // GEMM epilogue does a read-modify-write.  x is written back once per block: the attention-side LayerNorm only
   // forms x + dF(previous block) in registers, the FFN-side one forms (x + dF) + dA — the same two f32 additions in the
   // same order as adding them one LayerNorm apart — and stores it.
+  const bool geom = e->has_geom && e->frames_B > 0;
+  if (geom && (e->frames_B != B || e->frames_L != L))
+    return fail(e, ESMDIFF_E_INVALID, "frames were set for B=%d L=%d, forward called with B=%d L=%d", e->frames_B, e->frames_L, B, L);
+  const int VH = e->v_heads;
   bool pending = false;
   for (int i = 0; i < c.n_layers; ++i) {
     const Layer& ly = e->layers[i];
@@ -279,6 +298,14 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
     EACH(S_QKROPE, launch_qk_norm_rope(w.qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.q, w.k, w.B, L, H, w.st));
     EACH(S_ATTN, launch_attention(w.q, w.k, w.qkv, w.ctx, w.B, L, H, w.st));
     EACH(S_OUT, launch_gemm_bf16(w.ctx, ly.w_out, w.dlt2, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
+    if (i == 0 && geom) {
+      // x += dA; s = s_norm(x); p = proj(s); geometric attention; dG = out_proj(.) / scale  (block 0 only; the FFN-side
+      // LayerNorm below then adds dG instead of dA)
+      EACH(S_LN, launch_add_layernorm_bf16(w.x, nullptr, w.dlt2, 1, e->g_snorm_w, nullptr, w.h, M, D, w.st));
+      EACH(S_ATTN, launch_gemm_bf16(w.h, e->g_proj, w.gp, nullptr, M, 15 * VH, D, 15 * VH, 15 * VH, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
+      EACH(S_ATTN, launch_geom_attention(w.gp, w.f_rot, w.f_trans, w.f_mask, e->g_wrot, e->g_wdist, w.gctx, w.B, L, VH, w.st));
+      EACH(S_ATTN, launch_gemm_bf16(w.gctx, e->g_out, w.dlt2, nullptr, M, D, 3 * VH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
+    }
     EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, w.dlt2, 1, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
     EACH(S_FFN_UP, launch_gemm_bf16(w.h, ly.w_up, w.mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, w.st, w.gws));
     EACH(S_FFN_DOWN, launch_gemm_bf16(w.mid, ly.w_down, w.dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
@@ -395,6 +422,26 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
     TRY(load_f32(e, t, "sigma_embedder.mlp.2.weight", {D, D}, &e->sig_w2));
     TRY(load_f32(e, t, "sigma_embedder.mlp.2.bias", {D}, &e->sig_b2));
   }
+  // block 0's geometric attention: optional (the DDPM path never needs it: coordinates are all-NaN there)
+  if (const esmdiff_weight* pw = t.find("transformer.blocks.0.geom_attn.proj.weight")) {
+    const std::string ga = "transformer.blocks.0.geom_attn.";
+    const int VH = pw->ndim == 2 ? (int)(pw->shape[0] / 15) : 0;  // proj: Linear(D, v_heads * 3 * 5)
+    if (VH <= 0 || (15 * VH) % 128 || (3 * VH) % 64) return bail(fail(e, ESMDIFF_E_INVALID, "geom_attn v_heads=%d unsupported", VH));
+    e->v_heads = VH;
+    TRY(load_f32(e, t, ga + "s_norm.weight", {D}, &e->g_snorm_w));
+    TRY(load_bf16(e, t, ga + "proj.weight", {15 * VH, D}, &e->g_proj));
+    TRY(load_bf16(e, t, ga + "out_proj.weight", {D, 3 * VH}, &e->g_out));
+    TRY(load_f32(e, t, ga + "rotation_scale_per_head", {VH}, &e->g_wrot));
+    TRY(load_f32(e, t, ga + "distance_scale_per_head", {VH}, &e->g_wdist));
+    if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "geom weight conversion failed"));
+    std::vector<float> hw(VH);
+    for (float* p : {e->g_wrot, e->g_wdist}) {  // softplus once, on the host
+      hipMemcpy(hw.data(), p, VH * 4, hipMemcpyDeviceToHost);
+      for (float& v : hw) v = v > 20.f ? v : log1pf(expf(v));
+      hipMemcpy(p, hw.data(), VH * 4, hipMemcpyHostToDevice);
+    }
+    e->has_geom = true;
+  }
   // constant vector of the defaulted tracks (net.py:410-431 -> esm EncodeInputs): average_plddt = 1,
   // per_res_plddt = 0 through rbf(.,0,1,16) and a Linear(16,D); ss8 / sasa pad id 0; function and
   // residue-annotation pads embed to zero (padding_idx=0).
@@ -462,6 +509,13 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
     TRY(dalloc(e, &e->ctx, Mx * D));
     TRY(dalloc(e, &e->dlt, Mx * D));
     TRY(dalloc(e, &e->dlt2, Mx * D));
+    if (e->has_geom) {
+      TRY(dalloc(e, &e->gp, Mx * 15 * e->v_heads));
+      TRY(dalloc(e, &e->gctx, Mx * 3 * e->v_heads));
+      TRY(dalloc(e, &e->f_rot, Mx * 9));
+      TRY(dalloc(e, &e->f_trans, Mx * 3));
+      TRY(dalloc(e, &e->f_mask, Mx));
+    }
     TRY(dalloc(e, &e->mid, Mx * FH));
     TRY(dalloc(e, &e->logits, Mx * e->ld_logits));
     TRY(dalloc(e, &e->cond, (size_t)D));
@@ -634,6 +688,28 @@ int esmdiff_attention_bf16(esmdiff_engine* e, const void* qkv, const float* q_ln
   HIP_TRY(e, launch_qk_norm_rope((const bf16_t*)qkv, q_ln_w, k_ln_w, e->rope_cos, e->rope_sin, e->q, e->k, B, L,
                                  e->cfg.n_heads, (hipStream_t)stream));
   HIP_TRY(e, launch_attention(e->q, e->k, (const bf16_t*)qkv, (bf16_t*)ctx, B, L, e->cfg.n_heads, (hipStream_t)stream));
+  return 0;
+}
+
+int esmdiff_set_frames(esmdiff_engine* e, const float* rot, const float* trans, const uint8_t* has_frame, int32_t B,
+                       int32_t L, void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!rot) {
+    e->frames_B = e->frames_L = 0;
+    return 0;
+  }
+  if (!e->has_geom)
+    return fail(e, ESMDIFF_E_MISSING, "coordinates given but the weight table had no transformer.blocks.0.geom_attn.* tensors");
+  if (!trans || !has_frame) return fail(e, ESMDIFF_E_INVALID, "null argument");
+  if (int r = check_bl(e, B, L)) return r;
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)stream;
+  const size_t M = (size_t)B * L;
+  HIP_TRY(e, hipMemcpyAsync(e->f_rot, rot, M * 9 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(e, hipMemcpyAsync(e->f_trans, trans, M * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(e, hipMemcpyAsync(e->f_mask, has_frame, M, hipMemcpyDeviceToDevice, st));
+  e->frames_B = B;
+  e->frames_L = L;
   return 0;
 }
 

@@ -1,0 +1,130 @@
+// geom.hip — block 0's geometric attention: coordinate conditioning of ESM3 (gfx950).
+//
+// Reference call sites: /root/reference/slm/models/net.py:433-441 (coordinates -> frames), :468 (transformer(x,
+// sequence_id, affine, affine_mask, chain_id)), :339-346 (v_heads = 256, mask_and_zero_frameless = True);
+// the sampler reaches it only when coordinates are supplied (/root/reference/slm/sample_esmdiff.py:88-96, inpainting
+// in the default "gibbs" mode).  The arithmetic is esm==3.0.4's GeometricReasoningOriginalImpl, which is not
+// vendored: restated from SURVEY.md A.4 [ESM-RECALL], PARITY UNPINNED; checked against oracle/geom_ref.py.
+//
+//   p = proj(s_norm(x))                    [M, 15*VH] bf16 (GEMM), columns [q_rot | k_rot | value | q_dist | k_dist],
+//                                          each VH heads x 3 components
+//   q_rot,k_rot,value = R p                (rotation of the residue's frame);   q_dist,k_dist = R p + t
+//   logit[q,k] = softplus(rot_scale_h) (q_rot . k_rot)/sqrt3 - softplus(dist_scale_h) |q_dist - k_dist|/sqrt3
+//   keys without a frame are excluded; out[q] = R_q^T sum_k softmax(logit)[k] value[k]; rows without a frame := 0
+//
+// One 64-thread workgroup per (batch, head): the key side (9 floats per key) is rotated once into LDS, then every
+// lane owns a query and walks the keys with an online softmax (all lanes read the same key: LDS broadcast, no bank
+// conflicts).  Head dimension 3 leaves nothing for MFMA; the kernel is VALU-bound at ~25 ops per (query, key)
+// pair: 1.7e9 pairs per forward at config 2, i.e. about one millisecond, and only when coordinates are given.
+#include "kernels.h"
+
+namespace ed {
+
+__device__ __forceinline__ float gbf(const bf16_t* p) { return __uint_as_float((uint32_t)(*p) << 16); }
+
+__global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __restrict__ P, const float* __restrict__ rot,
+                                                           const float* __restrict__ trans,
+                                                           const uint8_t* __restrict__ fmask,
+                                                           const float* __restrict__ w_rot,
+                                                           const float* __restrict__ w_dist, bf16_t* __restrict__ out,
+                                                           int L, int VH) {
+  extern __shared__ float kl[];  // [L][10]: k_rot 3 | k_dist 3 | value 3 | has-frame
+  const int b = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
+  const int ldp = 15 * VH;
+  const int64_t row0 = (int64_t)b * L;
+  const float c = 0.57735026918962576f;  // 1/sqrt(3)
+  const float wr = w_rot[h] * c, wd = w_dist[h] * c;
+
+  auto load3 = [&](int64_t row, int col, float* v) {
+    const bf16_t* p = P + row * ldp + col;
+    v[0] = gbf(p); v[1] = gbf(p + 1); v[2] = gbf(p + 2);
+  };
+  auto rotate = [&](const float* R, const float* v, float* o) {  // o = R v, R row-major
+    o[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+    o[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+    o[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  };
+  for (int l = lane; l < L; l += 64) {
+    const int64_t row = row0 + l;
+    float R[9], t[3], v[3], o[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = rot[row * 9 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = trans[row * 3 + i];
+    float* k = kl + l * 10;
+    load3(row, 3 * VH + 3 * h, v);   // k_rot
+    rotate(R, v, o);
+    k[0] = o[0]; k[1] = o[1]; k[2] = o[2];
+    load3(row, 12 * VH + 3 * h, v);  // k_dist (second half of the distance block, which starts at 9*VH)
+    rotate(R, v, o);
+    k[3] = o[0] + t[0]; k[4] = o[1] + t[1]; k[5] = o[2] + t[2];
+    load3(row, 6 * VH + 3 * h, v);   // value
+    rotate(R, v, o);
+    k[6] = o[0]; k[7] = o[1]; k[8] = o[2];
+    k[9] = fmask[row] ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+
+  for (int q = lane; q < L; q += 64) {
+    const int64_t row = row0 + q;
+    float R[9], t[3], v[3], qr[3], qd[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = rot[row * 9 + i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t[i] = trans[row * 3 + i];
+    load3(row, 3 * h, v);            // q_rot
+    rotate(R, v, qr);
+    load3(row, 9 * VH + 3 * h, v);   // q_dist
+    rotate(R, v, qd);
+    qd[0] += t[0]; qd[1] += t[1]; qd[2] += t[2];
+    float m = -3.0e38f, den = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (fmask[row]) {  // rows without a frame are zeroed below; skip their walk
+      for (int k = 0; k < L; ++k) {
+        const float* kk = kl + k * 10;
+        if (kk[9] == 0.0f) continue;  // wave-uniform: every lane looks at the same key
+        const float dx = qd[0] - kk[3], dy = qd[1] - kk[4], dz = qd[2] - kk[5];
+        const float s = wr * (qr[0] * kk[0] + qr[1] * kk[1] + qr[2] * kk[2]) - wd * sqrtf(dx * dx + dy * dy + dz * dz);
+        if (s > m) {  // lazy rescale: rare after the first few keys
+          const float a = __expf(m - s);
+          den *= a; o0 *= a; o1 *= a; o2 *= a;
+          m = s;
+        }
+        const float p = __expf(s - m);
+        den += p;
+        o0 += p * kk[6]; o1 += p * kk[7]; o2 += p * kk[8];
+      }
+    }
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    if (den > 0.f) {
+      const float inv = 1.0f / den;
+      o0 *= inv; o1 *= inv; o2 *= inv;
+      r0 = R[0] * o0 + R[3] * o1 + R[6] * o2;  // R^T o: back into the residue's frame
+      r1 = R[1] * o0 + R[4] * o1 + R[7] * o2;
+      r2 = R[2] * o0 + R[5] * o1 + R[8] * o2;
+    }
+    bf16_t* dst = out + row * (3 * VH) + 3 * h;
+    auto f2b = [](float f) {
+      uint32_t u = __float_as_uint(f);
+      return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    };
+    dst[0] = f2b(r0); dst[1] = f2b(r1); dst[2] = f2b(r2);
+  }
+}
+
+hipError_t launch_geom_attention(const bf16_t* P, const float* rot, const float* trans, const uint8_t* fmask,
+                                 const float* w_rot, const float* w_dist, bf16_t* out, int B, int L, int VH,
+                                 hipStream_t stream) {
+  if (B <= 0 || L <= 0) return hipSuccess;
+  const size_t lds = (size_t)L * 10 * sizeof(float);
+  if (lds > 150 * 1024) return hipErrorInvalidValue;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void*)geom_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(geom_attention_kernel, dim3(VH, B), dim3(64), lds, stream, P, rot, trans, fmask, w_rot, w_dist, out,
+                     L, VH);
+  return hipGetLastError();
+}
+
+}  // namespace ed

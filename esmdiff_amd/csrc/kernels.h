@@ -57,6 +57,12 @@ hipError_t launch_qk_norm_rope(const bf16_t* qkv, const float* q_ln_w, const flo
 hipError_t launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* qkv, bf16_t* ctx, int B, int L,
                             int H, hipStream_t stream);
 
+// ---- geom.hip --------------------------------------------------------------------------------
+// P bf16 [B*L, 15*VH] (proj output) + frames -> out bf16 [B*L, 3*VH]; w_rot / w_dist = softplus(scale) per head
+hipError_t launch_geom_attention(const bf16_t* P, const float* rot, const float* trans, const uint8_t* fmask,
+                                 const float* w_rot, const float* w_dist, bf16_t* out, int B, int L, int VH,
+                                 hipStream_t stream);
+
 // ---- embed.hip -------------------------------------------------------------------------------
 // x[b,l,:] = E_seq[seq] + E_struct[struct'] + c + cond   (net.py:445-466)
 hipError_t launch_embed(const int64_t* seq, const int64_t* xtok, const float* e_seq, const float* e_struct,

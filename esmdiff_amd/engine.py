@@ -66,6 +66,8 @@ class Engine:
                                f"{self._lib.esmdiff_last_error(None).decode()}")
         del keep
         self.ld_logits = (cfg.n_structure_heads + 3) // 4 * 4
+        self.has_geom = any(k.endswith("transformer.blocks.0.geom_attn.proj.weight") for k in state_dict)
+        self._frames = None
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -184,6 +186,22 @@ class Engine:
                                                  tab.numpy().ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                                  ctypes.byref(rng), _stream()))
         return x
+
+    def set_frames(self, rot: Optional[torch.Tensor], trans: Optional[torch.Tensor] = None,
+                   has_frame: Optional[torch.Tensor] = None) -> None:
+        """Coordinate conditioning for the following forwards (esmdiff_set_frames): rot (B,L,3,3), trans (B,L,3),
+        has_frame (B,L) bool — see esmdiff_amd.geometry.build_affine3d_from_coordinates.  None clears them."""
+        if rot is None:
+            self._chk(self._lib.esmdiff_set_frames(self._h, None, None, None, 0, 0, _stream()))
+            self._frames = None
+            return
+        B, L = rot.shape[:2]
+        r = rot.to(device=self.device, dtype=torch.float32).contiguous()
+        t = trans.to(device=self.device, dtype=torch.float32).contiguous()
+        m = has_frame.to(device=self.device, dtype=torch.uint8).contiguous()
+        assert r.shape == (B, L, 3, 3) and t.shape == (B, L, 3) and m.shape == (B, L)
+        self._chk(self._lib.esmdiff_set_frames(self._h, _ptr(r), _ptr(t), _ptr(m), B, L, _stream()))
+        self._frames = (r, t, m)   # keep the staging tensors alive until the async copies have run
 
     # ---- per-kernel entry points (parity tests / roofline bench) ---------------------------------
     def set_profiling(self, mode):

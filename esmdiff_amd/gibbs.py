@@ -7,7 +7,11 @@
 encode every protein, batch them, `num_steps = min(num_steps, #masked)`, and at step t unmask the
 `still_masked - int(cos((t+1)/T * pi/2) * total + 0.1)` lowest-entropy masked positions with tokens drawn from the
 temperature / top-p filtered distribution.  One forward + one fused kernel pair per step, all on the device.
-Not covered: coordinates as conditioning (geometric attention) and decoding tokens to coordinates.
+Proteins that carry coordinates condition the model through block 0's geometric attention (frames from
+esmdiff_amd.geometry, residues with non-finite coordinates have no frame — the inpainting driver marks masked residues
+with Inf, sample_esmdiff.py:88-96); with `condition_on_coordinates_only` (the default) no structure tokens are derived
+from them.  Not covered: turning coordinates into structure tokens (VQ-VAE encoder) and tokens into coordinates
+(decoder), SURVEY.md 8f.
 """
 from __future__ import annotations
 
@@ -64,6 +68,20 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
         raise ValueError("all proteins of a batch must have the same length")
     seq = torch.stack(seqs)
     x0 = torch.stack([encode_structure_prior(p, L) for p in proteins])
+    has_xyz = [p.coordinates is not None for p in proteins]
+    if any(has_xyz):
+        from .geometry import build_affine3d_from_coordinates
+        if not getattr(eng, "has_geom", False):
+            raise RuntimeError("proteins carry coordinates but the loaded weights have no transformer.blocks.0.geom_attn.* "
+                               "tensors (geometric attention)")
+        xyz = torch.full((len(proteins), L, 3, 3), float("nan"))
+        for b, p in enumerate(proteins):
+            if p.coordinates is not None:
+                cb = torch.as_tensor(p.coordinates, dtype=torch.float32)
+                if cb.shape[0] != L - 2:
+                    raise ValueError(f"coordinates cover {cb.shape[0]} residues, sequence has {L - 2}")
+                xyz[b, 1:-1] = cb[:, :3, :]                  # BOS / EOS carry no coordinates
+        eng.set_frames(*build_affine3d_from_coordinates(xyz))
     totals = (x0 == C.STRUCTURE_MASK_TOKEN).sum(1).tolist()
     T = max(min(cfg0.num_steps, t) for t in totals) if max(totals) > 0 else 0
     if T == 0:
@@ -75,5 +93,7 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
             table[: len(sch), b] = torch.tensor(sch, dtype=torch.int32)
         out_x = eng.gibbs_sample(seq, x0, table, cfg0.temperature, cfg0.top_p, seed=seed,
                                  sample_offset=sample_offset).cpu()
+    if any(has_xyz):
+        eng.set_frames(None)
     return [ESMProtein(sequence=p.sequence, coordinates=None, structure_tokens=out_x[b, 1:-1].clone())
             for b, p in enumerate(proteins)]

@@ -103,5 +103,5 @@ def load_state_dict_from_lightning_ckpt(ckpt_path, device="cuda", max_batch: int
 def random_init_model(cfg: ModelConfig = ESM3_OPEN, seed: int = 0, max_batch: int = 128, max_len: int = 1026,
                       device: int = 0):
     """ESM3-open-sized random weights (no checkpoint can be fetched offline): synthetic benchmarking / tests."""
-    sd = random_init_state_dict(cfg, seed=seed, device=f"cuda:{device}")
+    sd = random_init_state_dict(cfg, seed=seed, device=f"cuda:{device}", with_geom=True)   # real checkpoints carry geom_attn too
     return MaskedDiffusionLanguageModeling(sd, cfg, LogLinearNoise(), max_batch, max_len, device, noise_removal=True)

@@ -110,9 +110,11 @@ def minibatch_gibbs_by_esm(protseq, esm3_model, output_dir: Path, sample_basenam
                            n_max_residue_square: int = DEFAULT_NMAX, coordinates=None, mask_ids=None,
                            structure_tokens=None, seed: int = 0, timestamp: bool = True):
     """sample_esmdiff.py:66-130: batches of ESMProtein copies through iterative_sampling_raw with
-    GenerationConfig(track="structure", num_steps, temperature, top_p).  Coordinates are accepted for interface
-    parity but do not condition the model here (geometric attention is not built); for inpainting
-    pass the known residues' `structure_tokens` (L,) and `mask_ids`."""
+    GenerationConfig(track="structure", num_steps, temperature, top_p).  Inpainting as the reference does it (:88-96):
+    `mask_ids` needs `coordinates` (L, >=3, 3); the masked residues get sequence '_' and coordinates Inf, and the known
+    backbone conditions the model through block 0's geometric attention while every structure token is sampled
+    (esm's condition_on_coordinates_only default).  Extension: `structure_tokens` (L,) of the known residues, when the
+    caller has them, are kept fixed as well."""
     from .gibbs import iterative_sampling_raw
     from .sdk import GenerationConfig
     str_time = ("_" + strftime("%Y%m%d-%H%M%S")) if timestamp else ""
@@ -125,16 +127,20 @@ def minibatch_gibbs_by_esm(protseq, esm3_model, output_dir: Path, sample_basenam
     if save_to.exists():
         print(f"Skip existing {save_to}")
         return None
-    st = None
+    st = None if structure_tokens is None else torch.as_tensor(structure_tokens, dtype=torch.int64).clone()
+    if coordinates is not None:
+        coordinates = torch.as_tensor(coordinates, dtype=torch.float32).clone()
     if mask_ids is not None:
         print(f"Masking {len(mask_ids)} residues and inpainting...")
-        assert structure_tokens is not None, "Need structure tokens of the known residues for masking"
+        assert coordinates is not None or st is not None, "Need to provide coordinates for masking"
         protseq = list(protseq)
-        st = torch.as_tensor(structure_tokens, dtype=torch.int64).clone()
         for idx in mask_ids:
             assert 0 <= idx < len(protseq), f"Invalid mask index {idx} for sequence of length {len(protseq)}"
             protseq[idx] = C.MASK_RESIDUE
-            st[idx] = C.STRUCTURE_MASK_TOKEN
+            if coordinates is not None:
+                coordinates[idx] = float("Inf")
+            if st is not None:
+                st[idx] = C.STRUCTURE_MASK_TOKEN
         protseq = "".join(protseq)
     start_t = time()
     offset, count = shard_samples(num_samples, world, rank)
@@ -174,6 +180,7 @@ def get_argparser(argv=None):
     p.add_argument("--mask_ids", type=str, default=None, help="Comma-separated list of masked indices.")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--random_init", action="store_true", help="ESM3-open-sized random weights instead of --ckpt")
+    p.add_argument("--tiny", action="store_true", help=argparse.SUPPRESS)   # tests: 2-block model with --random_init
     p.add_argument("--synthetic_len", type=int, default=0, help="sample a random sequence of this length")
     p.add_argument("--n_max_residue_square", type=int, default=DEFAULT_NMAX)
     p.add_argument("--parity", action="store_true", help="uniforms from torch's CPU generator, like the reference")
@@ -197,9 +204,14 @@ def main(argv=None):
         assert args.mode == "gibbs" or args.ckpt is not None, \
             "Only Gibbs sampling is supported for the pre-trained ESM3 model."
         raise SystemExit("no weights: pass --ckpt <release_v0.pt> or --random_init (synthetic weights)")
+    mask_ids = [int(i) for i in args.mask_ids.split(",")] if args.mask_ids else None   # 0-based index
+    if mask_ids is not None and args.mode == "ddpm":
+        raise SystemExit("--mode ddpm --mask_ids needs structure tokens of the known residues, i.e. the VQ-VAE encoder "
+                         "(SURVEY.md 8f-4); call ddpm_sample_by_esm(structure_tokens=...) from Python, or use the "
+                         "default gibbs mode, which conditions on the coordinates directly")
     from .model import load_state_dict_from_lightning_ckpt, random_init_model
 
-    targets = []
+    targets, coords_of = [], {}
     if args.synthetic_len:
         g = torch.Generator().manual_seed(args.seed)
         ids = torch.randint(4, 24, (args.synthetic_len,), generator=g)
@@ -208,25 +220,29 @@ def main(argv=None):
         data_path = Path(args.input)
         assert data_path.is_dir(), f"Invalid directory {data_path} (Currently we only support pdb files in a folder as input)."
         for p in sorted(q for q in data_path.iterdir() if q.suffix == ".pdb"):
-            targets.append((p.stem, ESMProtein.from_pdb(p).sequence))      # throw away other entities
+            prot = ESMProtein.from_pdb(p)
+            targets.append((p.stem, prot.sequence))                        # throw away other entities
+            coords_of[p.stem] = prot.coordinates
     max_len = max(len(s) for _, s in targets) + 2
     per_rank = -(-args.num_samples // world)
     max_b = max(1, min(per_rank, args.n_max_residue_square // (max_len * max_len)))
     if args.random_init:
-        model = random_init_model(seed=args.seed, max_batch=max_b, max_len=max_len, device=local_rank)
+        from .config import ESM3_OPEN, TINY
+        model = random_init_model(TINY if args.tiny else ESM3_OPEN, seed=args.seed, max_batch=max_b, max_len=max_len,
+                                  device=local_rank)
     else:
         model = load_state_dict_from_lightning_ckpt(args.ckpt, device=f"cuda:{local_rank}", max_batch=max_b,
                                                     max_len=max_len)
     if rank == 0:
         print(f">>> Sampling mode = {args.mode} ...")
-    mask_ids = [int(i) for i in args.mask_ids.split(",")] if args.mask_ids else None
-    if mask_ids is not None:
-        raise SystemExit("--mask_ids needs structure tokens of the known residues, i.e. the VQ-VAE encoder "
-                         "(SURVEY.md 8f-4); call ddpm_sample_by_esm(structure_tokens=...) from Python instead")
     for name, seq in targets:
         if args.mode == "gibbs":
+            coordinates = coords_of.get(name) if mask_ids is not None else None   # sample_esmdiff.py:286-289
+            if mask_ids is not None and coordinates is None:
+                raise SystemExit("--mask_ids needs the coordinates of an input PDB")
             minibatch_gibbs_by_esm(seq, model, Path(args.output), name, num_samples=args.num_samples,
                                    num_steps=args.num_steps, n_max_residue_square=args.n_max_residue_square,
+                                   coordinates=coordinates, mask_ids=mask_ids,
                                    seed=args.seed, timestamp=not args.no_timestamp)
         else:
             ddpm_sample_by_esm(seq, model, Path(args.output), name, num_samples=args.num_samples,

@@ -16,7 +16,7 @@ from .config import ModelConfig
 
 
 def random_init_state_dict(cfg: ModelConfig, seed: int = 0, prefix: str = "net.",
-                           device: str = "cpu") -> Dict[str, torch.Tensor]:
+                           device: str = "cpu", with_geom: bool = False) -> Dict[str, torch.Tensor]:
     """ESM3-architecture random weights (PyTorch default initialisers per layer type), float32.
 
     `device` selects where the numbers are drawn (the CPU and GPU generators give different streams; tests
@@ -69,6 +69,13 @@ def random_init_state_dict(cfg: ModelConfig, seed: int = 0, prefix: str = "net."
     s = "sigma_embedder.mlp."
     sd[s + "0.weight"], sd[s + "0.bias"] = _linear(g, D, cfg.freq_dim, True)
     sd[s + "2.weight"], sd[s + "2.bias"] = _linear(g, D, D, True)
+    if with_geom:   # block 0's geometric attention; drawn last so that the other tensors keep their stream
+        ga, VH = f"{prefix}transformer.blocks.0.geom_attn.", cfg.v_heads
+        sd[ga + "s_norm.weight"] = 1.0 + 0.1 * _R.randn(D)
+        sd[ga + "proj.weight"] = _linear(g, VH * 15, D, False)[0]
+        sd[ga + "out_proj.weight"] = _linear(g, D, VH * 3, False)[0]
+        sd[ga + "distance_scale_per_head"] = 0.5 * _R.randn(VH)
+        sd[ga + "rotation_scale_per_head"] = 0.5 * _R.randn(VH)
     return sd
 
 

@@ -174,6 +174,18 @@ int esmdiff_layernorm_bf16(const float* x, const float* w, const float* b, void*
 int esmdiff_attention_bf16(esmdiff_engine* eng, const void* qkv, const float* q_ln_w, const float* k_ln_w,
                            void* ctx, int32_t B, int32_t L, void* stream);
 
+/* Coordinate conditioning (block 0's geometric attention).  Replaces what the reference does inside
+ * CustomizedESM3.forward when structure_coords is given (/root/reference/slm/models/net.py:433-441, :468):
+ * the caller passes the per-residue backbone frames that esm's build_affine3d_from_coordinates derives from the
+ * N/CA/C coordinates (esmdiff_amd/geometry.py computes them on the host), and every following forward of this engine
+ * with the same (B, L) adds the geometric-attention branch of block 0.  rot: f32 [B,L,3,3] row-major rotation matrices,
+ * trans: f32 [B,L,3], has_frame: u8 [B,L] (0 = no coordinates for that residue) — device pointers, copied on `stream`.
+ * rot == NULL clears the frames (the branch is then exactly zero, as in the reference with all-NaN coordinates, and is
+ * skipped).  Needs the transformer.blocks.0.geom_attn.* weights in the table given to esmdiff_engine_create
+ * (ESMDIFF_E_MISSING otherwise). */
+int esmdiff_set_frames(esmdiff_engine* eng, const float* rot, const float* trans, const uint8_t* has_frame,
+                       int32_t B, int32_t L, void* stream);
+
 /* Accumulated per-section device time of the esmdiff_forward_logits/ddpm_sample calls since profiling was
  * enabled: esmdiff_set_profiling(eng, 1) brackets every launch with HIP events on the launch stream (no sync);
  * mode 2 brackets only the dominant kernel (FFN-up GEMM, section 6), cheap enough for a timed region; 0 = off. sections: 0 embed, 1 layernorm, 2 gemm_qkv,

@@ -107,29 +107,35 @@ class BlockRef(nn.Module):
     """Appendix A.2: pre-LN, residuals divided by sqrt(n_layers/36); geometric attention (block 0) is
     exactly zero without coordinates (net.py:433-441 + mask_and_zero_frameless) and is omitted."""
 
-    def __init__(self, d_model, n_heads, ffn_hidden, scale):
+    def __init__(self, d_model, n_heads, ffn_hidden, scale, v_heads=0):
         super().__init__()
         self.attn = MultiHeadAttentionRef(d_model, n_heads)
+        if v_heads:                                   # block 0 only (Appendix A.2: use_geom_attn = (i == 0))
+            from .geom_ref import GeometricAttentionRef
+            self.geom_attn = GeometricAttentionRef(d_model, v_heads)
         self.ffn = nn.Sequential(nn.LayerNorm(d_model), nn.Linear(d_model, 2 * ffn_hidden, bias=False), SwiGLU(),
                                  nn.Linear(ffn_hidden, d_model, bias=False))
         self.scale = scale
 
-    def forward(self, x):
+    def forward(self, x, frames=None):
         x = x + self.attn(x) / self.scale
+        if frames is not None and hasattr(self, "geom_attn"):
+            x = x + self.geom_attn(x, *frames) / self.scale
         x = x + self.ffn(x) / self.scale
         return x
 
 
 class TransformerRef(nn.Module):
-    def __init__(self, d_model, n_heads, n_layers, ffn_hidden):
+    def __init__(self, d_model, n_heads, n_layers, ffn_hidden, v_heads=0):
         super().__init__()
         scale = math.sqrt(n_layers / 36)
-        self.blocks = nn.ModuleList([BlockRef(d_model, n_heads, ffn_hidden, scale) for _ in range(n_layers)])
+        self.blocks = nn.ModuleList([BlockRef(d_model, n_heads, ffn_hidden, scale, v_heads if i == 0 else 0)
+                                     for i in range(n_layers)])
         self.norm = nn.LayerNorm(d_model, bias=False)
 
-    def forward(self, x):
+    def forward(self, x, frames=None):
         for b in self.blocks:
-            x = b(x)
+            x = b(x, frames)
         return self.norm(x), x
 
 
@@ -143,11 +149,12 @@ class OutputHeadsRef(nn.Module):
 
 
 class ESM3Ref(nn.Module):
-    def __init__(self, cfg):
+    def __init__(self, cfg, with_geom=False):
         super().__init__()
         self.cfg = cfg
         self.encoder = EncodeInputsRef(cfg.d_model)
-        self.transformer = TransformerRef(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden)
+        self.transformer = TransformerRef(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden,
+                                          cfg.v_heads if with_geom else 0)
         self.output_heads = OutputHeadsRef(cfg.d_model, cfg.n_structure_heads)
 
     def embed(self, structure_tokens, sequence_tokens, auxiliary_embeddings=None):
@@ -169,9 +176,14 @@ class ESM3Ref(nn.Module):
             x = x + auxiliary_embeddings
         return x
 
-    def forward(self, structure_tokens=None, sequence_tokens=None, auxiliary_embeddings=None, labels=None, **kw):
+    def forward(self, structure_tokens=None, sequence_tokens=None, auxiliary_embeddings=None, labels=None,
+                structure_coords=None, **kw):
         x = self.embed(structure_tokens, sequence_tokens, auxiliary_embeddings)
-        x, emb = self.transformer(x)
+        frames = None
+        if structure_coords is not None:              # net.py:433-441; all-NaN coordinates give an exactly zero branch
+            from .geom_ref import build_affine3d_from_coordinates
+            frames = build_affine3d_from_coordinates(structure_coords)
+        x, emb = self.transformer(x, frames)
         return SimpleNamespace(structure_logits=self.output_heads.structure_head(x), embeddings=emb)
 
 
@@ -179,8 +191,8 @@ def build_from_state_dict(cfg, state_dict, prefix="net."):
     """(net, sigma_embedder) loaded strictly from a reference-layout state dict."""
     from .sampler_ref import TimestepEmbedderRef
 
-    net = ESM3Ref(cfg)
     sub = {k[len(prefix):]: v.float() for k, v in state_dict.items() if k.startswith(prefix)}
+    net = ESM3Ref(cfg, with_geom=any("geom_attn" in k for k in sub))
     missing, unexpected = net.load_state_dict(sub, strict=False)
     assert not missing, missing
     unexpected = [k for k in unexpected if "geom_attn" not in k and "function_embed" not in k

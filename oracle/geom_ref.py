@@ -1,0 +1,103 @@
+"""TEST INFRASTRUCTURE — torch restatement of the coordinate conditioning of ESM3 block 0.
+
+What the reference's hot path reaches here (in-tree call sites):
+  /root/reference/slm/models/net.py:433-441   structure_coords[..., :3, :] -> build_affine3d_from_coordinates
+  /root/reference/slm/models/net.py:468       transformer(x, sequence_id, affine, affine_mask, chain_id)
+  /root/reference/slm/models/net.py:339-346   TransformerStack(d_model, n_heads, v_heads=256, n_layers,
+                                              mask_and_zero_frameless=True): block 0 carries geom_attn
+  /root/reference/slm/sample_esmdiff.py:88-96 inpainting: masked residues get coordinates = Inf and sequence '_'
+
+The arithmetic lives in the un-vendored dependency esm==3.0.4 (requirements.txt:30):
+esm.utils.structure.affine3d.build_affine3d_from_coordinates / Affine3D.from_graham_schmidt and
+esm.layers.geom_attention.GeometricReasoningOriginalImpl.  [ESM-RECALL] Restated from memory;
+PARITY UNPINNED — no esm code, test or vector exists in this container.  What CAN be checked here is internal
+consistency: the block is invariant under a global rigid motion of the input coordinates, frameless residues
+contribute nothing and receive nothing (tests/test_geom_cpu.py).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+MAX_SUPPORTED_DISTANCE = 1e6
+
+
+def graham_schmidt(x_axis: torch.Tensor, xy_plane: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    """Rotation matrices whose COLUMNS are (e0, e1, e2): e0 along x_axis, e1 in the (x_axis, xy_plane) plane."""
+    e1 = xy_plane
+    x_axis = x_axis / torch.sqrt((x_axis ** 2).sum(-1, keepdim=True) + eps)
+    e1 = e1 - x_axis * (x_axis * e1).sum(-1, keepdim=True)
+    e1 = e1 / torch.sqrt((e1 ** 2).sum(-1, keepdim=True) + eps)
+    e2 = torch.cross(x_axis, e1, dim=-1)
+    return torch.stack([x_axis, e1, e2], dim=-1)
+
+
+def frames_from_backbone(n: torch.Tensor, ca: torch.Tensor, c: torch.Tensor):
+    """Affine3D.from_graham_schmidt(neg_x_axis=C, origin=CA, xy_plane=N): x = CA - C, plane vector N - CA."""
+    return graham_schmidt(ca - c, n - ca), ca
+
+
+def build_affine3d_from_coordinates(coords: torch.Tensor):
+    """coords (B, L, 3, 3) = N, CA, C per residue (NaN/Inf where unknown) -> (rot (B,L,3,3), trans (B,L,3), mask (B,L)).
+
+    Residues without finite coordinates get the 'black hole' frame: the frame of the average N/CA/C of the known
+    residues (identity rotation when nothing is known)."""
+    coords = coords[..., :3, :]
+    mask = (torch.isfinite(coords) & (coords < MAX_SUPPORTED_DISTANCE)).all(-1).all(-1)
+    coords = coords.clone().float()
+    coords[~mask] = 0
+    avg = coords.sum(1) / (mask.sum(-1)[..., None, None] + 1e-8)                     # (B, 3, 3)
+    rot_avg, trans_avg = frames_from_backbone(avg[..., 0, :], avg[..., 1, :], avg[..., 2, :])
+    B, L = mask.shape
+    rot_bh = rot_avg[:, None].expand(B, L, 3, 3)
+    rot_bh = torch.where(mask.any(-1)[:, None, None, None], rot_bh, torch.eye(3).expand(B, L, 3, 3))
+    trans_bh = trans_avg[:, None].expand(B, L, 3)
+    rot, trans = frames_from_backbone(coords[..., 0, :], coords[..., 1, :], coords[..., 2, :])
+    rot = torch.where(mask[..., None, None], rot, rot_bh)
+    trans = torch.where(mask[..., None], trans, trans_bh)
+    return rot, trans, mask
+
+
+class GeometricAttentionRef(nn.Module):
+    """GeometricReasoningOriginalImpl(c_s, v_heads, bias=False, mask_and_zero_frameless=True)."""
+
+    def __init__(self, c_s: int, v_heads: int):
+        super().__init__()
+        self.c_s, self.v_heads = c_s, v_heads
+        self.s_norm = nn.LayerNorm(c_s, bias=False)
+        self.proj = nn.Linear(c_s, v_heads * 3 * 5, bias=False)     # [q_rot | k_rot | value | q_dist | k_dist] x (h, 3)
+        self.out_proj = nn.Linear(v_heads * 3, c_s, bias=False)
+        self.distance_scale_per_head = nn.Parameter(torch.zeros(v_heads))
+        self.rotation_scale_per_head = nn.Parameter(torch.zeros(v_heads))
+
+    def forward(self, s, rot, trans, mask, return_parts: bool = False):
+        B, L, _ = s.shape
+        H = self.v_heads
+        p = self.proj(self.s_norm(s))
+        vec_rot, vec_dist = p.split([H * 3 * 3, H * 2 * 3], dim=-1)
+        vec_rot = vec_rot.reshape(B, L, 3 * H, 3)
+        vec_dist = vec_dist.reshape(B, L, 2 * H, 3)
+        R = rot[:, :, None]                                           # (B, L, 1, 3, 3)
+        rotated = torch.einsum("blhij,blhj->blhi", R.expand(B, L, 3 * H, 3, 3), vec_rot)
+        q_rot, k_rot, value = rotated.split([H, H, H], dim=2)
+        moved = torch.einsum("blhij,blhj->blhi", R.expand(B, L, 2 * H, 3, 3), vec_dist) + trans[:, :, None]
+        q_dist, k_dist = moved.chunk(2, dim=2)
+        q_rot, k_rot, value = (t.permute(0, 2, 1, 3) for t in (q_rot, k_rot, value))   # (B, H, L, 3)
+        q_dist, k_dist = (t.permute(0, 2, 1, 3) for t in (q_dist, k_dist))
+        rotation_term = q_rot @ k_rot.transpose(-1, -2) / math.sqrt(3)
+        distance_term = (q_dist[:, :, :, None] - k_dist[:, :, None]).norm(dim=-1) / math.sqrt(3)
+        w_rot = F.softplus(self.rotation_scale_per_head)[None, :, None, None]
+        w_dist = F.softplus(self.distance_scale_per_head)[None, :, None, None]
+        logits = rotation_term * w_rot - distance_term * w_dist
+        logits = logits.masked_fill(~mask[:, None, None, :], torch.finfo(logits.dtype).min)   # keys without a frame
+        attn = torch.softmax(logits, dim=-1)
+        out = attn @ value                                            # (B, H, L, 3), global frame
+        out = out.permute(0, 2, 1, 3)                                 # (B, L, H, 3)
+        out = torch.einsum("blhji,blhj->blhi", R.expand(B, L, H, 3, 3), out)   # R^T: back to the local frame
+        out = out.reshape(B, L, H * 3)
+        out = out.masked_fill(~mask[..., None], 0.0)                  # mask_and_zero_frameless
+        y = self.out_proj(out)
+        return (y, p, out) if return_parts else y

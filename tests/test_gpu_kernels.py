@@ -305,6 +305,59 @@ def test_forward_logits_vs_oracle(tiny, B, L):
     assert float((got.argmax(-1) == ref.argmax(-1)).float().mean()) > 0.9
 
 
+def test_forward_with_coordinates_vs_oracle(monkeypatch):
+    """Block 0's geometric attention (esmdiff_set_frames + geom.hip) against oracle/geom_ref.py inside the whole
+    network: partly unknown coordinates (Inf = the inpainting marker, NaN at BOS/EOS), odd L, and the two-stream split.
+    All-unknown coordinates must reproduce the unconditioned forward bit for bit (net.py:433-441)."""
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.geometry import build_affine3d_from_coordinates
+    from esmdiff_amd.weights import random_init_state_dict
+    from oracle.esm3_ref import build_from_state_dict
+    sd = random_init_state_dict(TINY, seed=3, with_geom=True)
+    net, _ = build_from_state_dict(TINY, sd)
+    B, L = 3, 71
+    g = torch.Generator().manual_seed(11)
+    ca = torch.cumsum(torch.randn(B, L, 3, generator=g) * 2.2, 1)
+    xyz = torch.stack([ca + torch.randn(B, L, 3, generator=g) * 0.8, ca, ca + torch.randn(B, L, 3, generator=g) * 0.8], 2)
+    xyz[:, 0] = float("nan")
+    xyz[:, -1] = float("nan")
+    xyz[:, 20:33] = float("inf")
+    xyz[1, 40:] = float("inf")
+    seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1)
+    x = torch.full((B, L), MASK, dtype=torch.int64)
+    x[:, 5:15] = torch.randint(0, 4096, (B, 10), generator=g)
+    with torch.no_grad():
+        ref = net(structure_tokens=x, sequence_tokens=seq, structure_coords=xyz).structure_logits
+        ref0 = net(structure_tokens=x, sequence_tokens=seq).structure_logits
+    assert float((ref - ref0).abs().max()) > 5e-2
+    for streams in ("1", "2"):
+        monkeypatch.setenv("ESMDIFF_DUAL_STREAM", streams)
+        monkeypatch.setenv("ESMDIFF_DUAL_STREAM_MIN_TOKENS", "1")
+        eng = Engine(TINY, sd, max_batch=B, max_len=L)
+        base = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu().clone()
+        eng.set_frames(*build_affine3d_from_coordinates(xyz))
+        got = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu().clone()
+        eng.set_frames(*build_affine3d_from_coordinates(torch.full((B, L, 3, 3), float("nan"))))
+        nan = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu().clone()
+        eng.set_frames(None)
+        off = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu().clone()
+        with pytest.raises(RuntimeError):                      # frames for another shape
+            eng.set_frames(*build_affine3d_from_coordinates(xyz[:2]))
+            eng.forward_logits(x.cuda(), seq.cuda(), None)
+        eng.close()
+        err = (got - ref).abs()
+        # same bar as the unconditioned forward: bf16 GEMM operands through 2 blocks + head
+        assert float(err.max()) < 0.12 and float(err.mean()) < 1.2e-2, (streams, float(err.max()), float(err.mean()))
+        assert float((got - base).abs().max()) > 5e-2          # the branch is live
+        assert torch.equal(nan, base) and torch.equal(off, base)
+    # weights without geom_attn: coordinates are refused, loudly
+    eng = Engine(TINY, random_init_state_dict(TINY, seed=3), max_batch=B, max_len=L)
+    with pytest.raises(RuntimeError, match="geom_attn"):
+        eng.set_frames(*build_affine3d_from_coordinates(xyz))
+    eng.close()
+
+
 def test_two_stream_forward_is_bitwise_identical(tiny, monkeypatch):
     """The engine runs the two halves of a large batch on two HIP streams (engine.hip::forward).  Samples are
     independent and every kernel's per-row arithmetic does not depend on the tiling, so logits and sampled ids must
@@ -552,6 +605,32 @@ def test_cli_gibbs_default_mode(tmp_path):
           "--no_timestamp", "--seed", "2"])                                # --mode defaults to gibbs, as in the reference
     ids = np.load(tmp_path / "T1.4_step8_topp0.9_N3" / "synthetic40.tokens.npy")
     assert ids.shape == (3, 40) and ids.min() >= 0 and ids.max() < 4096
+
+
+def test_cli_gibbs_inpainting_from_pdb(tmp_path):
+    """`--mask_ids` in the default mode, as the reference runs it (sample_esmdiff.py:282-300, :88-96): the input PDB's
+    backbone conditions the model (geometric attention), the masked residues lose sequence and coordinates, every
+    structure token is sampled.  The conditioning must matter: other coordinates, other samples, same seed."""
+    from esmdiff_amd.pdbio import write_backbone_pdb
+    from esmdiff_amd.sample_esmdiff import main
+    seq = "RPDFCLEPPYTGPCKARIIRYFYNAKAGLCQTFVYGGCRA"
+    g = np.random.default_rng(0)
+    outs = []
+    for k in range(2):
+        ca = np.cumsum(g.normal(size=(len(seq), 3)) * 2.2, 0)
+        xyz = np.stack([ca + g.normal(size=ca.shape) * 0.8, ca, ca + g.normal(size=ca.shape) * 0.8], 1)
+        d = tmp_path / f"in{k}"
+        d.mkdir()
+        write_backbone_pdb(d / "toy.pdb", seq, xyz)
+        main(["--random_init", "--input", str(d), "--num_samples", "3", "--num_steps", "6", "--mask_ids", "10,11,12,13",
+              "--output", str(tmp_path / f"out{k}"), "--no_timestamp", "--seed", "4", "--tiny"])
+        ids = np.load(tmp_path / f"out{k}" / "T1.4_step6_topp0.9_N3" / "toy.tokens.npy")
+        assert ids.shape == (3, len(seq)) and ids.min() >= 0 and ids.max() < 4096
+        outs.append(ids)
+    assert (outs[0] != outs[1]).mean() > 0.3
+    with pytest.raises(SystemExit, match="ddpm"):
+        main(["--random_init", "--input", str(tmp_path / "in0"), "--mode", "ddpm", "--mask_ids", "1,2", "--output",
+              str(tmp_path / "o"), "--tiny"])
 
 
 # ---------------------------------------------------------------------------------------------------
