@@ -128,7 +128,7 @@ def main():
 
     cfg = TINY if args.tiny else ESM3_OPEN
     B, L, T = args.samples_per_gpu, args.residues + 2, args.num_steps
-    sd = random_init_state_dict(cfg, seed=args.seed, device=str(dev))   # same weights on every rank (GPU generator)
+    sd = random_init_state_dict(cfg, seed=args.seed, device=str(dev), with_geom=True)   # same weights on every rank (GPU generator)
     eng = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank)
     g = torch.Generator().manual_seed(args.seed)
     seq1 = torch.cat([torch.tensor([0]), torch.randint(4, 24, (args.residues,), generator=g), torch.tensor([2])])
@@ -149,6 +149,14 @@ def main():
         x0[:, 0], x0[:, -1] = 4098, 4097                          # structure BOS / EOS
         table = torch.tensor(unmask_schedule(L - 2, T), dtype=torch.int32)[:, None].repeat(1, B)
         x0 = x0.to(dev)
+        if args.inpaint:   # the CLI's inpainting (sample_esmdiff.py:88-96): known backbone conditions through block 0's
+            from esmdiff_amd.geometry import build_affine3d_from_coordinates   # geometric attention, masked residues = Inf
+            a, b = (int(v) for v in args.inpaint.split(":"))
+            ca = torch.cumsum(torch.randn(L, 3, generator=g) * 2.2, 0)
+            xyz = torch.stack([ca + torch.randn(L, 3, generator=g) * 0.8, ca, ca + torch.randn(L, 3, generator=g) * 0.8], 1)
+            xyz[0], xyz[-1], xyz[a:b] = float("nan"), float("nan"), float("inf")
+            eng.set_frames(*build_affine3d_from_coordinates(xyz[None].repeat(B, 1, 1, 1)))
+            prior = None
 
     def one_step(step_idx):
         if args.mode == "gibbs":
