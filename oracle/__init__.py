@@ -19,4 +19,10 @@ Parts
                    installable here; it is restated from the published architecture (SURVEY.md
                    Appendix A) and anchored only on the reference's call sites and in-tree
                    hyper-parameters (net.py:325-346, mdlm.yaml:26-58).
+  gibbs_ref.py     torch restatement of the per-prompt half of esm's iterative_sampling_raw (SURVEY.md
+                   Appendix B).  PARITY UNPINNED for the same reason.
+  geom_ref.py      torch restatement of esm's build_affine3d_from_coordinates and of block 0's
+                   GeometricReasoningOriginalImpl (call sites net.py:433-441, :468).
+                   PARITY UNPINNED; checked for what must hold regardless (rigid-motion invariance, exact
+                   zero branch without coordinates, frameless residues inert: tests/test_geom_cpu.py).
 """
