@@ -33,7 +33,9 @@ __global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __rest
   const int ldp = 15 * VH;
   const int64_t row0 = (int64_t)b * L;
   const float c = 0.57735026918962576f;  // 1/sqrt(3)
-  const float wr = w_rot[h] * c, wd = w_dist[h] * c;
+  const float LOG2E = 1.44269504088896341f;  // softmax in base 2 (v_exp_f32 is exp2)
+  const float wr = w_rot[h] * c * LOG2E, wd = w_dist[h] * c * LOG2E;
+  const int Lk = (L + 3) & ~3;               // key count padded to the 4-key trip; pad keys carry has-frame = 0
 
   auto load3 = [&](int64_t row, int col, float* v) {
     const bf16_t* p = P + row * ldp + col;
@@ -63,6 +65,11 @@ __global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __rest
     k[6] = o[0]; k[7] = o[1]; k[8] = o[2];
     k[9] = fmask[row] ? 1.0f : 0.0f;
   }
+  for (int l = L + lane; l < Lk; l += 64) {
+    float* k = kl + l * 10;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) k[i] = 0.0f;
+  }
   __syncthreads();
 
   for (int q = lane; q < L; q += 64) {
@@ -79,19 +86,30 @@ __global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __rest
     qd[0] += t[0]; qd[1] += t[1]; qd[2] += t[2];
     float m = -3.0e38f, den = 0.f, o0 = 0.f, o1 = 0.f, o2 = 0.f;
     if (fmask[row]) {  // rows without a frame are zeroed below; skip their walk
-      for (int k = 0; k < L; ++k) {
-        const float* kk = kl + k * 10;
-        if (kk[9] == 0.0f) continue;  // wave-uniform: every lane looks at the same key
-        const float dx = qd[0] - kk[3], dy = qd[1] - kk[4], dz = qd[2] - kk[5];
-        const float s = wr * (qr[0] * kk[0] + qr[1] * kk[1] + qr[2] * kk[2]) - wd * sqrtf(dx * dx + dy * dy + dz * dz);
-        if (s > m) {  // lazy rescale: rare after the first few keys
-          const float a = __expf(m - s);
-          den *= a; o0 *= a; o1 *= a; o2 *= a;
-          m = s;
+      // four keys per trip: their LDS reads and score arithmetic are independent (the single-key loop exposed one LDS
+      // latency per key), the running maximum moves at most once per trip, keys without a frame score -inf
+      for (int k = 0; k < Lk; k += 4) {
+        float sc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* kk = kl + (k + u) * 10;
+          const float dx = qd[0] - kk[3], dy = qd[1] - kk[4], dz = qd[2] - kk[5];
+          const float v = wr * (qr[0] * kk[0] + qr[1] * kk[1] + qr[2] * kk[2]) - wd * sqrtf(dx * dx + dy * dy + dz * dz);
+          sc[u] = kk[9] != 0.0f ? v : -__builtin_inff();
         }
-        const float p = __expf(s - m);
-        den += p;
-        o0 += p * kk[6]; o1 += p * kk[7]; o2 += p * kk[8];
+        const float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
+        if (mx > m) {  // lazy rescale: rare after the first few trips
+          const float a = __builtin_amdgcn_exp2f(m - mx);
+          den *= a; o0 *= a; o1 *= a; o2 *= a;
+          m = mx;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float* kk = kl + (k + u) * 10;
+          const float p = __builtin_amdgcn_exp2f(sc[u] - m);  // bare v_exp_f32; exp2(-inf) = 0 for keys without a frame
+          den += p;
+          o0 += p * kk[6]; o1 += p * kk[7]; o2 += p * kk[8];
+        }
       }
     }
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;
@@ -115,7 +133,7 @@ hipError_t launch_geom_attention(const bf16_t* P, const float* rot, const float*
                                  const float* w_rot, const float* w_dist, bf16_t* out, int B, int L, int VH,
                                  hipStream_t stream) {
   if (B <= 0 || L <= 0) return hipSuccess;
-  const size_t lds = (size_t)L * 10 * sizeof(float);
+  const size_t lds = (size_t)((L + 3) & ~3) * 10 * sizeof(float);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
   static bool attr_done = false;
   if (!attr_done) {
