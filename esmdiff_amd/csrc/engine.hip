@@ -652,6 +652,15 @@ int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias
   return 0;
 }
 
+int esmdiff_gemm_bf16_ws(esmdiff_engine* e, const void* A, const void* W, void* out, const float* bias, int32_t M,
+                         int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream) {
+  if (!e || !A || !W || !out) return ESMDIFF_E_INVALID;
+  hipError_t s = launch_gemm_bf16((const bf16_t*)A, (const bf16_t*)W, out, bias, M, N, K, ldc, n_valid, alpha, epilogue,
+                                  (hipStream_t)stream, e->gemm_ws[0].partial ? &e->gemm_ws[0] : nullptr);
+  if (s != hipSuccess) return fail(e, s == hipErrorInvalidValue ? ESMDIFF_E_INVALID : ESMDIFF_E_HIP, "gemm: %s", hipGetErrorString(s));
+  return 0;
+}
+
 int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N,
                             int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, int32_t iters,
                             float* ms_out, void* stream) {

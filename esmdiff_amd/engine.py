@@ -203,6 +203,17 @@ class Engine:
         self._chk(self._lib.esmdiff_set_frames(self._h, _ptr(r), _ptr(t), _ptr(m), B, L, _stream()))
         self._frames = (r, t, m)   # keep the staging tensors alive until the async copies have run
 
+    def gemm(self, A: torch.Tensor, W: torch.Tensor, epilogue: int, *, bias: Optional[torch.Tensor] = None,
+             alpha: float = 1.0) -> torch.Tensor:
+        """bf16-output GEMM exactly as the forward issues it (esmdiff_gemm_bf16_ws: split-K workspace attached)."""
+        M, K = A.shape
+        Nn = W.shape[0]
+        assert A.dtype == W.dtype == torch.bfloat16 and A.is_contiguous() and W.is_contiguous() and W.shape[1] == K
+        out = torch.empty(M, Nn // 2 if epilogue == N.EPI_SWIGLU_BF16 else Nn, dtype=torch.bfloat16, device=A.device)
+        self._chk(self._lib.esmdiff_gemm_bf16_ws(self._h, _ptr(A), _ptr(W), _ptr(out), _ptr(bias), M, Nn, K, out.stride(0),
+                                                 Nn, float(alpha), epilogue, _stream()))
+        return out
+
     # ---- per-kernel entry points (parity tests / roofline bench) ---------------------------------
     def set_profiling(self, mode):
         """0/False off; 1/True HIP events around every launch; 2 only around the dominant kernel (FFN-up GEMM)."""

@@ -159,6 +159,12 @@ typedef enum {
 int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N,
                       int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream);
 
+/* The same GEMM as the engine issues it: with the engine's split-K workspace, so the small-M path (M < 1024 rows,
+ * K >= 2048: FFN-down) runs as K slices + a fixed-order reduce kernel (csrc/gemm.hip).  Not re-entrant per engine. */
+int esmdiff_gemm_bf16_ws(esmdiff_engine* eng, const void* A, const void* W, void* out, const float* bias, int32_t M,
+                         int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue,
+                         void* stream);
+
 /* Wall-clock helper for the bench's roofline leg: runs the GEMM `iters` times on `stream` bracketed by
  * HIP events on that stream and returns the average milliseconds per launch in *ms_out [host]. */
 int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float* bias, int32_t M,

@@ -171,6 +171,31 @@ def test_gemm256_persistent_multi_tile(M, N, K, epi):
             assert float((err - ref.abs() * 2 ** -7).max()) < 1e-2, float(err.max())
 
 
+@pytest.mark.parametrize("M,N,K", [(240, 1536, 4096), (120, 1536, 4096), (774, 1536, 2048), (240, 512, 4096)])
+def test_gemm_small_m_split_k(tiny, monkeypatch, M, N, K):
+    """The small-M path as the engine runs it (FFN-down at a handful of short sequences): four-stage ring + K slices
+    + the fixed-order reduce kernel, against f32 torch and against the unsplit kernel (same bf16 result up to the f32
+    re-association of the slices), twice in a row (the workspace is reused)."""
+    from esmdiff_amd import _native as Nn
+    from esmdiff_amd.engine import gemm_bf16
+    _, _, eng, _, _ = tiny
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    A = _bf(torch.randn(M, K, generator=g, device="cuda"))
+    W = _bf(torch.randn(N, K, generator=g, device="cuda") / K ** 0.5)
+    ref = A.float() @ W.float().t()
+    plain = gemm_bf16(A, W, Nn.EPI_BF16, alpha=0.866).float()
+    for _ in range(2):
+        out = eng.gemm(A, W, Nn.EPI_BF16, alpha=0.866).float()
+        err = (out - ref * 0.866).abs()
+        assert float((err - ref.abs() * 0.866 * 2 ** -8).max()) < 2e-3, float(err.max())
+        assert float((out - plain).abs().max()) <= float(ref.abs().max()) * 2 ** -7   # at most one bf16 ulp apart
+        assert float((out != plain).float().mean()) < 0.05
+    bias = torch.randn(N, generator=g, device="cuda")
+    got = eng.gemm(A, W, Nn.EPI_BIAS_GELU_BF16, bias=bias).float()
+    want = torch.nn.functional.gelu(ref + bias)
+    assert float((got - want).abs().max()) < 3e-2 and float((got - want).abs().mean()) < 2e-3
+
+
 def test_gemm_asymmetric_identity():
     """A = I picks rows of W^T: catches transposed / permuted C layouts (asymmetric B)."""
     from esmdiff_amd import _native as Nn
