@@ -74,7 +74,7 @@ struct esmdiff_engine {
   std::vector<hipStream_t> side;
   std::vector<hipEvent_t> ev_join;
   hipEvent_t ev_fork = nullptr;
-  int64_t dual_min_tokens = 12288;
+  int64_t dual_min_tokens = 12288, dual_small_max_tokens = 6400;
   ed::GemmWorkspace gemm_ws[4] = {};  // split-K partials of the small-M GEMM path, one per launch queue
   // profiling
   int profiling = 0;  // 0 off, 1 every launch, 2 only the dominant kernel (FFN-up GEMM)
@@ -241,6 +241,12 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
 // persistent one-workgroup-per-CU kernel whose last round leaves CUs idle (N=1536: 606 tiles on 256 CUs = 2.37
 // rounds); with two independent launch queues the hardware scheduler fills those tails and the gaps around the
 // small LayerNorm / rotary / attention kernels with the other sub-batch's work (measured: -4.4 % per forward).
+// When: batches of >= 12 288 tokens (both halves still run the 256x256 GEMM) and small batches of <= 6 400 tokens
+// (1 024 .. 6 400: everything is on the 128x128 path either way and the kernels are latency-bound, so two queues simply
+// overlap them; below ~1 000 tokens it is a wash: B = 4, L_tok = 60 32.4 / 32.0).
+// In between the halves would fall below the 128-tile switch of the GEMM dispatch and lose more than the overlap gives
+// (samples/s at L_tok = 258, one stream / two: B = 8 29.4 / 31.7, 16 36.9 / 39.7, 24 43.1 / 44.1, 32 45.8 / 45.8,
+// 40 49.7 / 46.8, 48 47.4 / 51.9, 64 49.2 / 52.2, 100 50.7 / 53.0).
 int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const float* t_freq_dev, float* logits,
             int ld, int B, int L, hipStream_t st) {
   const esmdiff_config& c = e->cfg;
@@ -263,7 +269,9 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   // profiling == 1 (per-section breakdown) keeps one stream so that the sections do not overlap
   Part parts[4];
   int np = 1;
-  if (!e->side.empty() && e->profiling != 1 && (int64_t)B * L >= e->dual_min_tokens)
+  const int64_t tokens = (int64_t)B * L;
+  if (!e->side.empty() && e->profiling != 1 && B >= 2 &&
+      (tokens >= e->dual_min_tokens || (tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(1024, e->dual_min_tokens))))
     np = std::min<int>({(int)e->side.size() + 1, B, 4});
   for (int pi = 0; pi < np; ++pi) {
     const int b0 = (int)((int64_t)B * pi / np), b1 = (int)((int64_t)B * (pi + 1) / np);
@@ -555,6 +563,7 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
       e->ev_join.push_back(ev);
     }
     if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_MIN_TOKENS")) e->dual_min_tokens = atoll(mt);
+    if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_SMALL_MAX_TOKENS")) e->dual_small_max_tokens = atoll(mt);
   }
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "engine create: %s", hipGetErrorString(hipGetLastError())));
   *out = e;
