@@ -38,7 +38,8 @@ EXPORTS = [
     "esmdiff_forward_logits", "esmdiff_ddpm_step", "esmdiff_ddpm_sample", "esmdiff_gibbs_step",
     "esmdiff_gibbs_sample", "esmdiff_gemm_bf16",
     "esmdiff_gemm_bf16_timed", "esmdiff_layernorm_bf16", "esmdiff_attention_bf16", "esmdiff_set_profiling",
-    "esmdiff_get_profile", "esmdiff_set_frames", "esmdiff_gemm_bf16_ws",
+    "esmdiff_get_profile", "esmdiff_set_frames", "esmdiff_gemm_bf16_ws", "esmdiff_decoder_create",
+    "esmdiff_decoder_decode",
 ]
 
 
@@ -76,6 +77,8 @@ def lib():
     L.esmdiff_set_profiling.argtypes = [vp, i32]
     L.esmdiff_get_profile.argtypes = [vp, c_f32p, ctypes.POINTER(i32)]
     L.esmdiff_set_frames.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    L.esmdiff_decoder_create.argtypes = L.esmdiff_engine_create.argtypes
+    L.esmdiff_decoder_decode.argtypes = [vp, vp, vp, i32, i32, f32, vp]
     L.esmdiff_gemm_bf16_ws.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     for n in EXPORTS:
         if n not in ("esmdiff_engine_destroy", "esmdiff_last_error"):

@@ -31,3 +31,21 @@ class ModelConfig:
 ESM3_OPEN = ModelConfig()
 # small configuration with the same structure, for tests (d_model must be a multiple of 512)
 TINY = ModelConfig(d_model=512, n_heads=8, v_heads=128, n_layers=2)  # v_heads: the engine needs a multiple of 128
+
+
+@dataclass(frozen=True)
+class DecoderConfig:
+    """esm StructureTokenDecoder(d_model=1280, n_heads=20, n_layers=30) as ESM3.decode reaches it
+    (/root/reference/slm/sample_esmdiff.py:56-59) [ESM-RECALL, SURVEY.md 8f-1]: same blocks as ESM3, no residue scaling."""
+    d_model: int = 1280
+    n_heads: int = 20
+    n_layers: int = 30
+    trans_scale: float = 10.0      # Dim6RotStructureHead(trans_scale_factor=10)
+
+    @property
+    def ffn_hidden(self) -> int:
+        return int(((8.0 / 3.0 * self.d_model) + 255) // 256 * 256)
+
+
+STRUCTURE_DECODER_V0 = DecoderConfig()
+TINY_DECODER = DecoderConfig(d_model=768, n_heads=12, n_layers=2)   # 768: exercises the half-slab q/k LayerNorm path

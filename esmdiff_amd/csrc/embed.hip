@@ -79,4 +79,65 @@ hipError_t launch_sigma_mlp(const float* t_freq, const float* w1, const float* b
   return hipGetLastError();
 }
 
+// ---- VQ-VAE structure-token decoder ends ([ESM-RECALL]) -----------------------------------------
+// gather_rows: x[row] = table[tok[row]] (esm StructureTokenDecoder.embed: one nn.Embedding over the 4096 + 5 ids)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restrict__ tok, const float* __restrict__ table,
+                                                          float* __restrict__ out, int M, int D, int n_rows) {
+  const int row = blockIdx.x;
+  if (row >= M) return;
+  int64_t t = tok[row];
+  t = t < 0 ? 0 : (t >= n_rows ? n_rows - 1 : t);
+  const float* a = table + t * D;
+  float* o = out + (int64_t)row * D;
+  for (int c = threadIdx.x * 4; c < D; c += 1024) *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(a + c);
+}
+
+hipError_t launch_gather_rows(const int64_t* tok, const float* table, float* out, int M, int D, int n_rows,
+                              hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(M), dim3(256), 0, stream, tok, table, out, M, D, n_rows);
+  return hipGetLastError();
+}
+
+// dim6_to_backbone: the tail of esm's Dim6RotStructureHead with affine = identity: per residue the 23-vector is
+// [trans 3 | x 3 | y 3 | 14 unused]; trans *= trans_scale; x, y /= (|.| + 1e-5); frame = Gram-Schmidt with origin trans,
+// first axis along -x ... exactly Affine3D.from_graham_schmidt(neg_x_axis = x + trans, origin = trans, xy_plane =
+// y + trans): e0 = normalise(trans - (x + trans)) = -x^, e1 = normalise(y - (y.e0) e0), e2 = e0 x e1; the ideal N / CA / C
+// positions in that frame (BB_COORDINATES) are then moved to the global frame:  p = R b + trans.
+__global__ __launch_bounds__(256) void dim6_to_backbone_kernel(const float* __restrict__ v, int ld, float* __restrict__ out,
+                                                               int M, float trans_scale) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= M) return;
+  const float* p = v + (int64_t)row * ld;
+  const float t[3] = {p[0] * trans_scale, p[1] * trans_scale, p[2] * trans_scale};
+  float x[3] = {p[3], p[4], p[5]}, y[3] = {p[6], p[7], p[8]};
+  const float nx = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) + 1e-5f;
+  const float ny = sqrtf(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]) + 1e-5f;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { x[i] /= nx; y[i] /= ny; }
+  // Gram-Schmidt (eps 1e-12 under the square roots, as in the frame builder of the conditioning path)
+  float e0[3] = {-x[0], -x[1], -x[2]};
+  const float n0 = sqrtf(e0[0] * e0[0] + e0[1] * e0[1] + e0[2] * e0[2] + 1e-12f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e0[i] /= n0;
+  const float d = e0[0] * y[0] + e0[1] * y[1] + e0[2] * y[2];
+  float e1[3] = {y[0] - e0[0] * d, y[1] - e0[1] * d, y[2] - e0[2] * d};
+  const float n1 = sqrtf(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2] + 1e-12f);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) e1[i] /= n1;
+  const float e2[3] = {e0[1] * e1[2] - e0[2] * e1[1], e0[2] * e1[0] - e0[0] * e1[2], e0[0] * e1[1] - e0[1] * e1[0]};
+  const float bb[3][3] = {{0.5256f, 1.3612f, 0.0f}, {0.0f, 0.0f, 0.0f}, {-1.5251f, 0.0f, 0.0f}};  // N, CA, C
+  float* o = out + (int64_t)row * 9;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[a * 3 + i] = e0[i] * bb[a][0] + e1[i] * bb[a][1] + e2[i] * bb[a][2] + t[i];
+}
+
+hipError_t launch_dim6_to_backbone(const float* v, int ld, float* out, int M, float trans_scale, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(dim6_to_backbone_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, v, ld, out, M, trans_scale);
+  return hipGetLastError();
+}
+
 }  // namespace ed

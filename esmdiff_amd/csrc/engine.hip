@@ -42,6 +42,7 @@ struct Layer {
 
 struct esmdiff_engine {
   esmdiff_config cfg{};
+  int kind = 0;  // 0: ESM3 structure-token transformer (the sampler's network); 1: VQ-VAE structure-token decoder
   int device = 0;
   std::string err;
   std::vector<void*> allocs;
@@ -290,7 +291,11 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
     RUN(section, expr);                    \
   }
 
-  EACH(S_EMBED, launch_embed(w.seq, w.xtok, e->e_seq, e->e_struct, e->cvec, cond, w.x, w.B, L, D, w.st));
+  if (e->kind == 1) {
+    EACH(S_EMBED, launch_gather_rows(w.xtok, e->e_struct, w.x, M, D, ESMDIFF_VOCAB, w.st));
+  } else {
+    EACH(S_EMBED, launch_embed(w.seq, w.xtok, e->e_seq, e->e_struct, e->cvec, cond, w.x, w.B, L, D, w.st));
+  }
   // The residual stream x stays f32.  Each branch GEMM (out-proj -> dlt2, FFN-down -> dlt) writes its output, already
   // divided by the residue scale, as a bf16 delta; the LayerNorm kernels add the deltas while they read x anyway, so no
   // GEMM epilogue does a read-modify-write.  x is written back once per block: the attention-side LayerNorm only
@@ -354,8 +359,8 @@ void esmdiff_engine_destroy(esmdiff_engine* e) {
   delete e;
 }
 
-int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table, int32_t n, int32_t device,
-                          esmdiff_engine** out) {
+static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table, int32_t n, int32_t device, int kind,
+                         esmdiff_engine** out) {
   if (!cfg || !table || !out || n <= 0) return fail(nullptr, ESMDIFF_E_INVALID, "null argument");
   *out = nullptr;
   int ndev = 0;
@@ -367,12 +372,14 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
     return fail(nullptr, ESMDIFF_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
   const int D = cfg->d_model, H = cfg->n_heads, FH = cfg->ffn_hidden, V = cfg->vocab_out, F = cfg->freq_dim;
   if (D != H * 64) return fail(nullptr, ESMDIFF_E_INVALID, "d_model (%d) must be n_heads (%d) x 64", D, H);
-  if (D % 512 || D > 2048) return fail(nullptr, ESMDIFF_E_INVALID, "d_model must be a multiple of 512, <= 2048");
-  if (FH % 128 || cfg->n_layers <= 0 || V < ESMDIFF_MASK_ID || V > 5120 || F <= 0 || cfg->max_batch <= 0 || cfg->max_len <= 0)
+  if (D % 256 || D > 2048) return fail(nullptr, ESMDIFF_E_INVALID, "d_model must be a multiple of 256, <= 2048");
+  if (FH % 128 || cfg->n_layers <= 0 || cfg->max_batch <= 0 || cfg->max_len <= 0 ||
+      (kind == 0 && (V < ESMDIFF_MASK_ID || V > 5120 || F <= 0)) || (kind == 1 && V != 23))
     return fail(nullptr, ESMDIFF_E_INVALID, "invalid configuration");
 
   esmdiff_engine* e = new esmdiff_engine;
   e->cfg = *cfg;
+  e->kind = kind;
   e->device = device;
   auto bail = [&](int code) {
     g_create_error = e->err;
@@ -390,10 +397,16 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
     if (int _r = (x)) return bail(_r); \
   } while (0)
 
+  // kind 1 (esm StructureTokenDecoder, SURVEY.md 8f-1 [ESM-RECALL]): the same block stack under decoder_stack.*, a single
+  // token embedding, and affine_output_projection (Linear -> GELU -> LayerNorm -> Linear(23)) in place of the head
+  const std::string stack = kind == 1 ? "decoder_stack." : "transformer.";
+  const std::string head0 = kind == 1 ? "affine_output_projection.ffn1." : "output_heads.structure_head.0.";
+  const std::string head2 = kind == 1 ? "affine_output_projection.norm." : "output_heads.structure_head.2.";
+  const std::string head3 = kind == 1 ? "affine_output_projection.proj." : "output_heads.structure_head.3.";
   e->layers.resize(cfg->n_layers);
   for (int i = 0; i < cfg->n_layers; ++i) {
     Layer& ly = e->layers[i];
-    const std::string b = "transformer.blocks." + std::to_string(i) + ".";
+    const std::string b = stack + "blocks." + std::to_string(i) + ".";
     TRY(load_f32(e, t, b + "attn.layernorm_qkv.0.weight", {D}, &ly.ln1_w));
     TRY(load_f32(e, t, b + "attn.layernorm_qkv.0.bias", {D}, &ly.ln1_b));
     TRY(load_bf16(e, t, b + "attn.layernorm_qkv.1.weight", {3 * D, D}, &ly.w_qkv));
@@ -411,29 +424,33 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
     }
     TRY(load_bf16(e, t, b + "ffn.3.weight", {D, FH}, &ly.w_down));
   }
-  TRY(load_f32(e, t, "transformer.norm.weight", {D}, &e->final_ln_w));
-  TRY(load_bf16(e, t, "output_heads.structure_head.0.weight", {D, D}, &e->head_w0));
-  TRY(load_f32(e, t, "output_heads.structure_head.0.bias", {D}, &e->head_b0));
-  TRY(load_f32(e, t, "output_heads.structure_head.2.weight", {D}, &e->head_ln_w));
-  TRY(load_f32(e, t, "output_heads.structure_head.2.bias", {D}, &e->head_ln_b));
+  TRY(load_f32(e, t, stack + "norm.weight", {D}, &e->final_ln_w));
+  TRY(load_bf16(e, t, head0 + "weight", {D, D}, &e->head_w0));
+  TRY(load_f32(e, t, head0 + "bias", {D}, &e->head_b0));
+  TRY(load_f32(e, t, head2 + "weight", {D}, &e->head_ln_w));
+  TRY(load_f32(e, t, head2 + "bias", {D}, &e->head_ln_b));
   e->vocab_pad = round_up(V, 128);
-  TRY(load_bf16(e, t, "output_heads.structure_head.3.weight", {V, D}, &e->head_w3, e->vocab_pad));
+  TRY(load_bf16(e, t, head3 + "weight", {V, D}, &e->head_w3, e->vocab_pad));
   {
     const esmdiff_weight* w;
-    TRY(need(e, t, "output_heads.structure_head.3.bias", {V}, &w));
+    TRY(need(e, t, head3 + "bias", {V}, &w));
     TRY(dalloc(e, &e->head_b3, (size_t)e->vocab_pad, true));
     if (launch_to_f32(w->data, w->dtype, e->head_b3, V, 0) != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "to_f32 failed"));
   }
+  if (kind == 1) {
+    TRY(load_f32(e, t, "embed.weight", {ESMDIFF_VOCAB, D}, &e->e_struct));
+  } else {
   TRY(load_f32(e, t, "encoder.sequence_embed.weight", {64, D}, &e->e_seq));
   TRY(load_f32(e, t, "encoder.structure_tokens_embed.weight", {ESMDIFF_VOCAB, D}, &e->e_struct));
-  if (cfg->time_conditioning) {
+  }
+  if (kind == 0 && cfg->time_conditioning) {
     TRY(load_f32(e, t, "sigma_embedder.mlp.0.weight", {D, F}, &e->sig_w1));
     TRY(load_f32(e, t, "sigma_embedder.mlp.0.bias", {D}, &e->sig_b1));
     TRY(load_f32(e, t, "sigma_embedder.mlp.2.weight", {D, D}, &e->sig_w2));
     TRY(load_f32(e, t, "sigma_embedder.mlp.2.bias", {D}, &e->sig_b2));
   }
   // block 0's geometric attention: optional (the DDPM path never needs it: coordinates are all-NaN there)
-  if (const esmdiff_weight* pw = t.find("transformer.blocks.0.geom_attn.proj.weight")) {
+  if (const esmdiff_weight* pw = kind == 0 ? t.find("transformer.blocks.0.geom_attn.proj.weight") : nullptr) {
     const std::string ga = "transformer.blocks.0.geom_attn.";
     const int VH = pw->ndim == 2 ? (int)(pw->shape[0] / 15) : 0;  // proj: Linear(D, v_heads * 3 * 5)
     if (VH <= 0 || (15 * VH) % 128 || (3 * VH) % 64) return bail(fail(e, ESMDIFF_E_INVALID, "geom_attn v_heads=%d unsupported", VH));
@@ -455,7 +472,7 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
   // constant vector of the defaulted tracks (net.py:410-431 -> esm EncodeInputs): average_plddt = 1,
   // per_res_plddt = 0 through rbf(.,0,1,16) and a Linear(16,D); ss8 / sasa pad id 0; function and
   // residue-annotation pads embed to zero (padding_idx=0).
-  {
+  if (kind == 0) {
     float *pw, *pb, *sw, *sb, *ss8, *sasa;
     TRY(load_f32(e, t, "encoder.plddt_projection.weight", {D, 16}, &pw));
     TRY(load_f32(e, t, "encoder.plddt_projection.bias", {D}, &pb));
@@ -570,8 +587,36 @@ int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table
   return 0;
 }
 
+int esmdiff_engine_create(const esmdiff_config* cfg, const esmdiff_weight* table, int32_t n, int32_t device,
+                          esmdiff_engine** out) {
+  return create_engine(cfg, table, n, device, 0, out);
+}
+
+int esmdiff_decoder_create(const esmdiff_config* cfg, const esmdiff_weight* table, int32_t n, int32_t device,
+                           esmdiff_engine** out) {
+  if (!cfg) return fail(nullptr, ESMDIFF_E_INVALID, "null argument");
+  esmdiff_config c = *cfg;
+  c.vocab_out = 23;  // Dim6RotStructureHead.proj: 3 translation + 3 + 3 axis seeds + 14 (unused torsion slots)
+  c.freq_dim = 1;
+  c.time_conditioning = 0;
+  return create_engine(&c, table, n, device, 1, out);
+}
+
+int esmdiff_decoder_decode(esmdiff_engine* e, const int64_t* tokens, float* bb_coords, int32_t B, int32_t L,
+                           float trans_scale, void* stream) {
+  if (!e || !tokens || !bb_coords) return ESMDIFF_E_INVALID;
+  if (e->kind != 1) return fail(e, ESMDIFF_E_INVALID, "not a decoder engine");
+  if (int r = check_bl(e, B, L)) return r;
+  HIP_TRY(e, hipSetDevice(e->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (int r = forward(e, tokens, tokens, nullptr, e->logits, e->ld_logits, B, L, st)) return r;
+  HIP_TRY(e, launch_dim6_to_backbone(e->logits, e->ld_logits, bb_coords, B * L, trans_scale, st));
+  return 0;
+}
+
 int esmdiff_forward_logits(esmdiff_engine* e, const int64_t* seq, const int64_t* x, const float* t_freq,
                            float* logits_out, int32_t ld_logits, int32_t B, int32_t L, void* stream) {
+  if (e && e->kind != 0) return fail(e, ESMDIFF_E_INVALID, "this engine is a structure-token decoder (esmdiff_decoder_create)");
   if (!e) return ESMDIFF_E_INVALID;
   if (!seq || !x || !logits_out) return fail(e, ESMDIFF_E_INVALID, "null pointer");
   if (ld_logits < e->cfg.vocab_out || (ld_logits & 3)) return fail(e, ESMDIFF_E_INVALID, "ld_logits (%d) must be >= vocab (%d) rounded up to a multiple of 4", ld_logits, e->cfg.vocab_out);
@@ -598,6 +643,7 @@ int esmdiff_ddpm_step(esmdiff_engine* e, int64_t* x_inout, const float* logits, 
 int esmdiff_ddpm_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout, int32_t B, int32_t L, int32_t T,
                         const float* mc_t, const float* mc_s, const float* t_freq, const esmdiff_rng* rng,
                         void* stream) {
+  if (e && e->kind != 0) return fail(e, ESMDIFF_E_INVALID, "this engine is a structure-token decoder (esmdiff_decoder_create)");
   if (!e) return ESMDIFF_E_INVALID;
   if (!seq || !x_inout || !mc_t || !mc_s || !rng) return fail(e, ESMDIFF_E_INVALID, "null pointer");
   if (T <= 0 || T + 1 > e->tfreq_rows) return fail(e, ESMDIFF_E_INVALID, "num_steps %d out of range (1..%d)", T, e->tfreq_rows - 1);
@@ -639,6 +685,7 @@ int esmdiff_gibbs_step(esmdiff_engine* e, int64_t* x_inout, const int64_t* seq, 
 int esmdiff_gibbs_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout, int32_t B, int32_t L, int32_t T,
                          float temperature, float top_p, const int32_t* n_unmask_table, const esmdiff_rng* rng,
                          void* stream) {
+  if (e && e->kind != 0) return fail(e, ESMDIFF_E_INVALID, "this engine is a structure-token decoder (esmdiff_decoder_create)");
   if (!e) return ESMDIFF_E_INVALID;
   if (!seq || !x_inout || !n_unmask_table || !rng) return fail(e, ESMDIFF_E_INVALID, "null pointer");
   if (T <= 0 || T > e->tfreq_rows) return fail(e, ESMDIFF_E_INVALID, "num_steps %d out of range (1..%d)", T, e->tfreq_rows);

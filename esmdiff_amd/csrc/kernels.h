@@ -69,6 +69,10 @@ hipError_t launch_embed(const int64_t* seq, const int64_t* xtok, const float* e_
                         const float* cvec, const float* cond, float* out, int B, int L, int D,
                         hipStream_t stream);
 // cond = W2 · silu(W1 · t_freq + b1) + b2   (net.py:489-492,519-522), f32
+hipError_t launch_gather_rows(const int64_t* tok, const float* table, float* out, int M, int D, int n_rows,
+                              hipStream_t stream);
+// v f32 [M, ld] (23 used) -> backbone N/CA/C coordinates f32 [M, 3, 3]
+hipError_t launch_dim6_to_backbone(const float* v, int ld, float* out, int M, float trans_scale, hipStream_t stream);
 hipError_t launch_sigma_mlp(const float* t_freq, const float* w1, const float* b1, const float* w2,
                             const float* b2, float* hidden, float* cond, int F, int D, hipStream_t stream);
 

@@ -239,7 +239,8 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-      const uint4 p = *reinterpret_cast<const uint4*>(src + j * 512 + lane * 8);
+      // D = 1280 (the VQ-VAE decoder stack) ends in a half slab: lanes past D hold zeros and are not stored
+      const uint4 p = (j * 512 + lane * 8 < D) ? *reinterpret_cast<const uint4*>(src + j * 512 + lane * 8) : uint4{0, 0, 0, 0};
       const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
     for (int j = 0; j < NS; ++j)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float d = v[j][e] - mean;
+        const float d = (j * 512 + lane * 8 < D) ? v[j][e] - mean : 0.f;
         q += d * d;
       }
     const float rstd = rsqrtf(wsum(q) / (float)D + 1e-5f);
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
       const int c0 = j * 512 + lane * 8;
+      if (c0 >= D) continue;  // the shuffle partners (lane ^ 4) of a stored lane are always inside D: D % 64 == 0
       float n[8], r[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) n[e] = (v[j][e] - mean) * rstd * w[c0 + e];
@@ -288,11 +290,11 @@ hipError_t launch_qk_norm_rope(const bf16_t* qkv, const float* q_ln_w, const flo
                                int B, int L, int H, hipStream_t stream) {
   const int D = H * 64, M = B * L;
   if (M <= 0) return hipSuccess;
-  if (D % 512 != 0 || D > 2048) return hipErrorInvalidValue;
+  if (D % 64 != 0 || D > 2048) return hipErrorInvalidValue;
   dim3 grid((M + 3) / 4), block(256);
 #define ED_QK(N) \
   hipLaunchKernelGGL(qk_norm_rope_kernel<N>, grid, block, 0, stream, qkv, q_ln_w, k_ln_w, rope_cos, rope_sin, q, k, B, L, H)
-  switch (D / 512) {
+  switch ((D + 511) / 512) {
     case 1: ED_QK(1); break;
     case 2: ED_QK(2); break;
     case 3: ED_QK(3); break;

@@ -234,6 +234,54 @@ class Engine:
         return ctx
 
 
+class StructureDecoder:
+    """Structure tokens -> backbone coordinates on the device (esmdiff_decoder_create / esmdiff_decoder_decode): what the
+    reference gets from `esm3.decode(ESMProteinTensor(structure=...))`, /root/reference/slm/sample_esmdiff.py:40-61."""
+
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], max_batch: int, max_len: int, device: int = 0):
+        _require_gpu()
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self._lib = N.lib()
+        self._h = ctypes.c_void_p(0)
+        c = N.Config(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden, 23, 1, max_batch, max_len, 1.0, 0)
+        keep, table = [], (N.Weight * len(state_dict))()
+        with torch.cuda.device(self.device):
+            for i, (name, t) in enumerate(state_dict.items()):
+                if t.dtype not in (torch.float32, torch.bfloat16):
+                    t = t.float()
+                d = t.detach().to(self.device).contiguous()
+                keep.append(d)
+                shape = (ctypes.c_int64 * 4)(*(list(d.shape) + [0] * (4 - d.dim())))
+                table[i] = N.Weight(name.encode(), d.data_ptr(), N.DT_F32 if d.dtype == torch.float32 else N.DT_BF16,
+                                    d.dim(), shape)
+            torch.cuda.synchronize()
+            code = self._lib.esmdiff_decoder_create(ctypes.byref(c), table, len(state_dict), device, ctypes.byref(self._h))
+        if code != 0:
+            raise RuntimeError(f"esmdiff_decoder_create failed ({code}): {self._lib.esmdiff_last_error(None).decode()}")
+        del keep
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.esmdiff_engine_destroy(self._h)
+            self._h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decode(self, structure_tokens: torch.Tensor) -> torch.Tensor:
+        """structure_tokens (B, L) int64 including BOS / EOS -> backbone coordinates (B, L - 2, 3, 3) float32 (N, CA, C)."""
+        B, L = structure_tokens.shape
+        tok = structure_tokens.to(device=self.device, dtype=torch.int64).contiguous()
+        out = torch.empty(B, L, 3, 3, dtype=torch.float32, device=self.device)
+        N.check(self._lib.esmdiff_decoder_decode(self._h, _ptr(tok), _ptr(out), B, L, float(self.cfg.trans_scale),
+                                                 _stream()), self._h)
+        return out[:, 1:-1]
+
+
 def gemm_bf16(A: torch.Tensor, W: torch.Tensor, epilogue: int, *, out: Optional[torch.Tensor] = None,
               bias: Optional[torch.Tensor] = None, alpha: float = 1.0, n_valid: Optional[int] = None) -> torch.Tensor:
     """out = epilogue(A[M,K] @ W[N,K]^T) through esmdiff_gemm_bf16 (N % 128 == 0, K % 64 == 0)."""

@@ -47,13 +47,36 @@ def batch_sizes(n_tokens: int, num_samples: int, n_max_residue_square: int = DEF
     return bsz
 
 
+@torch.no_grad()
+def decode_to_pdb(tokens: torch.Tensor, sequence: str, decoder, save_to: Path, sample_basename: str, chunk: int = 64):
+    """sample_esmdiff.py:40-61 + :225-231: structure tokens (N, L) -> backbone coordinates -> one PDB per sample in a
+    temporary directory -> merge_pdbfiles into `<basename>.pdb` (MODEL n ... ENDMDL blocks).  The reference decodes one
+    sample per esm3.decode call; here the decoder engine takes them `chunk` at a time."""
+    import tempfile
+    from .pdbio import merge_pdbfiles, write_backbone_pdb
+    N_, L_ = tokens.shape
+    bos = torch.full((N_, 1), C.STRUCTURE_BOS_TOKEN, dtype=torch.int64)
+    eos = torch.full((N_, 1), C.STRUCTURE_EOS_TOKEN, dtype=torch.int64)
+    full = torch.cat([bos, tokens.cpu().to(torch.int64), eos], 1)
+    coords = torch.cat([decoder.decode(full[i:i + chunk]).cpu() for i in range(0, N_, chunk)], 0).numpy()
+    seq = sequence.replace(C.MASK_RESIDUE, "X")
+    with tempfile.TemporaryDirectory() as tmpdirname:
+        saved = []
+        for i in range(N_):
+            tmp = Path(tmpdirname) / f"{sample_basename}.{i}.pdb"
+            write_backbone_pdb(tmp, seq, coords[i])
+            saved.append(tmp)
+        merge_pdbfiles(saved, save_to, verbose=False)
+
+
 @timer
 @torch.no_grad()
 def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: str, num_samples: int = 5,
                        num_steps: int = 10, eps: float = 1e-5, n_max_residue_square: int = DEFAULT_NMAX,
                        coordinates=None, mask_ids=None, structure_tokens=None, sample_max_t: float = 1.0,
-                       seed: int = 0, noise: str = "philox", timestamp: bool = True):
-    """sample_esmdiff.py:137-233.  `structure_tokens` (L+2, with BOS/EOS) replaces what the reference gets from
+                       seed: int = 0, noise: str = "philox", timestamp: bool = True, decoder=None):
+    """sample_esmdiff.py:137-233.  With a `decoder` (esmdiff_amd.engine.StructureDecoder) rank 0 also writes the reference's
+    artefact, `<basename>.pdb` with one MODEL per sample; the token file is written either way.  `structure_tokens` (L+2, with BOS/EOS) replaces what the reference gets from
     ESM3.encode(coordinates) for the inpainting prior (:196-201); without it mask_ids cannot be honoured."""
     model = pl_model
     str_time = ("_" + strftime("%Y%m%d-%H%M%S")) if timestamp else ""
@@ -99,6 +122,8 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
         (output_dir / f"{sample_basename}.json").write_text(json.dumps(
             {"sequence": sequence, "num_steps": num_steps, "num_samples": num_samples, "eps": eps, "seed": seed,
              "noise": noise, "world_size": world, "sampling_seconds": round(time() - start_t, 3)}, indent=1))
+        if decoder is not None:
+            decode_to_pdb(tokens, sequence, decoder, output_dir / f"{sample_basename}.pdb", sample_basename)
         print(f"Total time: {time() - start_t:.2f}s")
     return []
 
@@ -108,7 +133,7 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
 def minibatch_gibbs_by_esm(protseq, esm3_model, output_dir: Path, sample_basename: str, num_samples: int = 10,
                            num_steps: int = 16, temperature: float = 1.4, top_p: float = 0.9,
                            n_max_residue_square: int = DEFAULT_NMAX, coordinates=None, mask_ids=None,
-                           structure_tokens=None, seed: int = 0, timestamp: bool = True):
+                           structure_tokens=None, seed: int = 0, timestamp: bool = True, decoder=None):
     """sample_esmdiff.py:66-130: batches of ESMProtein copies through iterative_sampling_raw with
     GenerationConfig(track="structure", num_steps, temperature, top_p).  Inpainting as the reference does it (:88-96):
     `mask_ids` needs `coordinates` (L, >=3, 3); the masked residues get sequence '_' and coordinates Inf, and the known
@@ -166,6 +191,8 @@ def minibatch_gibbs_by_esm(protseq, esm3_model, output_dir: Path, sample_basenam
             {"sequence": protseq, "mode": "gibbs", "num_steps": num_steps, "num_samples": num_samples,
              "temperature": temperature, "top_p": top_p, "seed": seed, "world_size": world,
              "sampling_seconds": round(time() - start_t, 3)}, indent=1))
+        if decoder is not None:
+            decode_to_pdb(tokens, protseq, decoder, output_dir / f"{sample_basename}.pdb", sample_basename)
     return []
 
 
@@ -181,6 +208,10 @@ def get_argparser(argv=None):
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--random_init", action="store_true", help="ESM3-open-sized random weights instead of --ckpt")
     p.add_argument("--tiny", action="store_true", help=argparse.SUPPRESS)   # tests: 2-block model with --random_init
+    p.add_argument("--decoder_ckpt", type=str, default=None,
+                   help="state dict of esm's StructureTokenDecoder (esm3_structure_decoder_v0): also write <name>.pdb "
+                        "with one MODEL per sample, as the reference does; without it only <name>.tokens.npy is written")
+    p.add_argument("--random_init_decoder", action="store_true", help="random decoder weights (plumbing / tests)")
     p.add_argument("--synthetic_len", type=int, default=0, help="sample a random sequence of this length")
     p.add_argument("--n_max_residue_square", type=int, default=DEFAULT_NMAX)
     p.add_argument("--parity", action="store_true", help="uniforms from torch's CPU generator, like the reference")
@@ -233,6 +264,17 @@ def main(argv=None):
     else:
         model = load_state_dict_from_lightning_ckpt(args.ckpt, device=f"cuda:{local_rank}", max_batch=max_b,
                                                     max_len=max_len)
+    decoder = None
+    if (args.decoder_ckpt or args.random_init_decoder) and rank == 0:
+        from .config import STRUCTURE_DECODER_V0, TINY_DECODER
+        from .engine import StructureDecoder
+        from .weights import random_init_decoder_state_dict
+        dcfg = TINY_DECODER if args.tiny else STRUCTURE_DECODER_V0
+        if args.decoder_ckpt:
+            dsd = torch.load(args.decoder_ckpt, map_location="cpu", weights_only=True)
+        else:
+            dsd = random_init_decoder_state_dict(dcfg, seed=args.seed, device=f"cuda:{local_rank}")
+        decoder = StructureDecoder(dcfg, dsd, max_batch=64, max_len=max_len, device=local_rank)
     if rank == 0:
         print(f">>> Sampling mode = {args.mode} ...")
     for name, seq in targets:
@@ -243,12 +285,12 @@ def main(argv=None):
             minibatch_gibbs_by_esm(seq, model, Path(args.output), name, num_samples=args.num_samples,
                                    num_steps=args.num_steps, n_max_residue_square=args.n_max_residue_square,
                                    coordinates=coordinates, mask_ids=mask_ids,
-                                   seed=args.seed, timestamp=not args.no_timestamp)
+                                   seed=args.seed, timestamp=not args.no_timestamp, decoder=decoder)
         else:
             ddpm_sample_by_esm(seq, model, Path(args.output), name, num_samples=args.num_samples,
                                num_steps=args.num_steps, n_max_residue_square=args.n_max_residue_square,
                                seed=args.seed, noise="torch-cpu" if args.parity else "philox",
-                               timestamp=not args.no_timestamp)
+                               timestamp=not args.no_timestamp, decoder=decoder)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

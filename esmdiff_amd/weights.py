@@ -79,6 +79,41 @@ def random_init_state_dict(cfg: ModelConfig, seed: int = 0, prefix: str = "net."
     return sd
 
 
+def random_init_decoder_state_dict(cfg, seed: int = 0, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """Random weights with the key layout of esm's StructureTokenDecoder: embed, decoder_stack.*,
+    affine_output_projection.* — for tests and offline plumbing (the real esm3_structure_decoder_v0 cannot be fetched)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    D, FH = cfg.d_model, cfg.ffn_hidden
+
+    def randn(*shape):
+        return torch.randn(*shape, generator=g, device=device)
+
+    def linear(out_f, in_f, bias):
+        bound = 1.0 / math.sqrt(in_f)
+        w = (torch.rand(out_f, in_f, generator=g, device=device) * 2 - 1) * bound
+        return w, ((torch.rand(out_f, generator=g, device=device) * 2 - 1) * bound if bias else None)
+
+    sd: Dict[str, torch.Tensor] = {"embed.weight": randn(4096 + 5, D)}
+    for i in range(cfg.n_layers):
+        b = f"decoder_stack.blocks.{i}."
+        sd[b + "attn.layernorm_qkv.0.weight"] = 1.0 + 0.1 * randn(D)
+        sd[b + "attn.layernorm_qkv.0.bias"] = 0.05 * randn(D)
+        sd[b + "attn.layernorm_qkv.1.weight"] = linear(3 * D, D, False)[0]
+        sd[b + "attn.q_ln.weight"] = 1.0 + 0.1 * randn(D)
+        sd[b + "attn.k_ln.weight"] = 1.0 + 0.1 * randn(D)
+        sd[b + "attn.out_proj.weight"] = linear(D, D, False)[0]
+        sd[b + "ffn.0.weight"] = 1.0 + 0.1 * randn(D)
+        sd[b + "ffn.0.bias"] = 0.05 * randn(D)
+        sd[b + "ffn.1.weight"] = linear(2 * FH, D, False)[0]
+        sd[b + "ffn.3.weight"] = linear(D, FH, False)[0]
+    sd["decoder_stack.norm.weight"] = 1.0 + 0.1 * randn(D)
+    h = "affine_output_projection."
+    sd[h + "ffn1.weight"], sd[h + "ffn1.bias"] = linear(D, D, True)
+    sd[h + "norm.weight"], sd[h + "norm.bias"] = 1.0 + 0.1 * randn(D), 0.05 * randn(D)
+    sd[h + "proj.weight"], sd[h + "proj.bias"] = linear(23, D, True)
+    return sd
+
+
 def load_checkpoint_state_dict(path) -> Dict[str, torch.Tensor]:
     """The reference's format (checkpoint_utils.py:41-64): a .pt whose 'module' entry is the state dict."""
     path = Path(path)

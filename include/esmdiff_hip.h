@@ -192,6 +192,21 @@ int esmdiff_attention_bf16(esmdiff_engine* eng, const void* qkv, const float* q_
 int esmdiff_set_frames(esmdiff_engine* eng, const float* rot, const float* trans, const uint8_t* has_frame,
                        int32_t B, int32_t L, void* stream);
 
+/* VQ-VAE structure-token decoder: structure tokens -> backbone coordinates.  Replaces `esm3.decode(...)` as the
+ * reference's decode() helper calls it once per sample (/root/reference/slm/sample_esmdiff.py:40-61, :225-230; the
+ * reference also moves the whole ESM3 model between CPU and GPU around it, :58, :176).  The decoder is esm's
+ * StructureTokenDecoder [ESM-RECALL, SURVEY.md 8f-1]: nn.Embedding(4101, d) -> the same pre-LN block stack as ESM3
+ * (no geometric attention, residue scaling 1) -> Dim6RotStructureHead.  cfg: d_model 1280, n_heads 20, n_layers 30,
+ * ffn_hidden 3584 for esm3_structure_decoder_v0; vocab_out / freq_dim / time_conditioning are ignored, residue_scale
+ * should be 1.  Weight names: embed.weight, decoder_stack.blocks.{i}.<as ESM3>, decoder_stack.norm.weight,
+ * affine_output_projection.{ffn1,norm,proj}.{weight,bias}.  Destroy with esmdiff_engine_destroy.
+ * esmdiff_decoder_decode: tokens int64 [B,L] INCLUDING BOS (4098) / EOS (4097); bb_coords f32 [B,L,3,3] = N, CA, C
+ * per position (rows 0 and L-1 belong to BOS/EOS and are to be dropped); trans_scale = 10 in esm. */
+int esmdiff_decoder_create(const esmdiff_config* cfg, const esmdiff_weight* table, int32_t n_weights,
+                           int32_t device, esmdiff_engine** out);
+int esmdiff_decoder_decode(esmdiff_engine* dec, const int64_t* tokens, float* bb_coords, int32_t B, int32_t L,
+                           float trans_scale, void* stream);
+
 /* Accumulated per-section device time of the esmdiff_forward_logits/ddpm_sample calls since profiling was
  * enabled: esmdiff_set_profiling(eng, 1) brackets every launch with HIP events on the launch stream (no sync);
  * mode 2 brackets only the dominant kernel (FFN-up GEMM, section 6), cheap enough for a timed region; 0 = off. sections: 0 embed, 1 layernorm, 2 gemm_qkv,

@@ -25,4 +25,6 @@ Parts
                    GeometricReasoningOriginalImpl (call sites net.py:433-441, :468).
                    PARITY UNPINNED; checked for what must hold regardless (rigid-motion invariance, exact
                    zero branch without coordinates, frameless residues inert: tests/test_geom_cpu.py).
+  decoder_ref.py   torch restatement of esm's StructureTokenDecoder backbone path (embed -> block stack ->
+                   Dim6RotStructureHead; call site sample_esmdiff.py:40-61).  PARITY UNPINNED.
 """

@@ -383,6 +383,37 @@ def test_forward_with_coordinates_vs_oracle(monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("B,L", [(3, 60), (2, 131)])
+def test_structure_decoder_vs_oracle(B, L):
+    """Structure tokens -> backbone coordinates (esmdiff_decoder_create / _decode: the ESM3 block stack at d = 768, the
+    half-slab q/k LayerNorm path, then Dim6RotStructureHead) against oracle/decoder_ref.py."""
+    from esmdiff_amd.config import TINY_DECODER
+    from esmdiff_amd.engine import StructureDecoder
+    from esmdiff_amd.weights import random_init_decoder_state_dict
+    from oracle.decoder_ref import build_decoder_from_state_dict
+    sd = random_init_decoder_state_dict(TINY_DECODER, seed=2)
+    ref_net = build_decoder_from_state_dict(TINY_DECODER, sd)
+    g = torch.Generator().manual_seed(L)
+    tok = torch.randint(0, 4096, (B, L), generator=g)
+    tok[:, 0], tok[:, -1] = 4098, 4097
+    with torch.no_grad():
+        ref = ref_net(tok)
+    dec = StructureDecoder(TINY_DECODER, sd, max_batch=B, max_len=L)
+    got = dec.decode(tok.cuda()).cpu()
+    assert got.shape == ref.shape == (B, L - 2, 3, 3)
+    # the frame is rigid: ideal N-CA / CA-C bond lengths whatever the network says
+    assert float(((got[:, :, 1] - got[:, :, 0]).norm(dim=-1) - 1.4592).abs().max()) < 2e-3
+    assert float(((got[:, :, 1] - got[:, :, 2]).norm(dim=-1) - 1.5251).abs().max()) < 2e-3
+    # translations are 10 x a head output computed from bf16 GEMM operands: a few hundredths of an Angstrom
+    err = (got - ref).norm(dim=-1)
+    assert float(err.mean()) < 0.08 and float(err.max()) < 0.6, (float(err.mean()), float(err.max()))
+    with pytest.raises(RuntimeError, match="decoder"):
+        dec._lib.esmdiff_forward_logits  # noqa: B018  (attribute exists)
+        from esmdiff_amd import _native as Nn
+        Nn.check(dec._lib.esmdiff_forward_logits(dec._h, None, None, None, None, 0, 1, 1, None), dec._h)
+    dec.close()
+
+
 def test_two_stream_forward_is_bitwise_identical(tiny, monkeypatch):
     """The engine runs the two halves of a large batch on two HIP streams (engine.hip::forward).  Samples are
     independent and every kernel's per-row arithmetic does not depend on the tiling, so logits and sampled ids must
@@ -630,6 +661,24 @@ def test_cli_gibbs_default_mode(tmp_path):
           "--no_timestamp", "--seed", "2"])                                # --mode defaults to gibbs, as in the reference
     ids = np.load(tmp_path / "T1.4_step8_topp0.9_N3" / "synthetic40.tokens.npy")
     assert ids.shape == (3, 40) and ids.min() >= 0 and ids.max() < 4096
+
+
+def test_cli_writes_multi_model_pdb_with_decoder(tmp_path):
+    """The reference's artefact: <basename>.pdb with one MODEL per sample (sample_esmdiff.py:225-231), produced by the
+    decoder engine (random weights here) + merge_pdbfiles; readable back with the in-tree PDB reader."""
+    from esmdiff_amd.sample_esmdiff import main
+    main(["--random_init", "--tiny", "--random_init_decoder", "--synthetic_len", "30", "--mode", "ddpm", "--num_samples", "4",
+          "--num_steps", "4", "--output", str(tmp_path), "--no_timestamp"])
+    d = tmp_path / "step4_eps1e-05_N4"
+    ids = np.load(d / "synthetic30.tokens.npy")
+    text = (d / "synthetic30.pdb").read_text().splitlines()
+    assert ids.shape == (4, 30)
+    # (the reference's merge closes single-model inputs twice at the very end — eval_utils.py:437-492, golden g8)
+    assert sum(l.startswith("MODEL") for l in text) == 4 and sum(l.startswith("ENDMDL") for l in text) in (4, 5)
+    assert text[-1].startswith("END") and all(len(l) == 80 for l in text)
+    assert sum(l.startswith("ATOM") for l in text) == 4 * 30 * 3
+    ca = [l for l in text if l.startswith("ATOM") and l[12:16].strip() == "CA"]
+    assert len(ca) == 120
 
 
 def test_cli_gibbs_inpainting_from_pdb(tmp_path):
