@@ -440,8 +440,8 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
   if (kind == 1) {
     TRY(load_f32(e, t, "embed.weight", {ESMDIFF_VOCAB, D}, &e->e_struct));
   } else {
-  TRY(load_f32(e, t, "encoder.sequence_embed.weight", {64, D}, &e->e_seq));
-  TRY(load_f32(e, t, "encoder.structure_tokens_embed.weight", {ESMDIFF_VOCAB, D}, &e->e_struct));
+    TRY(load_f32(e, t, "encoder.sequence_embed.weight", {64, D}, &e->e_seq));
+    TRY(load_f32(e, t, "encoder.structure_tokens_embed.weight", {ESMDIFF_VOCAB, D}, &e->e_struct));
   }
   if (kind == 0 && cfg->time_conditioning) {
     TRY(load_f32(e, t, "sigma_embedder.mlp.0.weight", {D, F}, &e->sig_w1));
