@@ -39,7 +39,8 @@ EXPORTS = [
     "esmdiff_gibbs_sample", "esmdiff_gemm_bf16",
     "esmdiff_gemm_bf16_timed", "esmdiff_layernorm_bf16", "esmdiff_attention_bf16", "esmdiff_set_profiling",
     "esmdiff_get_profile", "esmdiff_set_frames", "esmdiff_gemm_bf16_ws", "esmdiff_decoder_create",
-    "esmdiff_decoder_decode",
+    "esmdiff_decoder_decode", "esmdiff_metrics_js_pwd", "esmdiff_metrics_js_rg", "esmdiff_metrics_validity",
+    "esmdiff_metrics_bonding_validity",
 ]
 
 
@@ -79,6 +80,11 @@ def lib():
     L.esmdiff_set_frames.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.esmdiff_decoder_create.argtypes = L.esmdiff_engine_create.argtypes
     L.esmdiff_decoder_decode.argtypes = [vp, vp, vp, i32, i32, f32, vp]
+    f64, f64p = ctypes.c_double, ctypes.POINTER(ctypes.c_double)
+    L.esmdiff_metrics_js_pwd.argtypes = [vp, i32, vp, i32, i32, i32, i32, f64p, vp]
+    L.esmdiff_metrics_js_rg.argtypes = [vp, i32, vp, i32, i32, i32, f64p, vp]
+    L.esmdiff_metrics_validity.argtypes = [vp, i32, i32, f64, f64, i32, f64p, vp]
+    L.esmdiff_metrics_bonding_validity.argtypes = [vp, i32, vp, i32, i32, f64p, vp]
     L.esmdiff_gemm_bf16_ws.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     for n in EXPORTS:
         if n not in ("esmdiff_engine_destroy", "esmdiff_last_error"):

@@ -31,6 +31,7 @@ UNITS = {
     "convert": [],
     "sampler": ["-ffp-contract=off"],
     "gibbs": ["-ffp-contract=off"],
+    "metrics": ["-ffp-contract=off"],
 }
 EXTRA = os.environ.get("ESMDIFF_EXTRA_CXXFLAGS", "").split()
 COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",

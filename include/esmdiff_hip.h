@@ -207,6 +207,22 @@ int esmdiff_decoder_create(const esmdiff_config* cfg, const esmdiff_weight* tabl
 int esmdiff_decoder_decode(esmdiff_engine* dec, const int64_t* tokens, float* bb_coords, int32_t B, int32_t L,
                            float trans_scale, void* stream);
 
+/* Ensemble metrics on CA traces (float64, device pointers in, one double out on the host; each call synchronises
+ * `stream`).  They replace the numpy / scipy functions of /root/reference/slm/utils/eval_utils.py that score a generated
+ * ensemble against a reference ensemble: js_pwd :227-255 (Jensen-Shannon distance of the per-pair CA distance
+ * histograms, bins spanning the reference's range, pseudo count 1e-6, mean over pairs), js_rg :290-316, validity
+ * :158-173 (fraction of frames without a CA-CA distance below 2*radius - overlap among pairs |i-j| > k_exclusion),
+ * bonding_validity :176-188 (fraction of frames whose adjacent CA distances all stay below the reference's maximum
+ * + 1e-6).  ca_*: f64 [n, L, 3].  Values are returned unrounded (the reference rounds to 4 decimals last). */
+int esmdiff_metrics_js_pwd(const double* ca_model, int32_t n_model, const double* ca_ref, int32_t n_ref, int32_t L,
+                           int32_t n_bins, int32_t pwd_offset, double* js_out, void* stream);
+int esmdiff_metrics_js_rg(const double* ca_model, int32_t n_model, const double* ca_ref, int32_t n_ref, int32_t L,
+                          int32_t n_bins, double* js_out, void* stream);
+int esmdiff_metrics_validity(const double* ca, int32_t n, int32_t L, double ca_vdw_radius, double allowable_overlap,
+                             int32_t k_exclusion, double* out, void* stream);
+int esmdiff_metrics_bonding_validity(const double* ca_model, int32_t n_model, const double* ca_ref, int32_t n_ref,
+                                     int32_t L, double* out, void* stream);
+
 /* Accumulated per-section device time of the esmdiff_forward_logits/ddpm_sample calls since profiling was
  * enabled: esmdiff_set_profiling(eng, 1) brackets every launch with HIP events on the launch stream (no sync);
  * mode 2 brackets only the dominant kernel (FFN-up GEMM, section 6), cheap enough for a timed region; 0 = off. sections: 0 embed, 1 layernorm, 2 gemm_qkv,

@@ -25,6 +25,9 @@ Parts
                    GeometricReasoningOriginalImpl (call sites net.py:433-441, :468).
                    PARITY UNPINNED; checked for what must hold regardless (rigid-motion invariance, exact
                    zero branch without coordinates, frameless residues inert: tests/test_geom_cpu.py).
+  metrics_ref.py   numpy restatement of the ensemble metrics of eval_utils.py (js_pwd, js_rg, validity,
+                   bonding_validity, with numpy.histogram / scipy jensenshannon written out).  PINNED: reproduces
+                   tests/golden/g9_metrics.npz (made by the reference's own functions) to 1e-16.
   decoder_ref.py   torch restatement of esm's StructureTokenDecoder backbone path (embed -> block stack ->
                    Dim6RotStructureHead; call site sample_esmdiff.py:40-61).  PARITY UNPINNED.
 """
