@@ -40,7 +40,8 @@ EXPORTS = [
     "esmdiff_gemm_bf16_timed", "esmdiff_layernorm_bf16", "esmdiff_attention_bf16", "esmdiff_set_profiling",
     "esmdiff_get_profile", "esmdiff_set_frames", "esmdiff_gemm_bf16_ws", "esmdiff_decoder_create",
     "esmdiff_decoder_decode", "esmdiff_metrics_js_pwd", "esmdiff_metrics_js_rg", "esmdiff_metrics_validity",
-    "esmdiff_metrics_bonding_validity",
+    "esmdiff_metrics_bonding_validity", "esmdiff_encoder_create", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error",
+    "esmdiff_encoder_encode",
 ]
 
 
@@ -85,9 +86,15 @@ def lib():
     L.esmdiff_metrics_js_rg.argtypes = [vp, i32, vp, i32, i32, i32, f64p, vp]
     L.esmdiff_metrics_validity.argtypes = [vp, i32, i32, f64, f64, i32, f64p, vp]
     L.esmdiff_metrics_bonding_validity.argtypes = [vp, i32, vp, i32, i32, f64p, vp]
+    L.esmdiff_encoder_create.argtypes = [i32] * 8 + [ctypes.POINTER(Weight), i32, i32, ctypes.POINTER(vp)]
+    L.esmdiff_encoder_destroy.argtypes = [vp]
+    L.esmdiff_encoder_destroy.restype = None
+    L.esmdiff_encoder_last_error.argtypes = [vp]
+    L.esmdiff_encoder_last_error.restype = ctypes.c_char_p
+    L.esmdiff_encoder_encode.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.esmdiff_gemm_bf16_ws.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     for n in EXPORTS:
-        if n not in ("esmdiff_engine_destroy", "esmdiff_last_error"):
+        if n not in ("esmdiff_engine_destroy", "esmdiff_last_error", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error"):
             getattr(L, n).restype = ctypes.c_int
     if L.esmdiff_abi_version() != 1:
         raise RuntimeError("libesmdiff_hip.so ABI version mismatch")

@@ -25,6 +25,7 @@ UNITS = {
     "gemm": [],
     "gemm256": [],
     "geom": [],
+    "encoder": [],
     "attention": [],
     "norm": [],
     "embed": [],

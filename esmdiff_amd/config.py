@@ -49,3 +49,24 @@ class DecoderConfig:
 
 STRUCTURE_DECODER_V0 = DecoderConfig()
 TINY_DECODER = DecoderConfig(d_model=768, n_heads=12, n_layers=2)   # 768: exercises the half-slab q/k LayerNorm path
+
+
+@dataclass(frozen=True)
+class EncoderConfig:
+    """esm StructureTokenEncoder(d_model=1024, n_heads=1, v_heads=128, n_layers=2, d_out=128, n_codes=4096) as ESM3.encode
+    reaches it (/root/reference/slm/models/utils.py:136-137) [ESM-RECALL, SURVEY.md 8f-4]."""
+    d_model: int = 1024
+    v_heads: int = 128
+    n_layers: int = 2
+    d_out: int = 128
+    n_codes: int = 4096
+    knn: int = 16
+    relpos_bins: int = 32
+
+    @property
+    def ffn_hidden(self) -> int:       # swiglu_ln_ffn(d, expansion_ratio=4)
+        return int(((4.0 * self.d_model) + 255) // 256 * 256)
+
+
+STRUCTURE_ENCODER_V0 = EncoderConfig()
+TINY_ENCODER = EncoderConfig(d_model=512, n_layers=2)

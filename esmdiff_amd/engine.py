@@ -282,6 +282,61 @@ class StructureDecoder:
         return out[:, 1:-1]
 
 
+class StructureEncoder:
+    """Backbone coordinates -> structure tokens on the device (esmdiff_encoder_create / esmdiff_encoder_encode): what the
+    reference gets from `model.encode(ESMProtein(coordinates=...))`, /root/reference/slm/models/utils.py:136-137."""
+
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], device: int = 0):
+        _require_gpu()
+        self.cfg = cfg
+        self.device = torch.device("cuda", device)
+        self._lib = N.lib()
+        self._h = ctypes.c_void_p(0)
+        keep, table = [], (N.Weight * len(state_dict))()
+        with torch.cuda.device(self.device):
+            for i, (name, t) in enumerate(state_dict.items()):
+                if t.dtype not in (torch.float32, torch.bfloat16):
+                    t = t.float()
+                d = t.detach().to(self.device).contiguous()
+                keep.append(d)
+                shape = (ctypes.c_int64 * 4)(*(list(d.shape) + [0] * (4 - d.dim())))
+                table[i] = N.Weight(name.encode(), d.data_ptr(), N.DT_F32 if d.dtype == torch.float32 else N.DT_BF16,
+                                    d.dim(), shape)
+            torch.cuda.synchronize()
+            code = self._lib.esmdiff_encoder_create(cfg.d_model, cfg.v_heads, cfg.n_layers, cfg.ffn_hidden, cfg.d_out,
+                                                    cfg.n_codes, cfg.knn, cfg.relpos_bins, table, len(state_dict), device,
+                                                    ctypes.byref(self._h))
+        if code != 0:
+            raise RuntimeError(f"esmdiff_encoder_create failed ({code}): {self._lib.esmdiff_encoder_last_error(None).decode()}")
+        del keep
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.esmdiff_encoder_destroy(self._h)
+            self._h = ctypes.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def encode(self, coordinates: torch.Tensor) -> torch.Tensor:
+        """coordinates (B, L, >=3, 3) with N, CA, C first (NaN / Inf where unknown) -> structure tokens (B, L) int64 on the
+        device; MASK (4096) where a residue has no coordinates.  BOS / EOS are the caller's to add."""
+        from .geometry import build_affine3d_from_coordinates
+        rot, trans, has = build_affine3d_from_coordinates(coordinates)
+        B, L = has.shape
+        ca = torch.where(has[..., None], coordinates[..., 1, :].to(torch.float32), torch.zeros(B, L, 3))
+        dev = lambda t, dt: t.to(device=self.device, dtype=dt).contiguous()  # noqa: E731
+        ca, rot, trans, hm = dev(ca, torch.float32), dev(rot, torch.float32), dev(trans, torch.float32), dev(has, torch.uint8)
+        tok = torch.empty(B, L, dtype=torch.int64, device=self.device)
+        code = self._lib.esmdiff_encoder_encode(self._h, _ptr(ca), _ptr(rot), _ptr(trans), _ptr(hm), _ptr(tok), B, L, _stream())
+        if code != 0:
+            raise RuntimeError(f"esmdiff_encoder_encode failed ({code}): {self._lib.esmdiff_encoder_last_error(self._h).decode()}")
+        return tok
+
+
 def gemm_bf16(A: torch.Tensor, W: torch.Tensor, epilogue: int, *, out: Optional[torch.Tensor] = None,
               bias: Optional[torch.Tensor] = None, alpha: float = 1.0, n_valid: Optional[int] = None) -> torch.Tensor:
     """out = epilogue(A[M,K] @ W[N,K]^T) through esmdiff_gemm_bf16 (N % 128 == 0, K % 64 == 0)."""

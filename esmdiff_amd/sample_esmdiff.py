@@ -74,7 +74,7 @@ def decode_to_pdb(tokens: torch.Tensor, sequence: str, decoder, save_to: Path, s
 def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: str, num_samples: int = 5,
                        num_steps: int = 10, eps: float = 1e-5, n_max_residue_square: int = DEFAULT_NMAX,
                        coordinates=None, mask_ids=None, structure_tokens=None, sample_max_t: float = 1.0,
-                       seed: int = 0, noise: str = "philox", timestamp: bool = True, decoder=None):
+                       seed: int = 0, noise: str = "philox", timestamp: bool = True, decoder=None, encoder=None):
     """sample_esmdiff.py:137-233.  With a `decoder` (esmdiff_amd.engine.StructureDecoder) rank 0 also writes the reference's
     artefact, `<basename>.pdb` with one MODEL per sample; the token file is written either way.  `structure_tokens` (L+2, with BOS/EOS) replaces what the reference gets from
     ESM3.encode(coordinates) for the inpainting prior (:196-201); without it mask_ids cannot be honoured."""
@@ -89,8 +89,17 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
     if save_to.exists():
         print(f"Skip existing {save_to}")
         return None
+    if mask_ids is not None and structure_tokens is None and coordinates is not None and encoder is not None:
+        # protseq_to_data (models/utils.py:116-137): the masked residues lose their coordinates, the rest is tokenised by
+        # the VQ-VAE encoder; BOS / EOS as esm's tokenizer adds them
+        xyz = torch.as_tensor(coordinates, dtype=torch.float32).clone()
+        for idx in mask_ids:
+            assert 0 <= idx < len(sequence), f"Invalid mask index {idx} for sequence of length {len(sequence)}"
+            xyz[idx] = float("Inf")
+        body = encoder.encode(xyz[None, :, :3, :])[0].cpu()
+        structure_tokens = torch.cat([torch.tensor([C.STRUCTURE_BOS_TOKEN]), body, torch.tensor([C.STRUCTURE_EOS_TOKEN])])
     if mask_ids is not None:
-        assert structure_tokens is not None, "Need structure tokens of the known residues for masking"
+        assert structure_tokens is not None, "Need structure tokens of the known residues (or coordinates + an encoder) for masking"
         seq_l = list(sequence)
         for idx in mask_ids:
             assert 0 <= idx < len(seq_l), f"Invalid mask index {idx} for sequence of length {len(seq_l)}"
@@ -212,6 +221,10 @@ def get_argparser(argv=None):
                    help="state dict of esm's StructureTokenDecoder (esm3_structure_decoder_v0): also write <name>.pdb "
                         "with one MODEL per sample, as the reference does; without it only <name>.tokens.npy is written")
     p.add_argument("--random_init_decoder", action="store_true", help="random decoder weights (plumbing / tests)")
+    p.add_argument("--encoder_ckpt", type=str, default=None,
+                   help="state dict of esm's StructureTokenEncoder (esm3_structure_encoder_v0): lets --mode ddpm --mask_ids "
+                        "build its prior from the input PDB's coordinates, as the reference does")
+    p.add_argument("--random_init_encoder", action="store_true", help="random encoder weights (plumbing / tests)")
     p.add_argument("--synthetic_len", type=int, default=0, help="sample a random sequence of this length")
     p.add_argument("--n_max_residue_square", type=int, default=DEFAULT_NMAX)
     p.add_argument("--parity", action="store_true", help="uniforms from torch's CPU generator, like the reference")
@@ -236,10 +249,10 @@ def main(argv=None):
             "Only Gibbs sampling is supported for the pre-trained ESM3 model."
         raise SystemExit("no weights: pass --ckpt <release_v0.pt> or --random_init (synthetic weights)")
     mask_ids = [int(i) for i in args.mask_ids.split(",")] if args.mask_ids else None   # 0-based index
-    if mask_ids is not None and args.mode == "ddpm":
-        raise SystemExit("--mode ddpm --mask_ids needs structure tokens of the known residues, i.e. the VQ-VAE encoder "
-                         "(SURVEY.md 8f-4); call ddpm_sample_by_esm(structure_tokens=...) from Python, or use the "
-                         "default gibbs mode, which conditions on the coordinates directly")
+    if mask_ids is not None and args.mode == "ddpm" and not (args.encoder_ckpt or args.random_init_encoder):
+        raise SystemExit("--mode ddpm --mask_ids builds its prior with the VQ-VAE structure encoder: pass --encoder_ckpt "
+                         "<StructureTokenEncoder state dict> (or call ddpm_sample_by_esm(structure_tokens=...) from Python, "
+                         "or use the default gibbs mode, which conditions on the coordinates directly)")
     from .model import load_state_dict_from_lightning_ckpt, random_init_model
 
     targets, coords_of = [], {}
@@ -275,6 +288,15 @@ def main(argv=None):
         else:
             dsd = random_init_decoder_state_dict(dcfg, seed=args.seed, device=f"cuda:{local_rank}")
         decoder = StructureDecoder(dcfg, dsd, max_batch=64, max_len=max_len, device=local_rank)
+    encoder = None
+    if args.encoder_ckpt or args.random_init_encoder:
+        from .config import STRUCTURE_ENCODER_V0, TINY_ENCODER
+        from .engine import StructureEncoder
+        from .weights import random_init_encoder_state_dict
+        ecfg = TINY_ENCODER if args.tiny else STRUCTURE_ENCODER_V0
+        esd = (torch.load(args.encoder_ckpt, map_location="cpu", weights_only=True) if args.encoder_ckpt
+               else random_init_encoder_state_dict(ecfg, seed=args.seed, device=f"cuda:{local_rank}"))
+        encoder = StructureEncoder(ecfg, esd, device=local_rank)
     if rank == 0:
         print(f">>> Sampling mode = {args.mode} ...")
     for name, seq in targets:
@@ -289,6 +311,8 @@ def main(argv=None):
         else:
             ddpm_sample_by_esm(seq, model, Path(args.output), name, num_samples=args.num_samples,
                                num_steps=args.num_steps, n_max_residue_square=args.n_max_residue_square,
+                               coordinates=coords_of.get(name) if mask_ids is not None else None, mask_ids=mask_ids,
+                               encoder=encoder,
                                seed=args.seed, noise="torch-cpu" if args.parity else "philox",
                                timestamp=not args.no_timestamp, decoder=decoder)
     if world > 1:

@@ -114,6 +114,36 @@ def random_init_decoder_state_dict(cfg, seed: int = 0, device: str = "cpu") -> D
     return sd
 
 
+def random_init_encoder_state_dict(cfg, seed: int = 0, device: str = "cpu") -> Dict[str, torch.Tensor]:
+    """Random weights with the key layout of esm's StructureTokenEncoder — tests / offline plumbing."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    D, FH, VH = cfg.d_model, cfg.ffn_hidden, cfg.v_heads
+
+    def randn(*shape):
+        return torch.randn(*shape, generator=g, device=device)
+
+    def linear(out_f, in_f):
+        bound = 1.0 / math.sqrt(in_f)
+        return ((torch.rand(out_f, in_f, generator=g, device=device) * 2 - 1) * bound,
+                (torch.rand(out_f, generator=g, device=device) * 2 - 1) * bound)
+
+    sd: Dict[str, torch.Tensor] = {"relative_positional_embedding.embedding.weight": randn(2 * cfg.relpos_bins + 2, D)}
+    for i in range(cfg.n_layers):
+        b = f"transformer.blocks.{i}."
+        sd[b + "geom_attn.s_norm.weight"] = 1.0 + 0.1 * randn(D)
+        sd[b + "geom_attn.proj.weight"], sd[b + "geom_attn.proj.bias"] = linear(15 * VH, D)
+        sd[b + "geom_attn.out_proj.weight"], sd[b + "geom_attn.out_proj.bias"] = linear(D, 3 * VH)
+        sd[b + "geom_attn.out_proj.weight"] *= 8.0     # let the geometry dominate the (residue-independent) offset
+        sd[b + "geom_attn.distance_scale_per_head"] = 0.5 * randn(VH)
+        sd[b + "geom_attn.rotation_scale_per_head"] = 0.5 * randn(VH)
+        sd[b + "ffn.0.weight"], sd[b + "ffn.0.bias"] = 1.0 + 0.1 * randn(D), 0.05 * randn(D)
+        sd[b + "ffn.1.weight"], sd[b + "ffn.1.bias"] = linear(2 * FH, D)
+        sd[b + "ffn.3.weight"], sd[b + "ffn.3.bias"] = linear(D, FH)
+    sd["pre_vq_proj.weight"], sd["pre_vq_proj.bias"] = linear(cfg.d_out, D)
+    sd["codebook.embeddings"] = randn(cfg.n_codes, cfg.d_out) * 0.3
+    return sd
+
+
 def load_checkpoint_state_dict(path) -> Dict[str, torch.Tensor]:
     """The reference's format (checkpoint_utils.py:41-64): a .pt whose 'module' entry is the state dict."""
     path = Path(path)

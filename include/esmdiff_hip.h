@@ -207,6 +207,27 @@ int esmdiff_decoder_create(const esmdiff_config* cfg, const esmdiff_weight* tabl
 int esmdiff_decoder_decode(esmdiff_engine* dec, const int64_t* tokens, float* bb_coords, int32_t B, int32_t L,
                            float trans_scale, void* stream);
 
+/* VQ-VAE structure-token ENCODER: backbone frames -> structure tokens.  Replaces `model.encode(ESMProtein(coordinates))`
+ * as protseq_to_data calls it for the DDPM inpainting prior (/root/reference/slm/models/utils.py:136-137,
+ * /root/reference/slm/sample_esmdiff.py:196-201).  esm's StructureTokenEncoder [ESM-RECALL, SURVEY.md 8f-4]: 16 nearest
+ * residues per residue -> relative-position embedding -> 2 x (geometric attention + SwiGLU FFN, with biases) per
+ * neighbourhood -> Linear(d, 128) -> nearest of 4096 codebook vectors.  esm3_structure_encoder_v0: d_model 1024, v_heads
+ * 128, n_layers 2, ffn_hidden 4096, d_out 128, n_codes 4096, knn 16, relpos_bins 32.  Weight names:
+ * relative_positional_embedding.embedding.weight, transformer.blocks.{i}.geom_attn.{s_norm.weight, proj.{weight,bias},
+ * out_proj.{weight,bias}, rotation_scale_per_head, distance_scale_per_head}, transformer.blocks.{i}.ffn.{0,1,3}.{weight,
+ * bias}, pre_vq_proj.{weight,bias}, codebook.embeddings.
+ * encode: ca f32 [B,L,3] (CA positions), rot f32 [B,L,3,3], trans f32 [B,L,3], has_frame u8 [B,L] (the frames of
+ * esmdiff_set_frames; residues WITHOUT BOS/EOS) -> tokens int64 [B,L] (device), 4096 (MASK) where has_frame == 0.
+ * Synchronises `stream` before returning. */
+typedef struct esmdiff_encoder esmdiff_encoder;
+int esmdiff_encoder_create(int32_t d_model, int32_t v_heads, int32_t n_layers, int32_t ffn_hidden, int32_t d_out,
+                           int32_t n_codes, int32_t knn, int32_t relpos_bins, const esmdiff_weight* table,
+                           int32_t n_weights, int32_t device, esmdiff_encoder** out);
+void esmdiff_encoder_destroy(esmdiff_encoder* enc);
+const char* esmdiff_encoder_last_error(const esmdiff_encoder* enc);
+int esmdiff_encoder_encode(esmdiff_encoder* enc, const float* ca, const float* rot, const float* trans,
+                           const uint8_t* has_frame, int64_t* tokens, int32_t B, int32_t L, void* stream);
+
 /* Ensemble metrics on CA traces (float64, device pointers in, one double out on the host; each call synchronises
  * `stream`).  They replace the numpy / scipy functions of /root/reference/slm/utils/eval_utils.py that score a generated
  * ensemble against a reference ensemble: js_pwd :227-255 (Jensen-Shannon distance of the per-pair CA distance

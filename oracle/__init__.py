@@ -28,6 +28,8 @@ Parts
   metrics_ref.py   numpy restatement of the ensemble metrics of eval_utils.py (js_pwd, js_rg, validity,
                    bonding_validity, with numpy.histogram / scipy jensenshannon written out).  PINNED: reproduces
                    tests/golden/g9_metrics.npz (made by the reference's own functions) to 1e-16.
+  encoder_ref.py   torch restatement of esm's StructureTokenEncoder (kNN neighbourhoods -> geometric blocks ->
+                   codebook; call site models/utils.py:136-137).  PARITY UNPINNED; rigid-motion invariance checked.
   decoder_ref.py   torch restatement of esm's StructureTokenDecoder backbone path (embed -> block stack ->
                    Dim6RotStructureHead; call site sample_esmdiff.py:40-61).  PARITY UNPINNED.
 """

@@ -414,6 +414,41 @@ def test_structure_decoder_vs_oracle(B, L):
     dec.close()
 
 
+@pytest.mark.parametrize("B,L", [(2, 40), (1, 131), (3, 9)])
+def test_structure_encoder_vs_oracle(B, L):
+    """Coordinates -> structure tokens (esmdiff_encoder_create / _encode: kNN neighbourhoods, relative-position embedding,
+    two geometric-attention + FFN blocks with biases, codebook lookup) against oracle/encoder_ref.py, with unknown
+    residues; and what holds whatever esm's exact details are: tokens do not change under a rigid motion of the input."""
+    from esmdiff_amd.config import TINY_ENCODER
+    from esmdiff_amd.engine import StructureEncoder
+    from esmdiff_amd.weights import random_init_encoder_state_dict
+    from oracle.encoder_ref import build_encoder_from_state_dict
+    sd = random_init_encoder_state_dict(TINY_ENCODER, seed=1)
+    ref_net = build_encoder_from_state_dict(TINY_ENCODER, sd)
+    g = torch.Generator().manual_seed(B * 100 + L)
+    ca = torch.cumsum(torch.randn(B, L, 3, generator=g) * 2.2, 1)
+    xyz = torch.stack([ca + torch.randn(B, L, 3, generator=g) * 0.8, ca, ca + torch.randn(B, L, 3, generator=g) * 0.8], 2)
+    if L > 12:
+        xyz[0, 5:8] = float("inf")
+        xyz[-1, L - 2] = float("nan")
+    with torch.no_grad():
+        ref = ref_net(xyz)
+    enc = StructureEncoder(TINY_ENCODER, sd)
+    got = enc.encode(xyz).cpu()
+    assert got.shape == ref.shape == (B, L)
+    assert torch.equal(got == MASK, ref == MASK)
+    # nearest-code lookups after bf16 GEMMs: the same code except where two codes are almost equally near
+    agree = float((got == ref).float().mean())
+    assert agree > 0.85, agree
+    assert len(set(ref.flatten().tolist())) > min(8, L // 2)            # the fixture is not degenerate
+    A = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    if torch.det(A) < 0:
+        A[:, 0] = -A[:, 0]
+    moved = enc.encode(xyz @ A.T + torch.tensor([12.0, -40.0, 7.0])).cpu()
+    assert float((moved == got).float().mean()) > 0.9
+    enc.close()
+
+
 def test_two_stream_forward_is_bitwise_identical(tiny, monkeypatch):
     """The engine runs the two halves of a large batch on two HIP streams (engine.hip::forward).  Samples are
     independent and every kernel's per-row arithmetic does not depend on the tiling, so logits and sampled ids must
@@ -702,9 +737,28 @@ def test_cli_gibbs_inpainting_from_pdb(tmp_path):
         assert ids.shape == (3, len(seq)) and ids.min() >= 0 and ids.max() < 4096
         outs.append(ids)
     assert (outs[0] != outs[1]).mean() > 0.3
-    with pytest.raises(SystemExit, match="ddpm"):
+    with pytest.raises(SystemExit, match="encoder"):
         main(["--random_init", "--input", str(tmp_path / "in0"), "--mode", "ddpm", "--mask_ids", "1,2", "--output",
               str(tmp_path / "o"), "--tiny"])
+    # DDPM inpainting as the reference does it (sample_esmdiff.py:166-201): the encoder tokenises the known backbone, the
+    # masked residues (and, by the reference's token-space quirk, their left neighbours) are re-sampled, the rest is kept
+    from esmdiff_amd.config import TINY_ENCODER
+    from esmdiff_amd.engine import StructureEncoder
+    from esmdiff_amd.pdbio import read_pdb_backbone
+    from esmdiff_amd.weights import random_init_encoder_state_dict
+    main(["--random_init", "--tiny", "--random_init_encoder", "--input", str(tmp_path / "in0"), "--mode", "ddpm",
+          "--mask_ids", "10,11,12,13", "--num_samples", "3", "--num_steps", "5", "--output", str(tmp_path / "od"),
+          "--no_timestamp", "--seed", "4"])
+    ids = np.load(tmp_path / "od" / "step5_eps1e-05_N3" / "toy.tokens.npy")
+    _, xyz = read_pdb_backbone(tmp_path / "in0" / "toy.pdb")
+    enc = StructureEncoder(TINY_ENCODER, random_init_encoder_state_dict(TINY_ENCODER, seed=4, device="cuda:0"))
+    xyz = torch.from_numpy(xyz).float()
+    xyz[10:14] = float("inf")              # protseq_to_data removes the masked residues' coordinates before encoding
+    known = enc.encode(xyz[None])[0].cpu().numpy()
+    enc.close()
+    keep = np.ones(len(seq), bool)
+    keep[9:14] = False                     # residues 10-13 (coordinates removed) and residue 9 (token index 10)
+    assert ids.shape == (3, len(seq)) and (ids[:, keep] == known[keep]).all() and ids.max() < 4096
 
 
 # ---------------------------------------------------------------------------------------------------
