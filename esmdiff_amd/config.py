@@ -29,6 +29,9 @@ class ModelConfig:
 
 
 ESM3_OPEN = ModelConfig()
+# the stock esm3_sm_open_v1 network the reference samples from when no --ckpt is given (sample_esmdiff.py:37, :252-255):
+# 4096-way structure head, no time conditioning
+ESM3_OPEN_STOCK = ModelConfig(n_structure_heads=4096, time_conditioning=False)
 # small configuration with the same structure, for tests (d_model must be a multiple of 512)
 TINY = ModelConfig(d_model=512, n_heads=8, v_heads=128, n_layers=2)  # v_heads: the engine needs a multiple of 128
 

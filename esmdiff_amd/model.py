@@ -100,6 +100,17 @@ def load_state_dict_from_lightning_ckpt(ckpt_path, device="cuda", max_batch: int
     return model
 
 
+def load_stock_esm3(path, device="cuda", max_batch: int = 128, max_len: int = 1026):
+    """The pre-trained ESM3 the reference uses when --ckpt is absent (`ESM3.from_pretrained("esm3_sm_open_v1")`,
+    /root/reference/slm/sample_esmdiff.py:37, :252-255; gibbs mode only): a plain esm state dict (keys without the
+    `net.` prefix, 4096-way structure head, no sigma_embedder) saved with torch.save."""
+    from .config import ESM3_OPEN_STOCK
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
+    dev = torch.device(device).index or 0
+    return MaskedDiffusionLanguageModeling(sd, ESM3_OPEN_STOCK, None, max_batch, max_len, dev, noise_removal=True)
+
+
 def random_init_model(cfg: ModelConfig = ESM3_OPEN, seed: int = 0, max_batch: int = 128, max_len: int = 1026,
                       device: int = 0):
     """ESM3-open-sized random weights (no checkpoint can be fetched offline): synthetic benchmarking / tests."""

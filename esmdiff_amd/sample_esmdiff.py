@@ -216,6 +216,9 @@ def get_argparser(argv=None):
     p.add_argument("--mask_ids", type=str, default=None, help="Comma-separated list of masked indices.")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--random_init", action="store_true", help="ESM3-open-sized random weights instead of --ckpt")
+    p.add_argument("--esm3_ckpt", type=str, default=None,
+                   help="state dict of the stock esm3_sm_open_v1 model (torch.save): what the reference samples from in gibbs "
+                        "mode when --ckpt is absent (it downloads it; this engine cannot)")
     p.add_argument("--tiny", action="store_true", help=argparse.SUPPRESS)   # tests: 2-block model with --random_init
     p.add_argument("--decoder_ckpt", type=str, default=None,
                    help="state dict of esm's StructureTokenDecoder (esm3_structure_decoder_v0): also write <name>.pdb "
@@ -242,12 +245,15 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    if args.ckpt is None and not args.random_init:
+    if args.ckpt is None and not args.random_init and not args.esm3_ckpt:
         # the reference falls back to the stock esm3_sm_open_v1 weights in gibbs mode (sample_esmdiff.py:252-255);
         # they cannot be fetched offline, so a checkpoint (or --random_init) is required in both modes here
         assert args.mode == "gibbs" or args.ckpt is not None, \
             "Only Gibbs sampling is supported for the pre-trained ESM3 model."
-        raise SystemExit("no weights: pass --ckpt <release_v0.pt> or --random_init (synthetic weights)")
+        raise SystemExit("no weights: pass --ckpt <release_v0.pt>, --esm3_ckpt <esm3_sm_open_v1 state dict> (gibbs mode) or "
+                         "--random_init (synthetic weights)")
+    if args.esm3_ckpt and args.ckpt is None:
+        assert args.mode == "gibbs", "Only Gibbs sampling is supported for the pre-trained ESM3 model."
     mask_ids = [int(i) for i in args.mask_ids.split(",")] if args.mask_ids else None   # 0-based index
     if mask_ids is not None and args.mode == "ddpm" and not (args.encoder_ckpt or args.random_init_encoder):
         raise SystemExit("--mode ddpm --mask_ids builds its prior with the VQ-VAE structure encoder: pass --encoder_ckpt "
@@ -274,6 +280,9 @@ def main(argv=None):
         from .config import ESM3_OPEN, TINY
         model = random_init_model(TINY if args.tiny else ESM3_OPEN, seed=args.seed, max_batch=max_b, max_len=max_len,
                                   device=local_rank)
+    elif args.ckpt is None:
+        from .model import load_stock_esm3
+        model = load_stock_esm3(args.esm3_ckpt, device=f"cuda:{local_rank}", max_batch=max_b, max_len=max_len)
     else:
         model = load_state_dict_from_lightning_ckpt(args.ckpt, device=f"cuda:{local_rank}", max_batch=max_b,
                                                     max_len=max_len)

@@ -698,6 +698,29 @@ def test_cli_gibbs_default_mode(tmp_path):
     assert ids.shape == (3, 40) and ids.min() >= 0 and ids.max() < 4096
 
 
+def test_cli_gibbs_with_stock_esm3_state_dict(tmp_path):
+    """Without --ckpt the reference samples from the stock ESM3 (4096-way head, no time conditioning, plain esm keys:
+    sample_esmdiff.py:37, :252-255).  Here the state dict comes from a file (--esm3_ckpt); ddpm mode is refused as there."""
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.sample_esmdiff import main
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ModelConfig(n_layers=2, n_structure_heads=4096, time_conditioning=False)      # ESM3-open width, two blocks
+    sd = {k[len("net."):]: v for k, v in random_init_state_dict(cfg, seed=0).items() if k.startswith("net.")}
+    torch.save(sd, tmp_path / "esm3.pt")
+    import esmdiff_amd.config as C
+    old = C.ESM3_OPEN_STOCK
+    C.ESM3_OPEN_STOCK = cfg
+    try:
+        main(["--esm3_ckpt", str(tmp_path / "esm3.pt"), "--synthetic_len", "24", "--num_samples", "2", "--num_steps", "4",
+              "--output", str(tmp_path), "--no_timestamp"])
+        with pytest.raises(AssertionError, match="Only Gibbs"):
+            main(["--esm3_ckpt", str(tmp_path / "esm3.pt"), "--synthetic_len", "24", "--mode", "ddpm", "--output", str(tmp_path)])
+    finally:
+        C.ESM3_OPEN_STOCK = old
+    ids = np.load(tmp_path / "T1.4_step4_topp0.9_N2" / "synthetic24.tokens.npy")
+    assert ids.shape == (2, 24) and ids.min() >= 0 and ids.max() < 4096
+
+
 def test_cli_writes_multi_model_pdb_with_decoder(tmp_path):
     """The reference's artefact: <basename>.pdb with one MODEL per sample (sample_esmdiff.py:225-231), produced by the
     decoder engine (random weights here) + merge_pdbfiles; readable back with the in-tree PDB reader."""
