@@ -323,10 +323,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 #else
 #define ED_TSTAMP(i) do { } while (0)
 #endif
-  // All tiles take the same time, so without a nudge every CU reaches its epilogue at once and the chip sees a
-  // 16-32 MB store burst per round (s_memtime: epilogue = 10-12 % of a tile).  A start skew of 0..3 x ~2k cycles
-  // between neighbouring workgroups of an XCD spreads the bursts (+1 % measured; 2x the skew: same).
-  for (int i = 0; i < ((bid >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(32);
+  // (A 0-3 x 2k-cycle start skew between neighbouring workgroups paid +1 % while the epilogue went through LDS slabs and
+  // tile-boundary barriers; with the register-direct epilogue it measures -0.5 % and is gone.)
   for (int vt = bid; vt < n_tiles; vt += gridDim.x) {
     const int vtn = vt + gridDim.x;
     ED_TSTAMP(0);
