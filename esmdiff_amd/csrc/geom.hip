@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __rest
                                                            const float* __restrict__ w_rot,
                                                            const float* __restrict__ w_dist, bf16_t* __restrict__ out,
                                                            int L, int VH) {
-  extern __shared__ float kl[];  // [L][10]: k_rot 3 | k_dist 3 | value 3 | has-frame
+  extern __shared__ __attribute__((aligned(16))) float kl[];  // [Lk][12]: k_rot 3 | k_dist 3 | value 3 | has-frame | pad 2  (three 16-byte reads per key)
   const int b = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
   const int ldp = 15 * VH;
   const int64_t row0 = (int64_t)b * L;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __rest
     for (int i = 0; i < 9; ++i) R[i] = rot[row * 9 + i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) t[i] = trans[row * 3 + i];
-    float* k = kl + l * 10;
+    float* k = kl + l * 12;
     load3(row, 3 * VH + 3 * h, v);   // k_rot
     rotate(R, v, o);
     k[0] = o[0]; k[1] = o[1]; k[2] = o[2];
@@ -64,11 +64,12 @@ __global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __rest
     rotate(R, v, o);
     k[6] = o[0]; k[7] = o[1]; k[8] = o[2];
     k[9] = fmask[row] ? 1.0f : 0.0f;
+    k[10] = k[11] = 0.0f;
   }
   for (int l = L + lane; l < Lk; l += 64) {
-    float* k = kl + l * 10;
+    float* k = kl + l * 12;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) k[i] = 0.0f;
+    for (int i = 0; i < 12; ++i) k[i] = 0.0f;
   }
   __syncthreads();
 
@@ -92,9 +93,9 @@ __global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __rest
         float sc[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float* kk = kl + (k + u) * 10;
+          const float* kk = kl + (k + u) * 12;
           const float dx = qd[0] - kk[3], dy = qd[1] - kk[4], dz = qd[2] - kk[5];
-          const float v = wr * (qr[0] * kk[0] + qr[1] * kk[1] + qr[2] * kk[2]) - wd * sqrtf(dx * dx + dy * dy + dz * dz);
+          const float v = wr * (qr[0] * kk[0] + qr[1] * kk[1] + qr[2] * kk[2]) - wd * __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);  // bare v_sqrt_f32 (1 ulp)
           sc[u] = kk[9] != 0.0f ? v : -__builtin_inff();
         }
         const float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __rest
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float* kk = kl + (k + u) * 10;
+          const float* kk = kl + (k + u) * 12;
           const float p = __builtin_amdgcn_exp2f(sc[u] - m);  // bare v_exp_f32; exp2(-inf) = 0 for keys without a frame
           den += p;
           o0 += p * kk[6]; o1 += p * kk[7]; o2 += p * kk[8];
@@ -133,7 +134,7 @@ hipError_t launch_geom_attention(const bf16_t* P, const float* rot, const float*
                                  const float* w_rot, const float* w_dist, bf16_t* out, int B, int L, int VH,
                                  hipStream_t stream) {
   if (B <= 0 || L <= 0) return hipSuccess;
-  const size_t lds = (size_t)((L + 3) & ~3) * 10 * sizeof(float);
+  const size_t lds = (size_t)((L + 3) & ~3) * 12 * sizeof(float);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
   static bool attr_done = false;
   if (!attr_done) {
