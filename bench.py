@@ -55,9 +55,10 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(cfg, sd, L, T, seconds_budget=20.0):
+def cpu_baseline(cfg, sd, L, T, eng=None, seconds_budget=20.0):
     """Oracle on the host cores: whole reverse-diffusion updates (f32 torch forward of the full network +
-    C-oracle sampler) at a small batch, extrapolated to samples/s for a (T+1)-forward run."""
+    C-oracle sampler) at a small batch, extrapolated to samples/s for a (T+1)-forward run.  The oracle's logits of that
+    forward are also the checker for `parity_spot`: the engine's logits on the same tokens, compared once."""
     from esmdiff_amd.schedule import ddpm_schedule
     from oracle import c_oracle
     from oracle.esm3_ref import build_from_state_dict
@@ -79,10 +80,41 @@ def cpu_baseline(cfg, sd, L, T, seconds_budget=20.0):
         n += 1
         el = time.perf_counter() - t0
     per_update = el / n
+    spot = None
+    if eng is not None:
+        got = eng.forward_logits(x.to(eng.device), seq.to(eng.device), sch.t_freq[0]).float().cpu()
+        err = (got - lg).abs()
+        spot = {"what": f"engine (bf16 MFMA) vs oracle (f32 torch) logits of ONE forward of the full {cfg.n_layers}-block model, "
+                        f"B={Bc}, L_tok={L}, all positions masked, sigma of step 0",
+                "max_abs_logit_err": round(float(err.max()), 5), "mean_abs_logit_err": round(float(err.mean()), 6),
+                "logit_std": round(float(lg.std()), 4),
+                "cosine": round(float(torch.nn.functional.cosine_similarity(got.flatten().double(), lg.flatten().double(), dim=0)), 6),
+                "argmax_agreement": round(float((got.argmax(-1) == lg.argmax(-1)).float().mean()), 4)}
     return {"value": Bc / (per_update * (T + 1)), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{n} whole reverse-diffusion update(s) (f32 torch forward of all {cfg.n_layers} blocks + C "
                       f"sampler) at B={Bc}, L_tok={L}: {per_update:.2f} s each; samples/s = B / ({T + 1} x that)",
-            "cpu_count": os.cpu_count()}
+            "cpu_count": os.cpu_count()}, spot
+
+
+def workload_name(args, world):
+    """Which BASELINE.json configuration the arguments actually are (never a fixed label)."""
+    R, B, T = args.residues, args.samples_per_gpu, args.num_steps
+    base = f"{R}-residue synthetic sequence, num_steps={T}, num_samples={B}/GPU, ESM3-open-sized random-init weights, bf16 MFMA"
+    if args.tiny:
+        return "debug: tiny model, " + base
+    if args.mode == "ddpm" and not args.inpaint and (R, B, T) == (256, 100, 25):
+        if world == 1:
+            return "BASELINE configs[1]: single MI355X, " + base
+        return (f"BASELINE configs[2]{'' if world == 8 else ' scaling series'}: {world}xMI355X, {B * world} samples sharded "
+                f"{B}/GPU, one RCCL all_gather of the ids at the end, ") + base
+    if args.mode == "ddpm" and not args.inpaint and world == 1 and (R, B, T) == (1024, 32, 25):
+        return "BASELINE configs[3]: single MI355X, 1024-residue long chain, " + base
+    if args.mode == "ddpm" and args.inpaint and world == 1 and (R, B, T) == (256, 100, 50):
+        return f"BASELINE configs[4]: single MI355X, inpainting prior with residues {args.inpaint} masked (partial-mask resample), " + base
+    if args.mode == "ddpm" and not args.inpaint and world == 1 and (R, B, T) == (58, 4, 25):
+        return "BASELINE configs[0] shape on the GPU (BPTI length, 4 samples), " + base
+    return (f"not a BASELINE configuration: mode={args.mode}" + (f", inpaint {args.inpaint}" if args.inpaint else "")
+            + f", {world} GPU(s), " + base)
 
 
 def main():
@@ -231,17 +263,17 @@ def main():
                 traffic, traffic_note = rec["traffic_bytes_per_launch"], ("profiles/r01_gemm_traffic.json: FETCH_SIZE x2 "
                                                                            "(gfx950 correction) + WRITE_SIZE, fabric-level")
         out = {
-            "metric": "conformation samples/sec (256-res, 25 steps)" if args.mode == "ddpm" else "conformation samples/sec (gibbs mode)",
+            "metric": ("conformation samples/sec (256-res, 25 steps)" if (args.mode, args.residues, T) == ("ddpm", 256, 25) and not args.inpaint
+                       else f"conformation samples/sec ({args.residues}-res, {T} steps, {args.mode}{', inpaint' if args.inpaint else ''})"),
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic" if not args.tiny else "debug-tiny-model",
-            "config": {"workload": f"BASELINE configs[{4 if args.inpaint else 1}]: single MI355X, {args.residues}-residue synthetic sequence, "
-                                   f"num_steps={T}, num_samples={B}/GPU, ESM3-open-sized random-init weights, bf16 MFMA"
-                                   + (f", inpainting prior with residues {args.inpaint} masked" if args.inpaint else ""),
+            "config": {"workload": workload_name(args, world),
                        "samples_per_gpu": B, "L_tok": L, "num_steps": T, "forwards_per_sample": n_fwd_sample, "mode": args.mode,
                        "layers": cfg.n_layers, "d_model": cfg.d_model, "noise": "philox4x32-10",
-                       "parallelism": f"sample-sharded x{world}, one RCCL all_gather of int16 ids"},
+                       "parallelism": (f"sample-sharded x{world}, one RCCL all_gather of int16 ids per step" if use_dist else
+                                       "single process, one GPU, no process group (nothing crosses RCCL at N=1)")},
             "flop_per_sample": f_sample,
             "mfma_frac_whole_job": round(value / world * f_sample / (PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": {"bound": "mfma", "kernel": "g256::gemm256_kernel<SWIGLU> (FFN-up, M=%d N=%d K=%d)" % (M // parts, 2 * cfg.ffn_hidden, cfg.d_model),
@@ -262,7 +294,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, sd, L, T)
+                out["cpu_baseline"], out["parity_spot"] = cpu_baseline(cfg, sd, L, T, eng)
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out))

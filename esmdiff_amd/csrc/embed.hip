@@ -20,9 +20,12 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
                                                     float* __restrict__ out, int M, int D) {
   const int row = blockIdx.x;
   if (row >= M) return;
-  const int64_t s = seq[row];
+  // ids are validated by the host wrapper (Engine._check_ids); a direct C-ABI caller's out-of-range id is clamped
+  // here so that it can never read outside the embedding tables
+  const int64_t s = min(max(seq[row], (int64_t)0), (int64_t)63);
   int64_t t = xtok[row];
   if (t == -1) t = ESMDIFF_MASK_ID;
+  t = min(max(t, (int64_t)0), (int64_t)(ESMDIFF_VOCAB - 1));
   if (s == 0) t = ESMDIFF_STRUCT_BOS;          // SEQUENCE_BOS
   if (s == 1) t = ESMDIFF_STRUCT_PAD;          // SEQUENCE_PAD
   if (s == 2) t = ESMDIFF_STRUCT_EOS;          // SEQUENCE_EOS
@@ -132,6 +135,29 @@ __global__ __launch_bounds__(256) void dim6_to_backbone_kernel(const float* __re
   for (int a = 0; a < 3; ++a)
 #pragma unroll
     for (int i = 0; i < 3; ++i) o[a * 3 + i] = e0[i] * bb[a][0] + e1[i] * bb[a][1] + e2[i] * bb[a][2] + t[i];
+}
+
+// plddt_mean: esm's CategoricalMixture(plddt_logits, bins).mean() [ESM-RECALL]: softmax over the n_bins logits of a row
+// times the bin centres (i + 0.5) / n_bins of [0, 1].  One thread per row (n_bins = 50).
+__global__ __launch_bounds__(256) void plddt_mean_kernel(const float* __restrict__ v, int ld, int n_bins, float* __restrict__ out, int M) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= M) return;
+  const float* p = v + (int64_t)row * ld;
+  float m = p[0];
+  for (int i = 1; i < n_bins; ++i) m = fmaxf(m, p[i]);
+  float s = 0.f, a = 0.f;
+  for (int i = 0; i < n_bins; ++i) {
+    const float e = expf(p[i] - m);
+    s += e;
+    a += e * ((float)i + 0.5f) / (float)n_bins;
+  }
+  out[row] = a / s;
+}
+
+hipError_t launch_plddt_mean(const float* v, int ld, int n_bins, float* out, int M, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(plddt_mean_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, v, ld, n_bins, out, M);
+  return hipGetLastError();
 }
 
 hipError_t launch_dim6_to_backbone(const float* v, int ld, float* out, int M, float trans_scale, hipStream_t stream) {

@@ -55,6 +55,11 @@ struct esmdiff_engine {
   float *sig_w1 = nullptr, *sig_b1 = nullptr, *sig_w2 = nullptr, *sig_b2 = nullptr;
   float *rope_cos = nullptr, *rope_sin = nullptr;
   int vocab_pad = 0;
+  // decoder only (kind 1): esm's plddt_head = RegressionHead(d, 50) on the same final hidden state (optional weights)
+  bool has_plddt = false;
+  int plddt_bins = 0, ld_plddt = 0;
+  bf16_t *pl_w0 = nullptr, *pl_w3 = nullptr;
+  float *pl_b0 = nullptr, *pl_ln_w = nullptr, *pl_ln_b = nullptr, *pl_b3 = nullptr, *pl_logits = nullptr;
   // block 0 geometric attention (optional weights; live only while frames are set)
   bool has_geom = false;
   int v_heads = 0;  // rows of geom_attn.proj.weight / 15
@@ -213,7 +218,7 @@ int check_bl(esmdiff_engine* e, int B, int L) {
 // Workspace of one sub-batch: the engine's buffers are all sample-major, so a sub-batch is a pointer offset.
 struct Part {
   const int64_t *seq, *xtok;
-  float *x, *logits;
+  float *x, *logits, *pl_logits;
   bf16_t *h, *h2, *qkv, *q, *k, *ctx, *mid, *dlt, *dlt2;
   bf16_t *gp, *gctx;
   const float *f_rot, *f_trans;
@@ -227,7 +232,7 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
                hipStream_t st, int queue) {
   const esmdiff_config& c = e->cfg;
   const int64_t t0 = (int64_t)b0 * L, D = c.d_model;
-  return Part{seq + t0, xtok + t0, e->x + t0 * D, logits + t0 * ld, e->h + t0 * D, e->h2 + t0 * D, e->qkv + t0 * 3 * D,
+  return Part{seq + t0, xtok + t0, e->x + t0 * D, logits + t0 * ld, e->pl_logits ? e->pl_logits + t0 * e->ld_plddt : nullptr, e->h + t0 * D, e->h2 + t0 * D, e->qkv + t0 * 3 * D,
               e->q + t0 * D, e->k + t0 * D, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, e->dlt2 + t0 * D,
               e->gp ? e->gp + t0 * 15 * e->v_heads : nullptr, e->gctx ? e->gctx + t0 * 3 * e->v_heads : nullptr,
               e->f_rot ? e->f_rot + t0 * 9 : nullptr, e->f_trans ? e->f_trans + t0 * 3 : nullptr,
@@ -262,7 +267,10 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   } while (0)
 
   const float* cond = nullptr;
-  if (t_freq_dev && c.time_conditioning) {
+  // sigma_embedder runs whenever its weights were loaded and the caller hands a sinusoid: with time conditioning off the
+  // reference still adds sigma_embedder(0) (model.py:466-471 with _process_sigma zeroing sigma, :535-541), and the
+  // host passes the sinusoid of 0 for that case
+  if (t_freq_dev && e->sig_w1) {
     RUN(S_EMBED, launch_sigma_mlp(t_freq_dev, e->sig_w1, e->sig_b1, e->sig_w2, e->sig_b2, e->sig_hidden, e->cond,
                                   c.freq_dim, D, st));
     cond = e->cond;
@@ -328,8 +336,13 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   }
   EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, e->final_ln_w, nullptr, w.h, M, D, w.st));
   EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w0, w.h2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, w.st, w.gws));
+  // decoder: the pLDDT head reads the same normalised hidden state (w.h) before the structure head's LayerNorm reuses it;
+  // its intermediates live in ctx / q, which are free after the last block
+  if (e->has_plddt) EACH(S_HEAD, launch_gemm_bf16(w.h, e->pl_w0, w.ctx, e->pl_b0, M, D, D, D, D, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, w.st, w.gws));
   EACH(S_LN, launch_layernorm_bf16_in(w.h2, e->head_ln_w, e->head_ln_b, w.h, M, D, w.st));
+  if (e->has_plddt) EACH(S_LN, launch_layernorm_bf16_in(w.ctx, e->pl_ln_w, e->pl_ln_b, w.q, M, D, w.st));
   EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w3, w.logits, e->head_b3, M, e->vocab_pad, D, ld, c.vocab_out, 1.f, ESMDIFF_EPI_BIAS_F32, w.st, w.gws));
+  if (e->has_plddt) EACH(S_HEAD, launch_gemm_bf16(w.q, e->pl_w3, w.pl_logits, e->pl_b3, M, 128, D, e->ld_plddt, e->plddt_bins, 1.f, ESMDIFF_EPI_BIAS_F32, w.st, w.gws));
   for (int pi = 1; pi < np; ++pi) {
     HIP_TRY(e, hipEventRecord(e->ev_join[pi - 1], e->side[pi - 1]));
     HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[pi - 1], 0));
@@ -439,11 +452,27 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
   }
   if (kind == 1) {
     TRY(load_f32(e, t, "embed.weight", {ESMDIFF_VOCAB, D}, &e->e_struct));
+    if (const esmdiff_weight* pw = t.find("plddt_head.3.weight")) {   // RegressionHead(d, 50): Linear, GELU, LayerNorm, Linear
+      const int nb = pw->ndim == 2 ? (int)pw->shape[0] : 0;
+      if (nb <= 0 || nb > 128) return bail(fail(e, ESMDIFF_E_INVALID, "plddt_head.3.weight: %d bins unsupported (1..128)", nb));
+      e->plddt_bins = nb;
+      e->ld_plddt = round_up(nb, 4);
+      TRY(load_bf16(e, t, "plddt_head.0.weight", {D, D}, &e->pl_w0));
+      TRY(load_f32(e, t, "plddt_head.0.bias", {D}, &e->pl_b0));
+      TRY(load_f32(e, t, "plddt_head.2.weight", {D}, &e->pl_ln_w));
+      TRY(load_f32(e, t, "plddt_head.2.bias", {D}, &e->pl_ln_b));
+      TRY(load_bf16(e, t, "plddt_head.3.weight", {nb, D}, &e->pl_w3, 128));
+      const esmdiff_weight* w;
+      TRY(need(e, t, "plddt_head.3.bias", {nb}, &w));
+      TRY(dalloc(e, &e->pl_b3, (size_t)128, true));
+      if (launch_to_f32(w->data, w->dtype, e->pl_b3, nb, 0) != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "to_f32 failed"));
+      e->has_plddt = true;
+    }
   } else {
     TRY(load_f32(e, t, "encoder.sequence_embed.weight", {64, D}, &e->e_seq));
     TRY(load_f32(e, t, "encoder.structure_tokens_embed.weight", {ESMDIFF_VOCAB, D}, &e->e_struct));
   }
-  if (kind == 0 && cfg->time_conditioning) {
+  if (kind == 0 && (cfg->time_conditioning || t.find("sigma_embedder.mlp.0.weight"))) {
     TRY(load_f32(e, t, "sigma_embedder.mlp.0.weight", {D, F}, &e->sig_w1));
     TRY(load_f32(e, t, "sigma_embedder.mlp.0.bias", {D}, &e->sig_b1));
     TRY(load_f32(e, t, "sigma_embedder.mlp.2.weight", {D, D}, &e->sig_w2));
@@ -545,6 +574,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     }
     TRY(dalloc(e, &e->mid, Mx * FH));
     TRY(dalloc(e, &e->logits, Mx * e->ld_logits));
+    if (e->has_plddt) TRY(dalloc(e, &e->pl_logits, Mx * e->ld_plddt));
     TRY(dalloc(e, &e->cond, (size_t)D));
     TRY(dalloc(e, &e->sig_hidden, (size_t)D));
     e->tfreq_rows = 1026;
@@ -602,15 +632,17 @@ int esmdiff_decoder_create(const esmdiff_config* cfg, const esmdiff_weight* tabl
   return create_engine(&c, table, n, device, 1, out);
 }
 
-int esmdiff_decoder_decode(esmdiff_engine* e, const int64_t* tokens, float* bb_coords, int32_t B, int32_t L,
+int esmdiff_decoder_decode(esmdiff_engine* e, const int64_t* tokens, float* bb_coords, float* plddt, int32_t B, int32_t L,
                            float trans_scale, void* stream) {
   if (!e || !tokens || !bb_coords) return ESMDIFF_E_INVALID;
   if (e->kind != 1) return fail(e, ESMDIFF_E_INVALID, "not a decoder engine");
+  if (plddt && !e->has_plddt) return fail(e, ESMDIFF_E_MISSING, "plddt requested but the weight table had no plddt_head.* tensors");
   if (int r = check_bl(e, B, L)) return r;
   HIP_TRY(e, hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)stream;
   if (int r = forward(e, tokens, tokens, nullptr, e->logits, e->ld_logits, B, L, st)) return r;
   HIP_TRY(e, launch_dim6_to_backbone(e->logits, e->ld_logits, bb_coords, B * L, trans_scale, st));
+  if (plddt) HIP_TRY(e, launch_plddt_mean(e->pl_logits, e->ld_plddt, e->plddt_bins, plddt, B * L, st));
   return 0;
 }
 
@@ -672,11 +704,11 @@ int esmdiff_gibbs_step(esmdiff_engine* e, int64_t* x_inout, const int64_t* seq, 
   if (!u && !rng) return fail(e, ESMDIFF_E_INVALID, "need explicit uniforms or an rng");
   if (!(temperature > 0.f)) return fail(e, ESMDIFF_E_INVALID, "temperature must be > 0 (argmax decoding is not built)");
   if (!(top_p > 0.f)) return fail(e, ESMDIFF_E_INVALID, "top_p must be in (0, 1]");
-  if (ld_logits < 4096) return fail(e, ESMDIFF_E_INVALID, "bad shape");
+  if (ld_logits < 4096 || e->cfg.vocab_out < 4096 || ld_logits < e->cfg.vocab_out) return fail(e, ESMDIFF_E_INVALID, "bad shape");
   if (int r = check_bl(e, B, L)) return r;
   Prof p{e, (hipStream_t)stream};
   p.mark(S_SAMPLER);
-  HIP_TRY(e, launch_gibbs_step(x_inout, seq, logits, ld_logits, temperature, top_p, n_unmask, u, u ? 0 : 1, rng ? rng->seed : 0,
+  HIP_TRY(e, launch_gibbs_step(x_inout, seq, logits, ld_logits, e->cfg.vocab_out, temperature, top_p, n_unmask, u, u ? 0 : 1, rng ? rng->seed : 0,
                                rng ? rng->sample_offset : 0, step, e->g_sampled, e->g_entropy, B, L, (hipStream_t)stream));
   p.mark(S_SAMPLER);
   return 0;

@@ -3,16 +3,20 @@
 // Replaces, per step, the per-prompt post-processing of esm.utils.generation.iterative_sampling_raw as the
 // reference calls it (/root/reference/slm/sample_esmdiff.py:114-122: GenerationConfig(track="structure",
 // num_steps, temperature=1.4, top_p=0.9)).  [ESM-RECALL] That function lives in the un-vendored esm==3.0.4 package;
-// the semantics restated here are SURVEY.md Appendix B: for every position
-//     raw  = logits with the special ids (>= 4096) removed
-//     H    = entropy of softmax(raw)
-//     keep = nucleus: sorted descending, keep the prefix whose cumulative probability is <= top_p, always the top-1
-//     tok  ~ Categorical(softmax(keep(raw) / temperature))
+// the semantics restated here are SURVEY.md Appendix B, in esm's order of operations: for every position, with `raw` the
+// WHOLE structure-logit row (W = 4096 columns for the stock head, 4101 for the ESMDiff head the CLI samples from with
+// --ckpt and the default mode, sample_esmdiff.py:257-258,265)
+//     H    = entropy of softmax(raw)                                   (all W columns)
+//     keep = nucleus over all W columns: sorted descending, keep the prefix whose cumulative probability is <= top_p,
+//            always the top-1
+//     then the special ids (>= 4096) are removed from what was kept ("mask invalid ids" comes AFTER top-p)
+//     tok  ~ Categorical(softmax(kept / temperature))
+// (if nothing valid survives — a special id alone holds more than top_p of the mass — the best valid id is taken)
 // then per prompt the k_t lowest-entropy still-masked positions receive their sampled token, with
 // k_t = still_masked - int(cos((t+1)/T * pi/2) * total_to_sample + 0.1)  (host, esmdiff_amd/gibbs.py).
 //
-// gibbs_row_kernel     one 256-thread workgroup per MASKED (b,l) row; the 4096 logits are read once into
-//                      registers (16 per thread).  The nucleus needs no sort: element i is kept iff the
+// gibbs_row_kernel     one 256-thread workgroup per MASKED (b,l) row; the W logits are read once into
+//                      registers (17 per thread, columns >= W idle).  The nucleus needs no sort: element i is kept iff the
 //                      probability mass of {j : z_j >= z_i} is <= top_p, which is monotone in z_i, so the cut is
 //                      found by a 32-step bitwise search over the order-preserving integer image of the floats,
 //                      each step one masked block sum (wave halving tree + 4 partials, the canonical order of
@@ -28,7 +32,7 @@ namespace ed {
 constexpr int GNT = 256;
 constexpr int G_MASK = ESMDIFF_MASK_ID;
 constexpr int G_NVALID = 4096;  // VQ-VAE codebook ids; specials 4096..4100 are invalid draws
-constexpr int G_PER = G_NVALID / GNT;
+constexpr int G_PER = 17;        // 17 x 256 = 4352 >= the widest row (4101)
 
 __device__ __forceinline__ float g_wave_sum(float v) {
 #pragma unroll
@@ -48,7 +52,7 @@ __device__ __forceinline__ uint32_t g_key(float f) {  // order-preserving float 
 }
 
 __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restrict__ x, const float* __restrict__ logits,
-                                                        int ld, float inv_temperature, float top_p,
+                                                        int ld, int W, float inv_temperature, float top_p,
                                                         const float* __restrict__ u, int use_philox, uint64_t seed,
                                                         uint64_t sample_offset, int step, int L,
                                                         int32_t* __restrict__ sampled, float* __restrict__ entropy) {
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restric
   float m = -3.402823466e38f;
 #pragma unroll
   for (int j = 0; j < G_PER; ++j) {
-    zz[j] = z[t + j * GNT];
+    zz[j] = (t + j * GNT < W) ? z[t + j * GNT] : -3.402823466e38f;
     m = fmaxf(m, zz[j]);
   }
 #pragma unroll
@@ -76,10 +80,11 @@ __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restric
   float acc = 0.f, accz = 0.f;
 #pragma unroll
   for (int j = 0; j < G_PER; ++j) {
+    const bool in = t + j * GNT < W;
     const float d = zz[j] - m;
-    e[j] = ed_expf(d);
+    e[j] = in ? ed_expf(d) : 0.f;
     acc = acc + e[j];
-    accz = accz + e[j] * d;
+    accz = accz + (in ? e[j] * d : 0.f);
   }
   const float S = g_block_sum(acc, red, lane, wave);
   const float A = g_block_sum(accz, red, lane, wave);
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restric
     const float P = top_p * S;
     uint32_t kk[G_PER];
 #pragma unroll
-    for (int j = 0; j < G_PER; ++j) kk[j] = g_key(zz[j]);
+    for (int j = 0; j < G_PER; ++j) kk[j] = (t + j * GNT < W) ? g_key(zz[j]) : 0u;   // key 0 is below every candidate cut
     for (int bit = 31; bit >= 0; --bit) {
       const uint32_t cand = tau | (1u << bit);
       float part = 0.f;
@@ -106,9 +111,16 @@ __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restric
   const float* urow = u ? u + (int64_t)row * G_NVALID : nullptr;
   float best = -1.0f;
   int best_i = 0x7fffffff;
+  float fb = -3.402823466e38f;  // fall-back: the best VALID logit, used when the nucleus kept special ids only
+  int fb_i = 0x7fffffff;
 #pragma unroll
   for (int j = 0; j < G_PER; ++j) {
     const int v = t + j * GNT;
+    if (v >= G_NVALID) continue;   // special ids are removed after the nucleus cut
+    if (zz[j] > fb) {
+      fb = zz[j];
+      fb_i = v;
+    }
     const bool keep = (top_p >= 1.0f) || g_key(zz[j]) > tau || zz[j] == m;
     if (keep) {
       const float w = ed_expf((zz[j] - m) * inv_temperature);
@@ -130,23 +142,38 @@ __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restric
       best = ob;
       best_i = oi;
     }
+    const float of = __shfl_xor(fb, off, 64);
+    const int ofi = __shfl_xor(fb_i, off, 64);
+    if (of > fb || (of == fb && ofi < fb_i)) {
+      fb = of;
+      fb_i = ofi;
+    }
   }
+  __shared__ float s_fb[4];
+  __shared__ int s_fbi[4];
   __syncthreads();
   if (lane == 0) {
     red[wave] = best;
     s_idx[wave] = best_i;
+    s_fb[wave] = fb;
+    s_fbi[wave] = fb_i;
   }
   __syncthreads();
   if (t == 0) {
-    float bb = red[0];
-    int bi = s_idx[0];
+    float bb = red[0], ff = s_fb[0];
+    int bi = s_idx[0], fi = s_fbi[0];
 #pragma unroll
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 4; ++w) {
       if (red[w] > bb || (red[w] == bb && s_idx[w] < bi)) {
         bb = red[w];
         bi = s_idx[w];
       }
-    sampled[row] = bi;
+      if (s_fb[w] > ff || (s_fb[w] == ff && s_fbi[w] < fi)) {
+        ff = s_fb[w];
+        fi = s_fbi[w];
+      }
+    }
+    sampled[row] = bi != 0x7fffffff ? bi : fi;
     entropy[row] = H;
   }
 }
@@ -178,13 +205,13 @@ __global__ __launch_bounds__(GNT) void gibbs_select_kernel(int64_t* __restrict__
   }
 }
 
-hipError_t launch_gibbs_step(int64_t* x, const int64_t* seq, const float* logits, int ld, float temperature,
+hipError_t launch_gibbs_step(int64_t* x, const int64_t* seq, const float* logits, int ld, int vocab, float temperature,
                              float top_p, const int32_t* n_unmask, const float* u, int use_philox, uint64_t seed,
                              uint64_t sample_offset, int step, int32_t* sampled, float* entropy, int B, int L,
                              hipStream_t stream) {
   if (B <= 0 || L <= 0) return hipSuccess;
-  if (L > 1280 || ld < G_NVALID || !(temperature > 0.f)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gibbs_row_kernel, dim3(B * L), dim3(GNT), 0, stream, x, logits, ld, 1.0f / temperature, top_p, u,
+  if (L > 1280 || vocab < G_NVALID || vocab > G_PER * GNT || ld < vocab || !(temperature > 0.f)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gibbs_row_kernel, dim3(B * L), dim3(GNT), 0, stream, x, logits, ld, vocab, 1.0f / temperature, top_p, u,
                      use_philox, seed, sample_offset, step, L, sampled, entropy);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

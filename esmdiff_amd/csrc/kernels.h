@@ -18,7 +18,7 @@ hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, floa
 // ---- gibbs.hip ---------------------------------------------------------------------------------
 // one entropy-ordered unmasking step: per masked row nucleus(top_p) + temperature draw + entropy, then per prompt
 // the n_unmask[b] lowest-entropy masked positions take their token.  u: [B,L,4096] explicit uniforms or null.
-hipError_t launch_gibbs_step(int64_t* x, const int64_t* seq, const float* logits, int ld, float temperature,
+hipError_t launch_gibbs_step(int64_t* x, const int64_t* seq, const float* logits, int ld, int vocab, float temperature,
                              float top_p, const int32_t* n_unmask, const float* u, int use_philox, uint64_t seed,
                              uint64_t sample_offset, int step, int32_t* sampled, float* entropy, int B, int L,
                              hipStream_t stream);
@@ -73,6 +73,7 @@ hipError_t launch_gather_rows(const int64_t* tok, const float* table, float* out
                               hipStream_t stream);
 // v f32 [M, ld] (23 used) -> backbone N/CA/C coordinates f32 [M, 3, 3]
 hipError_t launch_dim6_to_backbone(const float* v, int ld, float* out, int M, float trans_scale, hipStream_t stream);
+hipError_t launch_plddt_mean(const float* v, int ld, int n_bins, float* out, int M, hipStream_t stream);
 hipError_t launch_sigma_mlp(const float* t_freq, const float* w1, const float* b1, const float* w2,
                             const float* b2, float* hidden, float* cond, int F, int D, hipStream_t stream);
 

@@ -21,17 +21,26 @@ def shard_samples(num_samples: int, world_size: int, rank: int) -> Tuple[int, in
     return offset, count
 
 
-def gather_ids(local_ids: torch.Tensor, num_samples: int) -> torch.Tensor:
-    """All ranks' (count_r, L) id blocks -> (num_samples, L) on every rank, in global sample order."""
+def gather_rows(local: torch.Tensor, num_samples: int) -> torch.Tensor:
+    """All ranks' (count_r, ...) blocks of any dtype -> (num_samples, ...) on every rank, in global sample order: ONE
+    all_gather of equally sized byte buffers (the shards differ by at most one sample)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local_ids
-    world, rank = dist.get_world_size(), dist.get_rank()
-    L = local_ids.shape[1]
+        return local
+    world = dist.get_world_size()
     cap = -(-num_samples // world)
-    buf = torch.zeros(cap, L, dtype=torch.int16, device=local_ids.device)
-    buf[: local_ids.shape[0]] = local_ids.to(torch.int16)
-    raw = buf.view(torch.uint8)          # all_gather is type-agnostic; neither gloo nor RCCL has an int16 type
+    buf = torch.zeros((cap,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    buf[: local.shape[0]] = local
+    raw = buf.reshape(cap, -1).view(torch.uint8)    # all_gather is type-agnostic; neither gloo nor RCCL has an int16 type
     out: List[torch.Tensor] = [torch.empty_like(raw) for _ in range(world)]
     dist.all_gather(out, raw)
-    parts = [out[r].view(torch.int16)[: shard_samples(num_samples, world, r)[1]] for r in range(world)]
-    return torch.cat(parts, 0).to(torch.int64)
+    parts = [out[r].view(local.dtype).reshape((cap,) + tuple(local.shape[1:]))[: shard_samples(num_samples, world, r)[1]]
+             for r in range(world)]
+    return torch.cat(parts, 0)
+
+
+def gather_ids(local_ids: torch.Tensor, num_samples: int) -> torch.Tensor:
+    """All ranks' (count_r, L) id blocks -> (num_samples, L) int64 on every rank, in global sample order (int16 on the wire:
+    ids <= 4100)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_ids
+    return gather_rows(local_ids.to(torch.int16).contiguous(), num_samples).to(torch.int64)

@@ -67,6 +67,7 @@ class Engine:
         del keep
         self.ld_logits = (cfg.n_structure_heads + 3) // 4 * 4
         self.has_geom = any(k.endswith("transformer.blocks.0.geom_attn.proj.weight") for k in state_dict)
+        self.has_sigma_embedder = any(k.startswith("sigma_embedder.mlp.0.") for k in state_dict)
         self._frames = None
 
     def close(self):
@@ -90,6 +91,26 @@ class Engine:
             t = t[None].expand(B, L)
         return t.contiguous()
 
+    def _check_ids(self, seq: torch.Tensor, x: torch.Tensor) -> None:
+        """The embedding tables hold 64 sequence rows and 4101 structure rows (net.py:445-466; -1 means MASK): an id
+        outside them is a caller error, reported here instead of being looked up."""
+        bad = ((seq < 0) | (seq > 63)).any() | ((x < -1) | (x >= STRUCTURE_VOCAB)).any()
+        if bool(bad):
+            raise ValueError(f"token id out of range: sequence ids must be in 0..63 (got {int(seq.min())}..{int(seq.max())}), "
+                             f"structure ids in -1..{STRUCTURE_VOCAB - 1} (got {int(x.min())}..{int(x.max())})")
+
+    def conditioning_rows(self, t_freq: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """What `_model_wrapper` conditions on (model.py:464-471): sigma_embedder(sigma) with time conditioning,
+        sigma_embedder(0) without it when the embedder exists (_process_sigma zeroes sigma, model.py:535-541), nothing
+        for a model without a sigma embedder.  In: (n, freq_dim) sinusoids of the real sigmas; out: the rows to feed."""
+        if t_freq is None or not self.has_sigma_embedder:
+            return None
+        if self.cfg.time_conditioning:
+            return t_freq
+        from .schedule import timestep_embedding
+        zero = timestep_embedding(torch.zeros(1, dtype=torch.float32), self.cfg.freq_dim)
+        return zero.expand(t_freq.shape[0], -1).contiguous() if t_freq.dim() == 2 else zero[0]
+
     def forward_logits(self, x: torch.Tensor, sequence_tokens: torch.Tensor, t_freq: Optional[torch.Tensor],
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x, sequence_tokens: (B,L) int64.  t_freq: (freq_dim,) f32 sinusoid of sigma, or None.
@@ -97,6 +118,7 @@ class Engine:
         B, L = x.shape
         x = self._tok(x, B, L)
         seq = self._tok(sequence_tokens, B, L)
+        self._check_ids(seq, x)
         if out is None:
             out = torch.empty(B, L, self.ld_logits, dtype=torch.float32, device=self.device)
         tf = None if t_freq is None else t_freq.to(device=self.device, dtype=torch.float32).contiguous()
@@ -139,13 +161,16 @@ class Engine:
             if tuple(input_prior.shape) != (B, L):
                 raise ValueError(f"Invalid input_prior shape: {tuple(input_prior.shape)} v.s. (seq) {(B, L)}")
             x = input_prior.to(device=self.device, dtype=torch.int64).contiguous().clone()
+        self._check_ids(seq, x)
         T = schedule.num_steps
         f32 = lambda t: t.detach().to("cpu", torch.float32).contiguous()
-        mc_t, mc_s, tf = f32(schedule.mc_t[:T]), f32(schedule.mc_s[:T]), f32(schedule.t_freq)
+        mc_t, mc_s = f32(schedule.mc_t[:T]), f32(schedule.mc_s[:T])
+        tf = self.conditioning_rows(schedule.t_freq)
+        tf = None if tf is None else f32(tf)
         rng = N.Rng(int(seed), int(sample_offset))
         as_p = lambda t: t.numpy().ctypes.data_as(N.c_f32p)
         self._chk(self._lib.esmdiff_ddpm_sample(self._h, _ptr(seq), _ptr(x), B, L, T, as_p(mc_t), as_p(mc_s),
-                                                as_p(tf) if self.cfg.time_conditioning else None,
+                                                None if tf is None else as_p(tf),
                                                 ctypes.byref(rng), _stream()))
         return x
 
@@ -178,6 +203,7 @@ class Engine:
         B, L = sequence_tokens.shape
         seq = self._tok(sequence_tokens, B, L)
         x = x0.to(device=self.device, dtype=torch.int64).contiguous().clone()
+        self._check_ids(seq, x)
         tab = n_unmask_table.detach().to("cpu", torch.int32).contiguous()
         T = tab.shape[0]
         assert tab.shape == (T, B)
@@ -260,6 +286,8 @@ class StructureDecoder:
         if code != 0:
             raise RuntimeError(f"esmdiff_decoder_create failed ({code}): {self._lib.esmdiff_last_error(None).decode()}")
         del keep
+        self.max_batch, self.max_len = max_batch, max_len
+        self.has_plddt = any(k == "plddt_head.3.weight" for k in state_dict)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -272,13 +300,19 @@ class StructureDecoder:
         except Exception:
             pass
 
-    def decode(self, structure_tokens: torch.Tensor) -> torch.Tensor:
-        """structure_tokens (B, L) int64 including BOS / EOS -> backbone coordinates (B, L - 2, 3, 3) float32 (N, CA, C)."""
+    def decode(self, structure_tokens: torch.Tensor, return_plddt: bool = False):
+        """structure_tokens (B, L) int64 including BOS / EOS -> backbone coordinates (B, L - 2, 3, 3) float32 (N, CA, C);
+        with return_plddt also the per-residue pLDDT (B, L - 2) in [0, 1] (None when the weights carry no plddt_head)."""
         B, L = structure_tokens.shape
         tok = structure_tokens.to(device=self.device, dtype=torch.int64).contiguous()
+        if int(tok.min()) < 0 or int(tok.max()) >= STRUCTURE_VOCAB:
+            raise ValueError(f"structure token id out of range 0..{STRUCTURE_VOCAB - 1}")
         out = torch.empty(B, L, 3, 3, dtype=torch.float32, device=self.device)
-        N.check(self._lib.esmdiff_decoder_decode(self._h, _ptr(tok), _ptr(out), B, L, float(self.cfg.trans_scale),
+        pl = torch.empty(B, L, dtype=torch.float32, device=self.device) if (return_plddt and self.has_plddt) else None
+        N.check(self._lib.esmdiff_decoder_decode(self._h, _ptr(tok), _ptr(out), _ptr(pl), B, L, float(self.cfg.trans_scale),
                                                  _stream()), self._h)
+        if return_plddt:
+            return out[:, 1:-1], (None if pl is None else pl[:, 1:-1])
         return out[:, 1:-1]
 
 

@@ -10,8 +10,9 @@ temperature / top-p filtered distribution.  One forward + one fused kernel pair 
 Proteins that carry coordinates condition the model through block 0's geometric attention (frames from
 esmdiff_amd.geometry, residues with non-finite coordinates have no frame — the inpainting driver marks masked residues
 with Inf, sample_esmdiff.py:88-96); with `condition_on_coordinates_only` (the default) no structure tokens are derived
-from them.  Not covered: turning coordinates into structure tokens (VQ-VAE encoder) and tokens into coordinates
-(decoder), SURVEY.md 8f.
+from them.  esm finishes with `client.decode` per protein (tokens -> coordinates + pLDDT), which is what lets the
+reference call `prot.to_pdb(tmp)` on every output (sample_esmdiff.py:124-128): pass `decoder=` (an
+esmdiff_amd.engine.StructureDecoder) and the returned proteins carry coordinates and pLDDT as well.
 """
 from __future__ import annotations
 
@@ -52,9 +53,12 @@ def encode_structure_prior(protein: ESMProtein, n_tokens: int) -> torch.Tensor:
 
 @torch.no_grad()
 def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequence[GenerationConfig], *,
-                           seed: int = 0, sample_offset: int = 0) -> List[ESMProtein]:
-    """client: an esmdiff_amd Engine, or an object with a `.net` Engine (the model wrapper)."""
+                           seed: int = 0, sample_offset: int = 0, decoder=None) -> List[ESMProtein]:
+    """client: an esmdiff_amd Engine, or an object with a `.net` Engine (the model wrapper); `decoder` defaults to the
+    client's own `.decoder` attribute when it has one."""
     eng = getattr(client, "net", client)
+    if decoder is None:
+        decoder = getattr(client, "decoder", None)
     assert len(proteins) == len(configs) and len(proteins) > 0
     cfg0 = configs[0]
     for c in configs:
@@ -95,5 +99,11 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
                                  sample_offset=sample_offset).cpu()
     if any(has_xyz):
         eng.set_frames(None)
-    return [ESMProtein(sequence=p.sequence, coordinates=None, structure_tokens=out_x[b, 1:-1].clone())
+    coords = plddt = None
+    if decoder is not None:                        # esm: client.decode(tensor) -> ESMProtein with coordinates and pLDDT
+        from .sample_esmdiff import decode_tokens
+        coords, plddt = decode_tokens(out_x[:, 1:-1], decoder)
+        coords, plddt = coords.cpu(), (None if plddt is None else plddt.cpu())
+    return [ESMProtein(sequence=p.sequence, coordinates=None if coords is None else coords[b],
+                       structure_tokens=out_x[b, 1:-1].clone(), plddt=None if plddt is None else plddt[b])
             for b, p in enumerate(proteins)]

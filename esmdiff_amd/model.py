@@ -11,6 +11,7 @@ which draws the uniforms exactly like the reference's CPU path — torch.rand_li
 """
 from __future__ import annotations
 
+from pathlib import Path
 from typing import Dict, Optional
 
 import torch
@@ -38,6 +39,8 @@ class MaskedDiffusionLanguageModeling:
         self.neg_infinity = -1000000.0
         self.net = Engine(cfg, state_dict, max_batch=max_batch, max_len=max_len, device=device)
         self.device = self.net.device
+        self._parity_gen = None      # noise="torch-cpu": ONE generator stream per run, like the reference's global RNG
+        self._parity_seed = None
 
     def eval(self):
         return self
@@ -68,15 +71,22 @@ class MaskedDiffusionLanguageModeling:
         # step-by-step drive (parity mode / noise_removal off)
         seq = sequence_tokens.to(self.device)
         x = (self._sample_prior(B, L) if input_prior is None else input_prior.clone()).to(self.device).contiguous()
-        tf = sch.t_freq if self.time_conditioning else [None] * (num_steps + 1)
+        tf = self.net.conditioning_rows(sch.t_freq)
+        tf = [None] * (num_steps + 1) if tf is None else tf
         if noise == "torch-cpu":
-            torch.manual_seed(seed)
+            # The reference never re-seeds between batches: torch.rand_like keeps consuming ONE process-wide CPU stream
+            # (model.py:27).  A private generator restarts that stream at the first batch of a run (global sample 0, or
+            # a new seed) and runs on through the later batches, so equally sized batches do not repeat each other.
+            if self._parity_gen is None or self._parity_seed != seed or sample_offset == 0:
+                self._parity_gen = torch.Generator().manual_seed(seed)     # same mt19937 stream as torch.manual_seed(seed)
+                self._parity_seed = seed
+            gen = self._parity_gen
         elif noise != "philox":
             raise ValueError(f"unknown noise source {noise!r}")
         for i in range(num_steps):
             logits = self.net.forward_logits(x, seq, tf[i])
             if noise == "torch-cpu":
-                u = torch.rand(B, L, STRUCTURE_VOCAB)       # == torch.rand_like(q_xs) on the CPU generator
+                u = torch.rand(B, L, STRUCTURE_VOCAB, generator=gen)   # == torch.rand_like(q_xs) on the CPU generator
                 self.net.ddpm_step(x, logits, sch.mc_t[i].item(), sch.mc_s[i].item(), u=u)
             else:
                 self.net.ddpm_step(x, logits, sch.mc_t[i].item(), sch.mc_s[i].item(), seed=seed,
@@ -87,15 +97,43 @@ class MaskedDiffusionLanguageModeling:
         return x
 
 
+def config_from_hydra_yaml(path, cfg: ModelConfig = ESM3_OPEN):
+    """The inference-time content of a run's `.hydra/config.yaml` (checkpoint_utils.py:45-57 instantiates `cfg.model`
+    from it): noise schedule, time_conditioning, structure-head width.  Returns (ModelConfig, Noise)."""
+    import dataclasses
+
+    import yaml
+    m = (yaml.safe_load(Path(path).read_text()) or {}).get("model", {}) or {}
+    ns = m.get("noise_schedule") or {}
+    target = str(ns.get("_target_", "slm.utils.noise_utils.LogLinearNoise")).rsplit(".", 1)[-1]
+    kinds = {"LogLinearNoise": LogLinearNoise, "CosineNoise": CosineNoise}
+    if target not in kinds:
+        raise NotImplementedError(f"noise schedule {target} (from {path}) is not built: LogLinearNoise / CosineNoise only")
+    noise = kinds[target](**({"eps": float(ns["eps"])} if "eps" in ns else {}))
+    net = m.get("net") or {}
+    cfg = dataclasses.replace(cfg, time_conditioning=bool(m.get("time_conditioning", cfg.time_conditioning)),
+                              n_structure_heads=int(net.get("n_structure_heads", cfg.n_structure_heads)))
+    return cfg, noise
+
+
 def load_state_dict_from_lightning_ckpt(ckpt_path, device="cuda", max_batch: int = 128, max_len: int = 1026,
                                         cfg: ModelConfig = ESM3_OPEN):
     """/root/reference/slm/utils/checkpoint_utils.py:41-74: a `.pt` whose 'module' dict holds `net.*` and
-    `sigma_embedder.*`; the model is the mdlm.yaml configuration (LogLinearNoise, time conditioning, 4101-way
-    head) with noise_removal forced on (:71)."""
+    `sigma_embedder.*`; the model is what the run's `.hydra/config.yaml` says when that file sits where the reference
+    looks for it (:45-50), else the mdlm.yaml configuration (LogLinearNoise, time conditioning, 4101-way head);
+    noise_removal is forced on (:71)."""
+    from .weights import checkpoint_file_and_config
     print(f"Loading ESMDiff ckpt from {ckpt_path}")
+    _, exp_cfg_path = checkpoint_file_and_config(ckpt_path)
+    noise = LogLinearNoise()
+    if exp_cfg_path is not None:
+        cfg, noise = config_from_hydra_yaml(exp_cfg_path, cfg)
+    else:
+        print("Config file not found next to the checkpoint. Use default config (configs/experiment/mdlm.yaml).")
+    print(f"Loaded experiment config: {exp_cfg_path or 'mdlm.yaml defaults'}...")
     sd = load_checkpoint_state_dict(ckpt_path)
     dev = torch.device(device).index or 0
-    model = MaskedDiffusionLanguageModeling(sd, cfg, LogLinearNoise(), max_batch, max_len, dev, noise_removal=True)
+    model = MaskedDiffusionLanguageModeling(sd, cfg, noise, max_batch, max_len, dev, noise_removal=True)
     print(f"Sucessfully loaded model from {ckpt_path}...")
     return model
 

@@ -14,8 +14,10 @@ Both sampling modes are built: `--mode ddpm` (MDLM ancestral sampler) and the re
 (entropy-ordered iterative unmasking, temperature 1.4 / top-p 0.9).
 
 Output: the reference decodes tokens to backbone coordinates with ESM3's VQ-VAE decoder and writes a
-multi-MODEL PDB (sample_esmdiff.py:225-231).  That decoder is outside this build, so the
-structure TOKENS are written to `<out>/<name>.tokens.npy` (N, L int16) next to a JSON with the run settings.
+multi-MODEL PDB (sample_esmdiff.py:225-231).  With --decoder_ckpt (esm's StructureTokenDecoder weights, which cannot be
+downloaded here) every rank decodes its own samples on the device and rank 0 writes `<out>/<name>.pdb` (one MODEL per
+sample, B-factor = pLDDT); the structure TOKENS are always written to `<out>/<name>.tokens.npy` (N, L int16) next to
+a JSON with the run settings.
 """
 from __future__ import annotations
 
@@ -36,37 +38,85 @@ from .sdk import ESMProtein, encode_sequence
 DEFAULT_NMAX = 1026 * 1026 * 32
 
 
-def batch_sizes(n_tokens: int, num_samples: int, n_max_residue_square: int = DEFAULT_NMAX):
-    """sample_esmdiff.py:181-193 (the length is the TOKEN count in ddpm mode)."""
+def batch_sizes(n_tokens: int, num_samples: int, n_max_residue_square: int = DEFAULT_NMAX, cap: int = 0):
+    """sample_esmdiff.py:181-193 (the length is the TOKEN count in ddpm mode, the residue count in gibbs mode).  The
+    reference's arithmetic can make the remainder batch larger than the regular ones; `cap` (the engine's max_batch)
+    additionally splits any batch the engine could not hold — samples are independent and the noise is keyed by the
+    global sample index, so the split does not change a single id."""
     sq = n_tokens * n_tokens
     total = sq * num_samples
     bsz = [n_max_residue_square // sq] * (total // n_max_residue_square)
     if total % n_max_residue_square > 0:
         bsz.append(num_samples - sum(bsz))
     assert sum(bsz) == num_samples, f"{sum(bsz)} != {num_samples}"
+    if cap > 0:
+        bsz = [c for b in bsz for c in ([cap] * (b // cap) + ([b % cap] if b % cap else []))]
     return bsz
 
 
+def engine_capacity(lengths, per_rank: int, n_max_residue_square: int, mode: str) -> int:
+    """max_batch an engine needs so that every batch `batch_sizes` will issue for these targets fits: ddpm mode batches
+    by token count (L + 2), gibbs mode by residue count (sample_esmdiff.py:97-105 vs :181-193)."""
+    need = 1
+    for n_res in lengths:
+        n = n_res + 2 if mode == "ddpm" else n_res
+        need = max([need] + batch_sizes(n, per_rank, n_max_residue_square))
+    return need
+
+
 @torch.no_grad()
-def decode_to_pdb(tokens: torch.Tensor, sequence: str, decoder, save_to: Path, sample_basename: str, chunk: int = 64):
-    """sample_esmdiff.py:40-61 + :225-231: structure tokens (N, L) -> backbone coordinates -> one PDB per sample in a
-    temporary directory -> merge_pdbfiles into `<basename>.pdb` (MODEL n ... ENDMDL blocks).  The reference decodes one
-    sample per esm3.decode call; here the decoder engine takes them `chunk` at a time."""
+def decode_tokens(tokens: torch.Tensor, decoder, chunk: int = 0):
+    """sample_esmdiff.py:40-61 without the file: structure tokens (n, L) WITHOUT BOS/EOS -> (coords (n, L, 3, 3) float32,
+    plddt (n, L) float32 or None) on the decoder's device.  The reference decodes one sample per esm3.decode call; the
+    decoder engine takes them `chunk` (default: its max_batch) at a time."""
+    n, L_ = tokens.shape
+    dev = decoder.device
+    chunk = chunk or getattr(decoder, "max_batch", 64)
+    if n == 0:
+        return torch.empty(0, L_, 3, 3, device=dev), (torch.empty(0, L_, device=dev) if decoder.has_plddt else None)
+    t = tokens.to(dev, torch.int64)
+    full = torch.cat([torch.full((n, 1), C.STRUCTURE_BOS_TOKEN, dtype=torch.int64, device=dev), t,
+                      torch.full((n, 1), C.STRUCTURE_EOS_TOKEN, dtype=torch.int64, device=dev)], 1)
+    cs, ps = [], []
+    for i in range(0, n, chunk):
+        c, pl = decoder.decode(full[i:i + chunk], return_plddt=True)
+        cs.append(c.clone())
+        ps.append(None if pl is None else pl.clone())
+    return torch.cat(cs, 0), (None if ps[0] is None else torch.cat(ps, 0))
+
+
+def write_models_pdb(coords, plddt, sequence: str, save_to: Path, sample_basename: str):
+    """sample_esmdiff.py:225-231: one PDB per sample in a temporary directory (B-factor column = pLDDT, as
+    ESMProtein.to_pdb writes it) -> merge_pdbfiles into `<basename>.pdb` (MODEL n ... ENDMDL blocks)."""
     import tempfile
     from .pdbio import merge_pdbfiles, write_backbone_pdb
-    N_, L_ = tokens.shape
-    bos = torch.full((N_, 1), C.STRUCTURE_BOS_TOKEN, dtype=torch.int64)
-    eos = torch.full((N_, 1), C.STRUCTURE_EOS_TOKEN, dtype=torch.int64)
-    full = torch.cat([bos, tokens.cpu().to(torch.int64), eos], 1)
-    coords = torch.cat([decoder.decode(full[i:i + chunk]).cpu() for i in range(0, N_, chunk)], 0).numpy()
+    coords = coords.cpu().numpy()
+    plddt = None if plddt is None else plddt.cpu().numpy()
     seq = sequence.replace(C.MASK_RESIDUE, "X")
     with tempfile.TemporaryDirectory() as tmpdirname:
         saved = []
-        for i in range(N_):
+        for i in range(coords.shape[0]):
             tmp = Path(tmpdirname) / f"{sample_basename}.{i}.pdb"
-            write_backbone_pdb(tmp, seq, coords[i])
+            write_backbone_pdb(tmp, seq, coords[i], None if plddt is None else plddt[i])
             saved.append(tmp)
         merge_pdbfiles(saved, save_to, verbose=False)
+
+
+def decode_shard_and_gather(local_tokens: torch.Tensor, decoder, num_samples: int):
+    """Multi-GPU tail: EVERY rank decodes the samples it drew, then one all_gather of coordinates (+ pLDDT) — the
+    decode time stays 1/N of the ensemble instead of rank 0 decoding all N shards after the id gather."""
+    from .dist import gather_rows
+    coords, plddt = decode_tokens(local_tokens, decoder)
+    coords = gather_rows(coords.contiguous(), num_samples)
+    plddt = None if plddt is None else gather_rows(plddt.contiguous(), num_samples)
+    return coords, plddt
+
+
+@torch.no_grad()
+def decode_to_pdb(tokens: torch.Tensor, sequence: str, decoder, save_to: Path, sample_basename: str, chunk: int = 0):
+    """Single-process convenience: decode_tokens + write_models_pdb."""
+    coords, plddt = decode_tokens(tokens, decoder, chunk)
+    write_models_pdb(coords, plddt, sequence, save_to, sample_basename)
 
 
 @timer
@@ -75,8 +125,9 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
                        num_steps: int = 10, eps: float = 1e-5, n_max_residue_square: int = DEFAULT_NMAX,
                        coordinates=None, mask_ids=None, structure_tokens=None, sample_max_t: float = 1.0,
                        seed: int = 0, noise: str = "philox", timestamp: bool = True, decoder=None, encoder=None):
-    """sample_esmdiff.py:137-233.  With a `decoder` (esmdiff_amd.engine.StructureDecoder) rank 0 also writes the reference's
-    artefact, `<basename>.pdb` with one MODEL per sample; the token file is written either way.  `structure_tokens` (L+2, with BOS/EOS) replaces what the reference gets from
+    """sample_esmdiff.py:137-233.  With a `decoder` (esmdiff_amd.engine.StructureDecoder, one per rank) every rank decodes
+    its own shard and rank 0 writes the reference's artefact, `<basename>.pdb` with one MODEL per sample; the token file
+    is written either way.  `structure_tokens` (L+2, with BOS/EOS) replaces what the reference gets from
     ESM3.encode(coordinates) for the inpainting prior (:196-201); without it mask_ids cannot be honoured."""
     model = pl_model
     str_time = ("_" + strftime("%Y%m%d-%H%M%S")) if timestamp else ""
@@ -110,7 +161,8 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
     offset, count = shard_samples(num_samples, world, rank)
     outs = []
     done = 0
-    for bs in batch_sizes(seq_tok.numel(), count, n_max_residue_square) if count else []:
+    cap = getattr(getattr(model, "net", model), "max_batch", 0)
+    for bs in batch_sizes(seq_tok.numel(), count, n_max_residue_square, cap) if count else []:
         batch = seq_tok[None, :].repeat(bs, 1)
         prior = None
         if mask_ids is not None:
@@ -123,16 +175,21 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
     L = seq_tok.numel()
     local = torch.cat(outs, 0) if outs else torch.empty(0, L, dtype=torch.int64, device=model.device)
     tokens = gather_ids(local, num_samples)[:, 1:-1]          # remove bos and eos positions (:220-221)
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    sample_t = time() - start_t
+    coords = plddt = None
+    if decoder is not None:                                   # every rank: decode the local shard, then one gather
+        coords, plddt = decode_shard_and_gather(local[:, 1:-1], decoder, num_samples)
     if rank == 0:
-        print(f"Sampling token time: {time() - start_t:.2f}s")
+        print(f"Sampling token time: {sample_t:.2f}s")
         output_dir.mkdir(parents=True, exist_ok=True)
         np.save(save_to, tokens.cpu().numpy().astype(np.int16))
         (output_dir / f"{sample_basename}.json").write_text(json.dumps(
             {"sequence": sequence, "num_steps": num_steps, "num_samples": num_samples, "eps": eps, "seed": seed,
-             "noise": noise, "world_size": world, "sampling_seconds": round(time() - start_t, 3)}, indent=1))
-        if decoder is not None:
-            decode_to_pdb(tokens, sequence, decoder, output_dir / f"{sample_basename}.pdb", sample_basename)
+             "noise": noise, "world_size": world, "sampling_seconds": round(sample_t, 3)}, indent=1))
+        if coords is not None:
+            write_models_pdb(coords, plddt, sequence, output_dir / f"{sample_basename}.pdb", sample_basename)
         print(f"Total time: {time() - start_t:.2f}s")
     return []
 
@@ -178,20 +235,31 @@ def minibatch_gibbs_by_esm(protseq, esm3_model, output_dir: Path, sample_basenam
         protseq = "".join(protseq)
     start_t = time()
     offset, count = shard_samples(num_samples, world, rank)
-    out_tokens, done = [], 0
-    for bs in batch_sizes(len(protseq), count, n_max_residue_square) if count else []:
+    out_list, done = [], 0
+    cap = getattr(getattr(esm3_model, "net", esm3_model), "max_batch", 0)
+    for bs in batch_sizes(len(protseq), count, n_max_residue_square, cap) if count else []:
         prot_list = [ESMProtein(sequence=protseq, coordinates=coordinates, structure_tokens=st) for _ in range(bs)]
         if rank == 0:
             print(f"Generating {len(prot_list)} samples for {protseq}...")
         cfg_list = [GenerationConfig(track="structure", num_steps=num_steps, temperature=temperature, top_p=top_p)
                     for _ in range(bs)]
         outs = iterative_sampling_raw(esm3_model, proteins=prot_list, configs=cfg_list, seed=seed,
-                                      sample_offset=offset + done)
-        out_tokens += [o.structure_tokens for o in outs]
+                                      sample_offset=offset + done, decoder=decoder)
+        out_list += outs
         done += bs
     dev = getattr(esm3_model, "net", esm3_model).device
+    out_tokens = [o.structure_tokens for o in out_list]
     local = (torch.stack(out_tokens) if out_tokens else torch.empty(0, len(protseq), dtype=torch.int64)).to(dev)
     tokens = gather_ids(local, num_samples)
+    coords = plddt = None
+    if decoder is not None:       # the proteins already carry the coordinates their rank decoded (iterative_sampling_raw)
+        from .dist import gather_rows
+        Lr = len(protseq)
+        lc = torch.stack([torch.as_tensor(o.coordinates) for o in out_list]) if out_list else torch.empty(0, Lr, 3, 3)
+        coords = gather_rows(lc.to(dev, torch.float32).contiguous(), num_samples)
+        if decoder.has_plddt:
+            lp = torch.stack([torch.as_tensor(o.plddt) for o in out_list]) if out_list else torch.empty(0, Lr)
+            plddt = gather_rows(lp.to(dev, torch.float32).contiguous(), num_samples)
     if rank == 0:
         print(f"Sampling token time: {time() - start_t:.2f}s")
         output_dir.mkdir(parents=True, exist_ok=True)
@@ -200,9 +268,9 @@ def minibatch_gibbs_by_esm(protseq, esm3_model, output_dir: Path, sample_basenam
             {"sequence": protseq, "mode": "gibbs", "num_steps": num_steps, "num_samples": num_samples,
              "temperature": temperature, "top_p": top_p, "seed": seed, "world_size": world,
              "sampling_seconds": round(time() - start_t, 3)}, indent=1))
-        if decoder is not None:
-            decode_to_pdb(tokens, protseq, decoder, output_dir / f"{sample_basename}.pdb", sample_basename)
-    return []
+        if coords is not None:
+            write_models_pdb(coords, plddt, protseq, output_dir / f"{sample_basename}.pdb", sample_basename)
+    return out_list
 
 
 def get_argparser(argv=None):
@@ -254,6 +322,9 @@ def main(argv=None):
                          "--random_init (synthetic weights)")
     if args.esm3_ckpt and args.ckpt is None:
         assert args.mode == "gibbs", "Only Gibbs sampling is supported for the pre-trained ESM3 model."
+    if args.parity and world > 1:
+        raise SystemExit("--parity replays the reference's single-process torch.rand stream; it cannot be sharded over "
+                         "ranks (every rank would draw the same uniforms) — run it on one GPU")
     mask_ids = [int(i) for i in args.mask_ids.split(",")] if args.mask_ids else None   # 0-based index
     if mask_ids is not None and args.mode == "ddpm" and not (args.encoder_ckpt or args.random_init_encoder):
         raise SystemExit("--mode ddpm --mask_ids builds its prior with the VQ-VAE structure encoder: pass --encoder_ckpt "
@@ -275,7 +346,10 @@ def main(argv=None):
             coords_of[p.stem] = prot.coordinates
     max_len = max(len(s) for _, s in targets) + 2
     per_rank = -(-args.num_samples // world)
-    max_b = max(1, min(per_rank, args.n_max_residue_square // (max_len * max_len)))
+    # every batch the per-target splitters will issue must fit (ddpm: token count, gibbs: residue count; the remainder
+    # batch can exceed the regular one); bounded so that one 288 GB GPU holds the workspace, larger batches are chunked
+    max_b = engine_capacity([len(s) for _, s in targets], per_rank, args.n_max_residue_square, args.mode)
+    max_b = max(1, min(max_b, per_rank, max(1, (4 * DEFAULT_NMAX) // (max_len * max_len))))
     if args.random_init:
         from .config import ESM3_OPEN, TINY
         model = random_init_model(TINY if args.tiny else ESM3_OPEN, seed=args.seed, max_batch=max_b, max_len=max_len,
@@ -287,7 +361,7 @@ def main(argv=None):
         model = load_state_dict_from_lightning_ckpt(args.ckpt, device=f"cuda:{local_rank}", max_batch=max_b,
                                                     max_len=max_len)
     decoder = None
-    if (args.decoder_ckpt or args.random_init_decoder) and rank == 0:
+    if args.decoder_ckpt or args.random_init_decoder:          # one per rank: each rank decodes its own shard
         from .config import STRUCTURE_DECODER_V0, TINY_DECODER
         from .engine import StructureDecoder
         from .weights import random_init_decoder_state_dict

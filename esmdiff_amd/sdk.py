@@ -2,8 +2,8 @@
 re-created so that the reference's call sites keep working against this engine: ESMProtein,
 ESMProteinTensor, GenerationConfig, and the sequence tokenizer ([ESM-RECALL] vocabulary, constants.py).
 
-Not covered this round: the VQ-VAE structure encoder/decoder, so `ESMProtein.to_pdb` needs
-coordinates that something else supplied, and coordinates are not turned into structure tokens.
+`ESMProtein.to_pdb` writes the backbone the structure decoder produced (B-factor column = pLDDT, as esm does); proteins
+that came out of a sampler run without a decoder attached carry tokens only and refuse to be written.
 """
 from __future__ import annotations
 
@@ -46,10 +46,12 @@ class ESMProtein:
 
     def to_pdb(self, path) -> None:
         if self.coordinates is None:
-            raise NotImplementedError(
-                "to_pdb needs coordinates; this engine emits structure TOKENS and the VQ-VAE decoder "
-                "(esm StructureTokenDecoder) is not part of this build yet (SURVEY.md 8f-1)")
-        write_backbone_pdb(path, self.sequence, np.asarray(self.coordinates)[:, :3, :])
+            raise ValueError(
+                "to_pdb needs coordinates: this protein carries structure TOKENS only — pass decoder=StructureDecoder(...) to "
+                "iterative_sampling_raw (or decode with esmdiff_amd.sample_esmdiff.decode_tokens) first")
+        seq = (self.sequence or "").replace(C.MASK_RESIDUE, "X")
+        write_backbone_pdb(path, seq, np.asarray(self.coordinates)[:, :3, :],
+                           None if self.plddt is None else np.asarray(self.plddt))
 
     def __len__(self):
         return len(self.sequence) if self.sequence is not None else 0

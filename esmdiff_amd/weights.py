@@ -79,7 +79,7 @@ def random_init_state_dict(cfg: ModelConfig, seed: int = 0, prefix: str = "net."
     return sd
 
 
-def random_init_decoder_state_dict(cfg, seed: int = 0, device: str = "cpu") -> Dict[str, torch.Tensor]:
+def random_init_decoder_state_dict(cfg, seed: int = 0, device: str = "cpu", with_plddt: bool = True) -> Dict[str, torch.Tensor]:
     """Random weights with the key layout of esm's StructureTokenDecoder: embed, decoder_stack.*,
     affine_output_projection.* — for tests and offline plumbing (the real esm3_structure_decoder_v0 cannot be fetched)."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -111,6 +111,10 @@ def random_init_decoder_state_dict(cfg, seed: int = 0, device: str = "cpu") -> D
     sd[h + "ffn1.weight"], sd[h + "ffn1.bias"] = linear(D, D, True)
     sd[h + "norm.weight"], sd[h + "norm.bias"] = 1.0 + 0.1 * randn(D), 0.05 * randn(D)
     sd[h + "proj.weight"], sd[h + "proj.bias"] = linear(23, D, True)
+    if with_plddt:       # esm RegressionHead(d, 50): drawn last so that the other tensors keep their stream
+        sd["plddt_head.0.weight"], sd["plddt_head.0.bias"] = linear(D, D, True)
+        sd["plddt_head.2.weight"], sd["plddt_head.2.bias"] = 1.0 + 0.1 * randn(D), 0.05 * randn(D)
+        sd["plddt_head.3.weight"], sd["plddt_head.3.bias"] = linear(50, D, True)
     return sd
 
 
@@ -144,14 +148,46 @@ def random_init_encoder_state_dict(cfg, seed: int = 0, device: str = "cpu") -> D
     return sd
 
 
-def load_checkpoint_state_dict(path) -> Dict[str, torch.Tensor]:
-    """The reference's format (checkpoint_utils.py:41-64): a .pt whose 'module' entry is the state dict."""
+def _torch_load_tensors(path):
+    """torch.load restricted to tensors and plain containers.  DeepSpeed / Lightning `mp_rank_00_model_states.pt` files
+    carry client state next to 'module' (omegaconf nodes, functools.partial, ds_config ...) that the restricted
+    unpickler refuses; say what to do instead of failing with a bare UnpicklingError."""
+    import pickle
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as ex:
+        raise RuntimeError(
+            f"{path} holds pickled Python objects besides tensors ({str(ex).splitlines()[0]}); this loader only unpickles "
+            "tensors (weights_only=True).  Re-export the weights once where the checkpoint is trusted:\n"
+            "    sd = torch.load(path, map_location='cpu', weights_only=False)['module']\n"
+            "    torch.save({'module': sd}, 'release_v0.module.pt')") from ex
+
+
+def checkpoint_file_and_config(path):
+    """checkpoint_utils.py:43-50: (file to load, the run's .hydra/config.yaml next to it or None)."""
     path = Path(path)
     if not path.exists():
         raise FileNotFoundError(f"Checkpoint not found: {path}")
     if path.suffix not in (".ckpt", ".pt"):
         raise ValueError(f"Unsupported ckpt format: {path}")
     if path.is_dir():
-        path = path / "checkpoint/mp_rank_00_model_states.pt"
-    blob = torch.load(path, map_location="cpu", weights_only=True)
-    return blob["module"] if "module" in blob else blob
+        file = path / "checkpoint/mp_rank_00_model_states.pt"
+        cfg = file.parent.parent.parent.parent / ".hydra/config.yaml"
+    else:
+        file, cfg = path, path.parent.parent / ".hydra/config.yaml"
+    if file.suffix != ".pt":
+        raise ValueError(f"Unsupported ckpt format: {file}")       # checkpoint_utils.py:65-66
+    return file, (cfg if cfg.exists() else None)
+
+
+def load_checkpoint_state_dict(path) -> Dict[str, torch.Tensor]:
+    """The reference's format (checkpoint_utils.py:41-64): a .pt whose 'module' entry is the state dict with the
+    `net.*` and `sigma_embedder.*` keys of MaskedDiffusionLanguageModeling."""
+    file, _ = checkpoint_file_and_config(path)
+    blob = _torch_load_tensors(file)
+    if not isinstance(blob, dict) or "module" not in blob:
+        raise KeyError(f"{file}: no 'module' entry (the reference reads torch.load(...)['module'], checkpoint_utils.py:63)")
+    sd = blob["module"]
+    if not any(k.startswith("net.") for k in sd):
+        raise KeyError(f"{file}: 'module' holds no net.* keys — not an ESMDiff task-module state dict")
+    return sd

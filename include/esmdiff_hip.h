@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESMDIFF_ABI_VERSION 1
+#define ESMDIFF_ABI_VERSION 2
 
 /* structure-track vocabulary: esm constants mirrored at model.py:380-381 */
 #define ESMDIFF_VOCAB 4101
@@ -105,8 +105,12 @@ const char* esmdiff_last_error(const esmdiff_engine* eng);
 /* Replaces self.net(structure_tokens=x, sequence_tokens=seq, auxiliary_embeddings=cond).structure_logits
  * (model.py:475-481 -> net.py:371-483) including conditions = sigma_embedder(sigma) (model.py:466-471,
  * net.py:519-522).  t_freq = TimestepEmbedder.timestep_embedding(sigma, freq_dim) [freq_dim] floats for
- * the single sigma all rows share (model.py:570-571), or NULL for no time conditioning.
- * seq, x: [B,L] int64.  logits_out: [B,L,ld_logits] float32, ld_logits >= vocab_out. */
+ * the single sigma all rows share (model.py:570-571), or NULL for no auxiliary embedding at all (esm's own forward,
+ * the gibbs path).  The MLP runs whenever sigma_embedder.* weights were in the table: a model built with
+ * time_conditioning = false still adds sigma_embedder(0) in the reference (_process_sigma, model.py:535-541), so its
+ * caller passes the sinusoid of sigma = 0.
+ * seq, x: [B,L] int64; seq ids outside 0..63 and structure ids outside -1..4100 are clamped (the Python host raises
+ * before it gets here).  logits_out: [B,L,ld_logits] float32, ld_logits >= vocab_out. */
 int esmdiff_forward_logits(esmdiff_engine* eng, const int64_t* seq, const int64_t* x,
                            const float* t_freq, float* logits_out, int32_t ld_logits,
                            int32_t B, int32_t L, void* stream);
@@ -200,12 +204,15 @@ int esmdiff_set_frames(esmdiff_engine* eng, const float* rot, const float* trans
  * ffn_hidden 3584 for esm3_structure_decoder_v0; vocab_out / freq_dim / time_conditioning are ignored, residue_scale
  * should be 1.  Weight names: embed.weight, decoder_stack.blocks.{i}.<as ESM3>, decoder_stack.norm.weight,
  * affine_output_projection.{ffn1,norm,proj}.{weight,bias}.  Destroy with esmdiff_engine_destroy.
+ * Optional: plddt_head.{0,2,3}.{weight,bias} (esm's RegressionHead(d, 50) on the same hidden state) enables `plddt`.
  * esmdiff_decoder_decode: tokens int64 [B,L] INCLUDING BOS (4098) / EOS (4097); bb_coords f32 [B,L,3,3] = N, CA, C
- * per position (rows 0 and L-1 belong to BOS/EOS and are to be dropped); trans_scale = 10 in esm. */
+ * per position (rows 0 and L-1 belong to BOS/EOS and are to be dropped); plddt f32 [B,L] or NULL = mean of the
+ * categorical mixture over the 50 bins of [0,1] (what ESMProtein.to_pdb writes into the B-factor column,
+ * sample_esmdiff.py:56-61); trans_scale = 10 in esm.  The pTM / PAE pairwise head is not built. */
 int esmdiff_decoder_create(const esmdiff_config* cfg, const esmdiff_weight* table, int32_t n_weights,
                            int32_t device, esmdiff_engine** out);
-int esmdiff_decoder_decode(esmdiff_engine* dec, const int64_t* tokens, float* bb_coords, int32_t B, int32_t L,
-                           float trans_scale, void* stream);
+int esmdiff_decoder_decode(esmdiff_engine* dec, const int64_t* tokens, float* bb_coords, float* plddt, int32_t B,
+                           int32_t L, float trans_scale, void* stream);
 
 /* VQ-VAE structure-token ENCODER: backbone frames -> structure tokens.  Replaces `model.encode(ESMProtein(coordinates))`
  * as protseq_to_data calls it for the DDPM inpainting prior (/root/reference/slm/models/utils.py:136-137,

@@ -50,7 +50,7 @@ def lib():
         _lib.oracle_philox_uniforms.argtypes = [ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
                                                 ctypes.c_uint32, ctypes.c_int, _f32p]
         _lib.oracle_philox_uniforms.restype = None
-        _lib.oracle_gibbs_step.argtypes = [_i64p, _i64p, _f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
+        _lib.oracle_gibbs_step.argtypes = [_i64p, _i64p, _f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                            ctypes.POINTER(ctypes.c_int32), _f32p, ctypes.c_uint64, ctypes.c_uint64,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p,
                                            ctypes.POINTER(ctypes.c_int32)]
@@ -116,9 +116,11 @@ def philox_uniforms(seed, sample, step, l, vocab=4101):
 
 
 def gibbs_step(x, seq, logits, temperature, top_p, n_unmask, u=None, seed=0, sample_offset=0, step=0,
-               return_aux=False):
-    """One entropy-ordered unmasking step (oracle_gibbs_step).  x, seq [B,L]; logits [B,L,ld>=4096];
-    n_unmask [B]; u [B,L,4096] or None (Philox)."""
+               return_aux=False, vocab=4096):
+    """One entropy-ordered unmasking step (oracle_gibbs_step).  x, seq [B,L]; logits [B,L,ld>=vocab]; `vocab` = width of
+    the structure head's row (4096 stock ESM3, 4101 ESMDiff): entropy and nucleus run over all of it, draws over the
+    4096 codebook ids; n_unmask [B]; u [B,L,4096] or None (Philox)."""
+    assert 4096 <= vocab <= 4352
     x = np.array(x, dtype=np.int64, order="C", copy=True)
     seq = np.ascontiguousarray(seq, dtype=np.int64)
     B, L = x.shape
@@ -130,7 +132,8 @@ def gibbs_step(x, seq, logits, temperature, top_p, n_unmask, u=None, seed=0, sam
         assert ua.shape == (B, L, 4096)
     ent = np.full((B, L), np.inf, dtype=np.float32)
     smp = np.full((B, L), -1, dtype=np.int32)
-    lib().oracle_gibbs_step(x.ctypes.data_as(_i64p), seq.ctypes.data_as(_i64p), lgp, lg.shape[2],
+    assert lg.shape[2] >= vocab
+    lib().oracle_gibbs_step(x.ctypes.data_as(_i64p), seq.ctypes.data_as(_i64p), lgp, lg.shape[2], int(vocab),
                             np.float32(temperature), np.float32(top_p), nu.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                             up, int(seed), int(sample_offset), int(step), B, L, ent.ctypes.data_as(_f32p),
                             smp.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))

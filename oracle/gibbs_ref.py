@@ -41,12 +41,18 @@ def top_p_logits(logits: torch.Tensor, top_p: float) -> torch.Tensor:
     return out.scatter(-1, idx, torch.where(keep, srt, torch.full_like(srt, float("-inf"))))
 
 
-def gibbs_step_ref(x, seq, logits, temperature, top_p, n_unmask, u):
-    """x, seq (B,L) int64; logits (B,L,>=4096); u (B,L,4096) uniforms.  Returns new x, entropy, sampled."""
-    z = logits[..., :NVALID].float()
+def gibbs_step_ref(x, seq, logits, temperature, top_p, n_unmask, u, vocab: int = NVALID):
+    """x, seq (B,L) int64; logits (B,L,>=vocab); u (B,L,4096) uniforms.  Returns new x, entropy, sampled.
+    esm's order of operations: entropy and top-p on the WHOLE structure-logit row (`vocab` = 4096
+    for the stock head, 4101 for the ESMDiff head), the special ids >= 4096 are masked AFTER top-p, then temperature.
+    (A row whose nucleus holds special ids only has no valid candidate left; the best valid id is taken.)"""
+    z = logits[..., :vocab].float()
     logp = torch.log_softmax(z, -1)
     ent = -(logp.exp() * logp).sum(-1)
-    zp = top_p_logits(z, top_p)
+    zp = top_p_logits(z, top_p)[..., :NVALID]            # mask invalid ids after top-p
+    dead = torch.isinf(zp).all(-1, keepdim=True)
+    best_valid = torch.nn.functional.one_hot(z[..., :NVALID].argmax(-1), NVALID).bool()
+    zp = torch.where(dead & best_valid, torch.zeros_like(zp), zp)
     w = torch.softmax(zp / temperature, -1)
     g = 1e-10 - (u + 1e-10).log()
     sampled = (w / g).argmax(-1)

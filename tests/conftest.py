@@ -10,8 +10,24 @@ if str(ROOT) not in sys.path:
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
 
+def usable_cores() -> int:
+    """min(affinity, cgroup cpu quota).  torch defaults to one thread per visible core; under a cgroup quota (the GPU boxes
+    grant 16 of several hundred cores) that oversubscribes the oracle's f32 matmuls by an order of magnitude."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import torch
+    torch.set_num_threads(usable_cores())
 
 
 @pytest.fixture(scope="session")

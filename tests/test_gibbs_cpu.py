@@ -2,6 +2,7 @@
 the plain-torch statement of the same semantics (sort-based nucleus, log_softmax entropy, top-k by entropy).
 PARITY UNPINNED vs the reference: esm's iterative_sampling_raw is not available here (oracle/gibbs_ref.py header)."""
 import numpy as np
+import pytest
 import torch
 
 from oracle import c_oracle
@@ -28,13 +29,17 @@ def test_schedule_cosine_unmasking():
     assert G.unmask_schedule(256, 4) == [20, 55, 83, 98]   # 256 - int(cos(pi/8)*256 + .1) = 20, ...
 
 
-def test_c_oracle_matches_torch_semantics():
+@pytest.mark.parametrize("vocab", [4096, 4101])
+def test_c_oracle_matches_torch_semantics(vocab):
+    """Sort-based (torch) and threshold-search (C, what the HIP kernel mirrors) forms of the same rule, for the stock
+    4096-way head and the ESMDiff 4101-way head (entropy / nucleus over the whole row, specials masked after top-p)."""
     for (B, L, seed, scale, temp, top_p) in ((2, 9, 0, 2.0, 1.4, 0.9), (3, 12, 1, 4.0, 0.7, 0.5), (2, 8, 2, 1.0, 1.0, 1.0)):
         logits, u, seq, x = _case(B, L, seed, scale)
+        logits[:, 1::3, 4097] += 3.0 * scale          # a special id inside the nucleus of some rows (only seen when vocab = 4101)
         n_un = torch.tensor([3, 2, 4][:B], dtype=torch.int32)
-        xr, ent_r, smp_r = G.gibbs_step_ref(x, seq, logits, temp, top_p, n_un, u)
+        xr, ent_r, smp_r = G.gibbs_step_ref(x, seq, logits, temp, top_p, n_un, u, vocab=vocab)
         xc, ent_c, smp_c = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), temp, top_p, n_un.numpy(),
-                                               u=u.numpy(), return_aux=True)
+                                               u=u.numpy(), return_aux=True, vocab=vocab)
         masked = (x == 4096).numpy()
         np.testing.assert_allclose(ent_c[masked], ent_r.numpy()[masked], rtol=0, atol=3e-5)
         # draws agree everywhere (a disagreement needs a nucleus-boundary or argmax near-tie: none in these cases)
@@ -45,6 +50,22 @@ def test_c_oracle_matches_torch_semantics():
         assert changed.sum(1).tolist() == n_un.tolist()
         assert not changed[:, 0].any() and not changed[:, -1].any() and xc[0, 3] == 17
         assert xc[changed].max() < 4096
+
+
+def test_full_row_semantics_differ_from_truncated_row():
+    """4101-way head: a heavy special id takes nucleus mass and entropy (esm runs top_p_logits and the entropy on the whole
+    row and masks invalid ids afterwards), so fewer valid ids survive than on the truncated row; and when the special id
+    alone exceeds top_p nothing valid survives and the best valid id is taken."""
+    logits, u, seq, x = _case(1, 6, 9, 1.0)
+    logits[0, 2, 4100] = 12.0                                   # ~ all of the mass on a special id
+    n_un = np.array([4], np.int32)
+    _, e96, s96 = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 1.4, 0.9, n_un, u=u.numpy(), return_aux=True, vocab=4096)
+    _, e01, s01 = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 1.4, 0.9, n_un, u=u.numpy(), return_aux=True, vocab=4101)
+    assert e01[0, 2] < 0.5 < e96[0, 2]                          # the spike dominates the full-row entropy only
+    assert s01[0, 2] == int(logits[0, 2, :4096].argmax())       # nothing valid in the nucleus -> best valid id
+    assert s01[0, 2] < 4096 and s96[0, 2] < 4096
+    _, er, sr = G.gibbs_step_ref(x, seq, logits, 1.4, 0.9, torch.tensor(n_un), u, vocab=4101)
+    assert int(sr[0, 2]) == s01[0, 2] and abs(float(er[0, 2]) - e01[0, 2]) < 3e-5
 
 
 def test_nucleus_keeps_top1_and_respects_mass():

@@ -399,7 +399,15 @@ def test_structure_decoder_vs_oracle(B, L):
     with torch.no_grad():
         ref = ref_net(tok)
     dec = StructureDecoder(TINY_DECODER, sd, max_batch=B, max_len=L)
-    got = dec.decode(tok.cuda()).cpu()
+    got, pl = dec.decode(tok.cuda(), return_plddt=True)
+    got, pl = got.cpu(), pl.cpu()
+    with torch.no_grad():
+        _, pl_ref = ref_net(tok, return_plddt=True)
+    # pLDDT = mean of the 50-bin categorical mixture (what to_pdb writes as B-factor): a softmax average, so the bf16
+    # logit noise (~1e-2) moves it by well under a percent
+    assert pl.shape == pl_ref.shape == (B, L - 2) and float(pl.min()) > 0 and float(pl.max()) < 1
+    assert float((pl - pl_ref).abs().max()) < 5e-3, float((pl - pl_ref).abs().max())
+    assert float(pl_ref.std()) > 1e-3                                       # the fixture is not constant
     assert got.shape == ref.shape == (B, L - 2, 3, 3)
     # the frame is rigid: ideal N-CA / CA-C bond lengths whatever the network says
     assert float(((got[:, :, 1] - got[:, :, 0]).norm(dim=-1) - 1.4592).abs().max()) < 2e-3
@@ -571,6 +579,53 @@ def test_model_wrapper_reference_rng_parity(tmp_path):
     model.net.close()
 
 
+def test_parity_stream_runs_across_batches_and_sigma0_conditioning():
+    """(1) noise="torch-cpu" keeps ONE generator stream per run, like the reference's process-wide RNG: the second batch
+    of a run continues the stream (its samples differ from the first batch's), and a new run (sample_offset 0) restarts
+    it.  (2) A model built with time_conditioning = false still adds sigma_embedder(0) (model.py:466-471, 535-541)."""
+    import dataclasses
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.model import MaskedDiffusionLanguageModeling
+    from esmdiff_amd.schedule import LogLinearNoise, timestep_embedding
+    from esmdiff_amd.weights import random_init_state_dict
+    from oracle.esm3_ref import build_from_state_dict
+    sd = random_init_state_dict(TINY, seed=4)
+    model = MaskedDiffusionLanguageModeling(sd, TINY, LogLinearNoise(), max_batch=4, max_len=40, device=0)
+    B, L, T = 2, 20, 3
+    g = torch.Generator().manual_seed(1)
+    seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1)
+    a0 = model.ddpm_sample(seq, num_steps=T, seed=9, sample_offset=0, noise="torch-cpu").cpu()
+    a1 = model.ddpm_sample(seq, num_steps=T, seed=9, sample_offset=B, noise="torch-cpu").cpu()
+    b0 = model.ddpm_sample(seq, num_steps=T, seed=9, sample_offset=0, noise="torch-cpu").cpu()
+    assert torch.equal(a0, b0) and not torch.equal(a0, a1)
+    model.net.close()
+    # (2)
+    cfg0 = dataclasses.replace(TINY, time_conditioning=False)
+    m0 = MaskedDiffusionLanguageModeling(sd, cfg0, LogLinearNoise(), max_batch=4, max_len=40, device=0)
+    net, emb = build_from_state_dict(cfg0, sd)
+    x = torch.full((B, L), MASK, dtype=torch.int64)
+    with torch.no_grad():
+        cond0 = torch.tile(emb(torch.zeros(B))[:, None, :], (1, L, 1))
+        ref0 = net(structure_tokens=x, sequence_tokens=seq, auxiliary_embeddings=cond0).structure_logits
+        refn = net(structure_tokens=x, sequence_tokens=seq).structure_logits
+    tf = m0.net.conditioning_rows(timestep_embedding(torch.tensor([0.7, 0.3]), cfg0.freq_dim))
+    assert tf is not None and torch.equal(tf[0], tf[1])                     # sigma is zeroed, the embedder still runs
+    got = m0.net.forward_logits(x.cuda(), seq.cuda(), tf[0]).float().cpu()
+    assert float((got - ref0).abs().max()) < 0.12 and float((ref0 - refn).abs().max()) > 0.12
+    ids = m0.ddpm_sample(seq, num_steps=T, seed=1).cpu()                    # whole loop runs through the sigma(0) path
+    assert int((ids == MASK).sum()) == 0
+    m0.net.close()
+    # out-of-range ids are refused by the host wrapper instead of being looked up
+    eng = MaskedDiffusionLanguageModeling(sd, TINY, LogLinearNoise(), max_batch=2, max_len=24, device=0).net
+    bad = seq.clone()
+    bad[0, 3] = 64
+    with pytest.raises(ValueError, match="out of range"):
+        eng.forward_logits(x.cuda(), bad.cuda(), None)
+    with pytest.raises(ValueError, match="out of range"):
+        eng.forward_logits(torch.full((B, L), 4101, dtype=torch.int64).cuda(), seq.cuda(), None)
+    eng.close()
+
+
 def test_cli_ddpm_full_size_random_init(tmp_path):
     """The CLI end to end on ESM3-open-sized random weights: 58-residue synthetic target, 4 samples, 3 steps."""
     from esmdiff_amd.sample_esmdiff import main
@@ -631,27 +686,47 @@ def test_config5_inpainting_prior_properties(tiny):
 
 # ---------------------------------------------------------------------------------------------------
 # "gibbs" mode (entropy-ordered iterative unmasking; esm iterative_sampling_raw, parity unpinned vs esm)
+@pytest.fixture(scope="module")
+def tiny_stock():
+    """The stock-ESM3 head shape: 4096-way structure head, no sigma embedder (what gibbs mode samples from without --ckpt)."""
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ModelConfig(d_model=512, n_heads=8, v_heads=128, n_layers=1, n_structure_heads=4096, time_conditioning=False)
+    sd = {k: v for k, v in random_init_state_dict(cfg, seed=2).items() if not k.startswith("sigma_embedder.")}
+    eng = Engine(cfg, sd, max_batch=4, max_len=300)
+    yield eng
+    eng.close()
+
+
+@pytest.mark.parametrize("vocab", [4101, 4096])
 @pytest.mark.parametrize("B,L,temp,top_p", [(2, 9, 1.4, 0.9), (3, 60, 0.7, 0.5), (2, 258, 1.0, 1.0)])
-def test_gibbs_step_bit_exact(tiny, B, L, temp, top_p):
+def test_gibbs_step_bit_exact(tiny, tiny_stock, vocab, B, L, temp, top_p):
+    """Both head widths: entropy and nucleus over the whole row (4101 columns for the ESMDiff head), draws over the 4096
+    codebook ids; some rows carry a heavy special-id logit so that the two widths really differ."""
     from oracle import c_oracle
-    _, _, eng, _, _ = tiny
+    eng = tiny[2] if vocab == 4101 else tiny_stock
+    assert eng.cfg.n_structure_heads == vocab
     g = torch.Generator().manual_seed(L)
     logits = torch.randn(B, L, 4104, generator=g) * 3
+    logits[:, 1::4, 4099] += 9.0
+    logits[0, 3, 4097] = 40.0                     # nothing valid survives the nucleus (4101-way): best valid id
     u = torch.rand(B, L, 4096, generator=g)
     seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1)
     x = torch.full((B, L), MASK, dtype=torch.int64)
     x[:, 0], x[:, -1] = 4098, 4097
     x[0, 2] = 5
     n_un = torch.tensor([3, 1, 5][:B], dtype=torch.int32)
-    want = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), temp, top_p, n_un.numpy(), u=u.numpy())
+    want = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), temp, top_p, n_un.numpy(), u=u.numpy(), vocab=vocab)
     got = eng.gibbs_step(x.clone().cuda(), seq.cuda(), logits.cuda(), temp, top_p, n_un, u=u.cuda()).cpu().numpy()
     assert np.array_equal(got, want)
     want = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), temp, top_p, n_un.numpy(), seed=11,
-                               sample_offset=2 ** 33 + 1, step=4)
+                               sample_offset=2 ** 33 + 1, step=4, vocab=vocab)
     got = eng.gibbs_step(x.clone().cuda(), seq.cuda(), logits.cuda(), temp, top_p, n_un, seed=11,
                          sample_offset=2 ** 33 + 1, step=4).cpu().numpy()
     assert np.array_equal(got, want)
     assert ((got != x.numpy()).sum(1) == n_un.numpy()).all()
+    assert int(got[(got != x.numpy())].max()) < 4096
 
 
 def test_gibbs_iterative_sampling_raw_and_cli(tiny, tmp_path):
@@ -688,6 +763,23 @@ def test_gibbs_iterative_sampling_raw_and_cli(tiny, tmp_path):
     assert torch.equal(o2[0].structure_tokens[keep], known[keep]) and int((o2[0].structure_tokens == MASK).sum()) == 0
     with pytest.raises(NotImplementedError):
         iterative_sampling_raw(eng, prots[:1], [GenerationConfig(track="sequence")])
+    # with a decoder attached the outputs are what the reference's call site needs: prot.to_pdb(tmp) works
+    # (sample_esmdiff.py:124-128); without one the protein refuses, loudly
+    from esmdiff_amd.config import TINY_DECODER
+    from esmdiff_amd.engine import StructureDecoder
+    from esmdiff_amd.weights import random_init_decoder_state_dict
+    with pytest.raises(ValueError, match="decoder"):
+        out[0].to_pdb(tmp_path / "no.pdb")
+    dec = StructureDecoder(TINY_DECODER, random_init_decoder_state_dict(TINY_DECODER, seed=2), max_batch=2, max_len=60)
+    o3 = iterative_sampling_raw(eng, prots, cfgs, seed=5, decoder=dec)
+    assert all(torch.equal(a.structure_tokens, b.structure_tokens) for a, b in zip(o3, out))
+    assert all(o.coordinates.shape == (58, 3, 3) and o.plddt.shape == (58,) for o in o3)
+    o3[1].to_pdb(tmp_path / "one.pdb")
+    back = ESMProtein.from_pdb(tmp_path / "one.pdb")
+    assert back.sequence == seqs and float((back.coordinates - o3[1].coordinates).abs().max()) < 1e-3
+    bf = [float(ln[60:66]) for ln in (tmp_path / "one.pdb").read_text().splitlines() if ln.startswith("ATOM")]
+    assert abs(bf[0] - float(o3[1].plddt[0])) < 6e-3
+    dec.close()
 
 
 def test_cli_gibbs_default_mode(tmp_path):

@@ -39,8 +39,12 @@ def test_pdb_reader_and_tokenizer(tmp_path):
     out = tmp_path / "y.pdb"
     ESMProtein(sequence="RPD", coordinates=torch.nan_to_num(prot.coordinates)).to_pdb(out)
     assert ESMProtein.from_pdb(out).sequence == "RPD"
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="decoder"):
         ESMProtein(sequence="RPD").to_pdb(out)
+    # B-factor column = pLDDT, as esm's to_pdb writes it
+    ESMProtein(sequence="RPD", coordinates=torch.nan_to_num(prot.coordinates), plddt=torch.tensor([0.25, 0.5, 0.875])).to_pdb(out)
+    bf = [float(ln[60:66]) for ln in out.read_text().splitlines() if ln.startswith("ATOM")]
+    assert bf[:3] == [0.25] * 3 and bf[-1] == 0.88
 
 
 def test_merge_pdbfiles_matches_reference_golden(golden_dir, tmp_path):
@@ -109,6 +113,152 @@ def test_sharded_equals_unsharded_gloo_world2(tmp_path):
     want = c_oracle.ddpm_step(np.full((5, 9), 4096, np.int64), logits, 0.6, 0.5, seed=5, sample_offset=0, step=3)
     assert np.array_equal(got, want)
     assert len({tuple(r) for r in got.tolist()}) > 1      # samples differ: the noise is per global sample index
+
+
+class _StubEngine:
+    """Stands in for esmdiff_amd.engine.Engine in the CPU tests of the driver functions: ids are a pure function of the
+    GLOBAL sample index (like the Philox noise), so any sharding / chunking must reproduce the same ensemble."""
+    max_batch = 2
+    device = torch.device("cpu")
+    has_geom = False
+
+    @staticmethod
+    def ids(n, L, seed, offset):
+        b = torch.arange(offset, offset + n)[:, None]
+        return (seed * 7 + b * 131 + torch.arange(L)[None] * 17) % 4096
+
+    def gibbs_sample(self, seq, x0, table, temperature, top_p, *, seed, sample_offset=0):
+        n, L = x0.shape
+        assert n <= self.max_batch
+        return torch.where(x0 == 4096, self.ids(n, L, seed, sample_offset), x0)
+
+
+class _StubModel:
+    def __init__(self):
+        self.net = _StubEngine()
+        self.device = self.net.device
+
+    def ddpm_sample(self, num_steps, sequence_tokens, eps, input_prior, sample_max_t, seed, sample_offset, noise):
+        n, L = sequence_tokens.shape
+        assert n <= self.net.max_batch, "the driver must chunk to the engine capacity"
+        return _StubEngine.ids(n, L, seed, sample_offset)
+
+
+class _StubDecoder:
+    device = torch.device("cpu")
+    has_plddt = True
+    max_batch = 3
+
+    def decode(self, full, return_plddt=False):
+        body = full[:, 1:-1].to(torch.float32)
+        coords = body[:, :, None, None] * 1e-3 + torch.arange(9, dtype=torch.float32).view(1, 1, 3, 3)
+        return (coords, (body % 100) / 100) if return_plddt else coords
+
+
+def _cli_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from esmdiff_amd.sample_esmdiff import ddpm_sample_by_esm, minibatch_gibbs_by_esm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seq = "ACDEFGHIKL"
+    ddpm_sample_by_esm(seq, _StubModel(), Path(tmp) / "ddpm", "t", num_samples=7, num_steps=3, seed=4, timestamp=False,
+                       decoder=_StubDecoder())
+    minibatch_gibbs_by_esm(seq, _StubModel(), Path(tmp) / "gibbs", "t", num_samples=7, num_steps=3, seed=4,
+                           timestamp=False, decoder=_StubDecoder())
+    dist.destroy_process_group()
+
+
+def test_cli_drivers_shard_decode_gather_gloo_world2(tmp_path):
+    """world_size 2, odd sample count, engine capacity 2 (forces chunking), decoder capacity 3: every rank samples and
+    DECODES its own shard, one gather per artefact, rank 0 writes the token file and the multi-MODEL PDB in global sample
+    order — identical to what a single process computes."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_cli_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    N, L = 7, 10
+    for mode, sub, toks in (("ddpm", "step3_eps1e-05_N7", _StubEngine.ids(N, L + 2, 4, 0)[:, 1:-1]),
+                            ("gibbs", "T1.4_step3_topp0.9_N7", _StubEngine.ids(N, L + 2, 4, 0)[:, 1:-1])):
+        d = tmp_path / mode / sub
+        got = np.load(d / "t.tokens.npy")
+        assert got.shape == (N, L) and np.array_equal(got, toks.numpy()), mode
+        meta = json.loads((d / "t.json").read_text())
+        assert meta["world_size"] == 2 and meta["num_samples"] == N
+        text = (d / "t.pdb").read_text().splitlines()
+        assert sum(ln.startswith("MODEL") for ln in text) == N
+        atoms = [ln for ln in text if ln.startswith("ATOM")]
+        assert len(atoms) == N * L * 3
+        # sample i, residue j: x of atom N = token * 1e-3 + 0; B-factor = (token % 100) / 100
+        for i in (0, 3, 6):
+            for j in (0, L - 1):
+                ln = atoms[(i * L + j) * 3]
+                assert abs(float(ln[30:38]) - float(toks[i, j]) * 1e-3) < 2e-3, (mode, i, j)
+                assert abs(float(ln[60:66]) - float(toks[i, j] % 100) / 100) < 6e-3
+
+
+def test_engine_capacity_covers_every_issued_batch():
+    """max_batch must come from the batches the splitters really issue (per target, per mode, remainder batch
+    included), and any batch can be chunked to a smaller engine."""
+    from esmdiff_amd.sample_esmdiff import DEFAULT_NMAX, batch_sizes, engine_capacity
+    assert engine_capacity([100, 500], 1000, DEFAULT_NMAX, "ddpm") == 1000      # the 100-residue target is issued as one batch
+    assert engine_capacity([200], 1000, DEFAULT_NMAX, "gibbs") == max(batch_sizes(200, 1000, DEFAULT_NMAX)) == 842
+    assert engine_capacity([200], 1000, DEFAULT_NMAX, "ddpm") == max(batch_sizes(202, 1000, DEFAULT_NMAX))
+    nmax = 200 * 200 * 105
+    for n_tok, n in ((60, 4), (258, 100), (258, 1000), (1026, 33)):
+        ref = batch_sizes(n_tok, n, nmax)
+        for cap in (1, 7, 64):
+            got = batch_sizes(n_tok, n, nmax, cap)
+            assert sum(got) == n and max(got) <= cap
+        assert batch_sizes(n_tok, n, nmax, max(ref)) == ref                      # a big enough engine: the reference's split
+
+
+def test_hydra_config_next_to_checkpoint(tmp_path):
+    """checkpoint_utils.py:45-57: the run's .hydra/config.yaml decides noise schedule / time_conditioning / head width."""
+    from esmdiff_amd.model import config_from_hydra_yaml
+    from esmdiff_amd.schedule import CosineNoise, LogLinearNoise
+    from esmdiff_amd.weights import checkpoint_file_and_config
+    run = tmp_path / "run"
+    (run / ".hydra").mkdir(parents=True)
+    (run / "checkpoints").mkdir()
+    ck = run / "checkpoints" / "last.pt"
+    ck.write_bytes(b"")
+    assert checkpoint_file_and_config(ck) == (ck, None)
+    (run / ".hydra" / "config.yaml").write_text(
+        "model:\n  noise_schedule:\n    _target_: slm.utils.noise_utils.CosineNoise\n    eps: 0.002\n"
+        "  time_conditioning: false\n  net:\n    n_structure_heads: 4101\n")
+    f, y = checkpoint_file_and_config(ck)
+    assert f == ck and y == run / ".hydra" / "config.yaml"
+    cfg, noise = config_from_hydra_yaml(y)
+    assert isinstance(noise, CosineNoise) and noise.eps == 0.002 and cfg.time_conditioning is False
+    (run / ".hydra" / "config.yaml").write_text("model:\n  noise_schedule:\n    _target_: slm.utils.noise_utils.LogLinearNoise\n")
+    cfg, noise = config_from_hydra_yaml(y)
+    assert isinstance(noise, LogLinearNoise) and cfg.time_conditioning is True
+    (run / ".hydra" / "config.yaml").write_text("model:\n  noise_schedule:\n    _target_: slm.utils.noise_utils.GeometricNoise\n")
+    with pytest.raises(NotImplementedError):
+        config_from_hydra_yaml(y)
+    with pytest.raises(FileNotFoundError):
+        checkpoint_file_and_config(tmp_path / "nope.pt")
+    with pytest.raises(ValueError):
+        (tmp_path / "x.bin").write_bytes(b"")
+        checkpoint_file_and_config(tmp_path / "x.bin")
+
+
+def test_checkpoint_loader_needs_module_dict(tmp_path):
+    from esmdiff_amd.weights import load_checkpoint_state_dict
+    torch.save({"net.a": torch.zeros(1)}, tmp_path / "flat.pt")
+    with pytest.raises(KeyError, match="module"):
+        load_checkpoint_state_dict(tmp_path / "flat.pt")
+    torch.save({"module": {"foo": torch.zeros(1)}}, tmp_path / "other.pt")
+    with pytest.raises(KeyError, match="net"):
+        load_checkpoint_state_dict(tmp_path / "other.pt")
+    torch.save({"module": {"net.x": torch.ones(2)}, "ds_version": "0.1"}, tmp_path / "ok.pt")
+    assert list(load_checkpoint_state_dict(tmp_path / "ok.pt")) == ["net.x"]
+    import functools
+    torch.save({"module": {"net.x": torch.ones(2)}, "hyper_parameters": functools.partial(print)}, tmp_path / "obj.pt")
+    with pytest.raises(RuntimeError, match="Re-export"):
+        load_checkpoint_state_dict(tmp_path / "obj.pt")
 
 
 def test_cli_argparser_matches_reference_defaults():
