@@ -61,7 +61,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if LIB.exists() and not force and LIB.stat().st_mtime >= _newest_src():
         return LIB
     cc = _hipcc()
-    headers = [p.stat().st_mtime for p in list(CSRC.glob("*.h")) + [INCLUDE / "esmdiff_hip.h"]]
+    headers = [p.stat().st_mtime for p in list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [INCLUDE / "esmdiff_hip.h"]]
 
     def compile_one(name):
         src, obj = CSRC / f"{name}.hip", OBJDIR / f"{name}.o"

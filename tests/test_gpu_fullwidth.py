@@ -142,7 +142,7 @@ def test_forward_full_depth_vs_oracle(full, B, L):
     """One forward of the 1.4 B-parameter instance the benchmark runs (48 blocks, d 1536, 24 heads, V 4101) against
     the f32 oracle network on the host, then the first reverse-diffusion update: engine logits -> engine sampler vs
     oracle logits -> C-oracle sampler with the same Philox noise.  Bars are set from the measured figures (DESIGN.md
-    section 4) with a factor ~2 of head-room; what they bound is the bf16 rounding of GEMM operands and of the branch
+    section 4) with a factor ~2-3 of head-room; what they bound is the bf16 rounding of GEMM operands and of the branch
     outputs accumulated over 48 blocks in an f32 residual stream."""
     from esmdiff_amd.schedule import ddpm_schedule
     from oracle import c_oracle
@@ -172,9 +172,11 @@ def test_forward_full_depth_vs_oracle(full, B, L):
         want2 = c_oracle.ddpm_step(x.numpy(), lg.float().cpu().numpy(), mc_t, mc_s, seed=42, sample_offset=3, step=i)
         assert np.array_equal(got, want2)
         out[tag] = s
-        assert s["cos"] > 0.995, (tag, s)
-        assert s["max_err"] < 0.5 and s["mean_err"] < 4e-2, (tag, s)
-        assert s["update_id_agree_masked_rows"] > 0.8, (tag, s)
+        # measured (r02): max 0.0127-0.0141, mean 0.0023, cosine 0.999988, first-update ids 100 %
+        assert s["cos"] > 0.9999, (tag, s)
+        assert s["max_err"] < 0.04 and s["mean_err"] < 5e-3, (tag, s)
+        assert s["argmax_agree"] > 0.97, (tag, s)
+        assert s["update_id_agree_masked_rows"] >= 0.98, (tag, s)
     _record(f"full48_B{B}_L{L}", out)
 
 
@@ -204,7 +206,7 @@ def test_structure_decoder_production_width():
         assert float(((got[:, :, 1] - got[:, :, 2]).norm(dim=-1) - 1.5251).abs().max()) < 2e-3
         err = (got - ref).norm(dim=-1)
         rec[f"B{B}_L{L}"] = {"mean_A": float(err.mean()), "max_A": float(err.max())}
-        assert float(err.mean()) < 0.08 and float(err.max()) < 0.6, rec
+        assert float(err.mean()) < 0.08 and float(err.max()) < 0.3, rec       # measured 0.038 / 0.107 A
     _record("decoder1280_3blocks", rec)
     dec.close()
 
@@ -243,6 +245,7 @@ def test_structure_encoder_full_size_margin(B, L):
            "max_rel_margin_of_disagreements": float(rel[~agree].max()) if (~agree).any() else 0.0,
            "median_gap_best_vs_second": float(gap12.median())}
     _record(f"encoder1024_B{B}_L{L}", rec)
-    NOISE = 0.03   # relative distance error a bf16 GEMM chain can cause (2^-8 per operand, a few hundred terms)
+    NOISE = 0.004  # relative distance error of the bf16 GEMM chain; measured: every disagreement has margin < 5e-4
     assert float(rel.max()) < NOISE, rec                       # never a clearly farther code
     assert bool(agree[gap12 > 2 * NOISE].all()), rec           # clear winners always agree
+    assert rec["agree"] > 0.95, rec                            # measured 0.984 / 0.991
