@@ -5,7 +5,10 @@ from __future__ import annotations
 import ctypes
 from pathlib import Path
 
-_LIB_PATH = Path(__file__).resolve().parent / "lib" / "libesmdiff_hip.so"
+import os
+
+# ESMDIFF_LIB: another build of the same library (ablation / A-B variants made by scratch/build_variant.py); never a fallback
+_LIB_PATH = Path(os.environ.get("ESMDIFF_LIB") or Path(__file__).resolve().parent / "lib" / "libesmdiff_hip.so")
 _lib = None
 
 c_f32p = ctypes.POINTER(ctypes.c_float)

@@ -66,13 +66,16 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // v_cvt_pk
   return u;
 }
 #define ED_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
-// -DED_GEMM_DEBUG: ESMDIFF_GEMM_DBG bits (2: no LDS-DMA in the main loop, 4: no stores, 8: no vmcnt wait, 16: no
-// barrier) for ablations, and s_memtime stamps of one workgroup into the `bias` buffer of an EPI_BF16 launch.
-#ifdef ED_GEMM_DEBUG
-#define ED_DBG(bit) (dbg & (bit))
-#else
-#define ED_DBG(bit) 0
+// Ablation builds: -DED_ABL=<bits> compiles parts of the kernel out (results are then wrong by construction; only the
+// times mean something).  Bits: 1 no fragment reads, 2 no LDS-DMA in the main loop, 4 no stores, 8 no vmcnt wait, 16 no
+// barrier, 64 no MFMA, 128 no lgkmcnt waits, 256 every workgroup streams the panels of tile (0,0) (perfect L2 locality).
+// Compile-time on purpose: the r01 run-time switch (a kernel argument tested around every statement) made the debug
+// build itself 1.5x slower than the product build, so its differences said little about the product kernel.
+// -DED_GEMM_DEBUG adds s_memtime stamps of one workgroup into the `bias` buffer of an EPI_BF16 launch.
+#ifndef ED_ABL
+#define ED_ABL 0
 #endif
+#define ED_DBG(bit) (((ED_ABL) & (bit)) != 0)
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
@@ -112,9 +115,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int r = h * 128 + (i * 8 + wave) * 8 + srow;
-        const int am = min(m0_ + r, M - 1);
+        const int am = min((ED_DBG(256) ? 0 : m0_) + r, M - 1);
         ao[h][i] = (uint32_t)(((int64_t)am * K + schunk * 8) * 2);
-        wo[h][i] = (uint32_t)(((int64_t)(n0_ + r) * K + schunk * 8) * 2);
+        wo[h][i] = (uint32_t)(((int64_t)((ED_DBG(256) ? 0 : n0_) + r) * K + schunk * 8) * 2);
       }
   };
   set_offsets(a_off, w_off, m0, n0);
@@ -136,26 +139,41 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
   // K-tile 0 of the NEXT tile (xnext), which keeps the DMA stream running across the tile boundary.
   bool xnext = false;
   int nk_ = K / BK;
+  // -DED_KROT=1 (experiment): tile column tn starts its K loop at K-tile (tn & 3) * nk / 4 and wraps, so that the four
+  // workgroups of an XCD that share an A panel do not ask L2 for the same lines at the same moment (a function of the
+  // COLUMN tile only: a row's result must not depend on where its sample sits in the batch)
+#ifndef ED_KROT
+#define ED_KROT 0
+#endif
+  int rot = 0, rotn = 0;
+  auto krot_of = [&](int n0_) { return ED_KROT ? ((n0_ / BN) & 3) * (nk_ >> 2) : 0; };
+  auto kt_of = [&](int v, int r) {
+    int kk = v + r;
+    return kk >= nk_ ? kk - nk_ : kk;
+  };
+  rot = krot_of(n0);
   auto issue_Ah = [&](int h, int buf, int v) {
     if (v < nk_) {
-      const char* sb = Ab + (size_t)v * kstride;
+      const char* sb = Ab + (size_t)kt_of(v, rot) * kstride;
 #pragma unroll
       for (int i = 0; i < 2; ++i) glds16s(sb, a_off[h][i], lds_base + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
     } else if (xnext && v == nk_) {
+      const char* sb = Ab + (size_t)rotn * kstride;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) glds16s(Ab, a_offn[h][i], lds_base + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+      for (int i = 0; i < 2; ++i) glds16s(sb, a_offn[h][i], lds_base + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
     }
   };
   auto issue_Wh = [&](int h, int buf, int v) {
     if (v < nk_) {
-      const char* sb = Wb + (size_t)v * kstride;
+      const char* sb = Wb + (size_t)kt_of(v, rot) * kstride;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         glds16s(sb, w_off[h][i], lds_base + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
     } else if (xnext && v == nk_) {
+      const char* sb = Wb + (size_t)rotn * kstride;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        glds16s(Wb, w_offn[h][i], lds_base + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+        glds16s(sb, w_offn[h][i], lds_base + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
     }
   };
   auto issue_A = [&](int buf, int kt) {
@@ -163,14 +181,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        glds16(Ab + (size_t)kt * kstride + a_off[h][i], smem + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
+        glds16(Ab + (size_t)kt_of(kt, rot) * kstride + a_off[h][i], smem + (h * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
   };
   auto issue_W = [&](int buf, int kt) {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        glds16(Wb + (size_t)kt * kstride + w_off[h][i],
+        glds16(Wb + (size_t)kt_of(kt, rot) * kstride + w_off[h][i],
                smem + ((2 + h) * 2 + buf) * HALF_BYTES + (i * 8 + wave) * 1024);
   };
 
@@ -190,6 +208,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
 #define ED_DSR(dst, addr, imm)                                                                       \
   do {                                                                                               \
     if (!ED_DBG(1)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm)); \
+    else asm volatile("" : "=v"(dst));                                                               \
   } while (0)
   // half-sets: A[f][j] = rows (mh*64 + f*32 ..), k-step 2*h + j ; B[j] = cols (nh*32 ..), k-step 2*h + j
   auto read_A = [&](bf16x8 (&a)[2][2], auto P, auto MH, auto H) {
@@ -333,6 +352,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     if (xnext) {
       tile_origin(vtn, m0n, n0n);
       set_offsets(a_offn, w_offn, m0n, n0n);
+      rotn = krot_of(n0n);
     }
     if (!have_k0) {
       issue_A(0, 0);
@@ -369,12 +389,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     // Every wave is past the barrier of the last K-tile and reads no more LDS for this tile: stage 1 is free, so
     // K-tile 1 of the next tile starts streaming now, under the epilogue.
     if (xnext && nk > 1) {
+      const size_t k1 = (size_t)kt_of(1, rotn) * kstride;
 #pragma unroll
       for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          glds16s(Ab + kstride, a_offn[h][i], lds_base + (h * 2 + 1) * HALF_BYTES + (i * 8 + wave) * 1024);
-          glds16s(Wb + kstride, w_offn[h][i], lds_base + ((2 + h) * 2 + 1) * HALF_BYTES + (i * 8 + wave) * 1024);
+          glds16s(Ab + k1, a_offn[h][i], lds_base + (h * 2 + 1) * HALF_BYTES + (i * 8 + wave) * 1024);
+          glds16s(Wb + k1, w_offn[h][i], lds_base + ((2 + h) * 2 + 1) * HALF_BYTES + (i * 8 + wave) * 1024);
         }
     }
 
@@ -478,6 +499,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
       if (xnext) {
         m0 = m0n;
         n0 = n0n;
+        rot = rotn;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -488,6 +510,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
       } else {
         tile_origin(vtn, m0, n0);
         set_offsets(a_off, w_off, m0, n0);
+        rot = krot_of(n0);
       }
     }
   }
