@@ -71,6 +71,11 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {  // ds_read_b64
 
 // Two register budgets of the same body: 3 waves per SIMD (137 VGPRs, no spill) and 4 waves per SIMD (128 VGPRs, a
 // handful of spilled address registers outside the tile loop); the launcher picks (ESMDIFF_ATTN_OCC overrides).
+// Ablation builds (-DED_ATTN_ABL=<bits>, wrong results by construction): 1 no v_exp_f32, 2 K/V staged once (tile 0 is
+// reused: no LDS-DMA in the loop), 4 no vmcnt wait / barrier per tile, 8 no P·V MFMAs.
+#ifndef ED_ATTN_ABL
+#define ED_ATTN_ABL 0
+#endif
 #define ED_ATTN_NAME attention_kernel_occ3
 #define ED_ATTN_WPE 3
 #include "attention_kernel.inc"
@@ -117,10 +122,11 @@ hipError_t launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* qkv,
   }();
   const int W = forced > 0 ? std::min(forced, 10) : (forced < 0 ? attention_waves(L, occ) : std::min(4, (L + 31) / 32));
   const int nw = (L + 31) / 32;
-  dim3 grid((nw + W - 1) / W, B * H), block(64 * W);
+  const int nqb = (nw + W - 1) / W, BH = B * H;
+  dim3 grid(8 * nqb * ((BH + 7) / 8)), block(64 * W);
   const size_t lds = (L <= KV_TILE ? 1 : 2) * 2 * KV_BYTES;
-  if (occ == 3) hipLaunchKernelGGL(attention_kernel_occ3, grid, block, lds, stream, q, k, qkv, ctx, L, H);
-  else hipLaunchKernelGGL(attention_kernel_occ4, grid, block, lds, stream, q, k, qkv, ctx, L, H);
+  if (occ == 3) hipLaunchKernelGGL(attention_kernel_occ3, grid, block, lds, stream, q, k, qkv, ctx, L, H, BH, nqb);
+  else hipLaunchKernelGGL(attention_kernel_occ4, grid, block, lds, stream, q, k, qkv, ctx, L, H, BH, nqb);
   return hipGetLastError();
 }
 

@@ -231,17 +231,41 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
   const int b = tok / L, l = tok - b * L;
   const float qscale = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e): softmax in base 2
 
+  // both rows are requested before anything is reduced (6 x 16 B in flight per lane at D = 1536)
+  uint4 raw[2][NS];
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     const bf16_t* src = qkv + (int64_t)tok * (3 * D) + which * D;
+#pragma unroll
+    for (int j = 0; j < NS; ++j)  // D = 1280 (the VQ-VAE decoder stack) ends in a half slab: lanes past D hold zeros and are not stored
+      raw[which][j] = (j * 512 + lane * 8 < D) ? *reinterpret_cast<const uint4*>(src + j * 512 + lane * 8) : uint4{0, 0, 0, 0};
+  }
+  // rotary factors of this lane's 8 columns: they depend on the position and on the column offset inside the head only,
+  // i.e. they are the same for every slab and for q and k -> four 16-byte loads per token instead of 16 scalar loads per
+  // slab and row (r01: the kernel issued ~150 small loads per lane and ran at 4.5 TB/s instead of the copy rate)
+  const int o = (lane & 7) * 8;          // column offset inside the head
+  const int fi = o & 31;                 // rotary frequency index of element 0
+  const bool second = o >= 32;
+  float cs[8], sn[8];
+  {
+    const f32x4 c0 = *reinterpret_cast<const f32x4*>(rope_cos + l * 32 + fi), c1 = *reinterpret_cast<const f32x4*>(rope_cos + l * 32 + fi + 4);
+    const f32x4 s0 = *reinterpret_cast<const f32x4*>(rope_sin + l * 32 + fi), s1 = *reinterpret_cast<const f32x4*>(rope_sin + l * 32 + fi + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cs[e] = c0[e]; cs[4 + e] = c1[e];
+      sn[e] = second ? s0[e] : -s0[e];   // rotate_half: first half gets -x2, second half gets +x1
+      sn[4 + e] = second ? s1[e] : -s1[e];
+    }
+  }
+
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
     const float* w = which ? k_w : q_w;
     float v[NS][8];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
-      // D = 1280 (the VQ-VAE decoder stack) ends in a half slab: lanes past D hold zeros and are not stored
-      const uint4 p = (j * 512 + lane * 8 < D) ? *reinterpret_cast<const uint4*>(src + j * 512 + lane * 8) : uint4{0, 0, 0, 0};
-      const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+      const uint32_t pw[4] = {raw[which][j].x, raw[which][j].y, raw[which][j].z, raw[which][j].w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[j][2 * e] = bf2f(pw[e] & 0xffffu);
@@ -259,25 +283,23 @@ __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const bf16_t* __restr
         q += d * d;
       }
     const float rstd = rsqrtf(wsum(q) / (float)D + 1e-5f);
-    const int o = (lane & 7) * 8;          // column offset inside the head
-    const int fi = o & 31;                 // rotary frequency index of element 0
-    const bool second = o >= 32;
     bf16_t* dst = which ? ko : qo;
 #pragma unroll
     for (int j = 0; j < NS; ++j) {
       const int c0 = j * 512 + lane * 8;
-      if (c0 >= D) continue;  // the shuffle partners (lane ^ 4) of a stored lane are always inside D: D % 64 == 0
+      const bool in = c0 < D;  // wave-uniform per slab except in the half slab; the shuffles below need every lane
       float n[8], r[8];
+      const f32x4 w0 = in ? *reinterpret_cast<const f32x4*>(w + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 w1 = in ? *reinterpret_cast<const f32x4*>(w + c0 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) n[e] = (v[j][e] - mean) * rstd * w[c0 + e];
+      for (int e = 0; e < 8; ++e) n[e] = (v[j][e] - mean) * rstd * (e < 4 ? w0[e] : w1[e - 4]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float partner = __shfl_xor(n[e], 4, 64);
-        const float cs = rope_cos[l * 32 + fi + e], sn = rope_sin[l * 32 + fi + e];
-        // rotate_half: first half gets -x2, second half gets +x1
-        r[e] = second ? (n[e] * cs + partner * sn) : (n[e] * cs - partner * sn);
+        r[e] = n[e] * cs[e] + partner * sn[e];
         if (which == 0) r[e] *= qscale;
       }
+      if (!in) continue;  // the shuffle partners (lane ^ 4) of a stored lane are always inside D: D % 64 == 0
       uint4 p;
       p.x = pack2(r[0], r[1]); p.y = pack2(r[2], r[3]); p.z = pack2(r[4], r[5]); p.w = pack2(r[6], r[7]);
       *reinterpret_cast<uint4*>(dst + (int64_t)tok * D + c0) = p;  // token-major: 1 KiB contiguous per wave store
