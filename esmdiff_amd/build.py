@@ -24,6 +24,7 @@ UNITS = {
     "engine": [],
     "gemm": [],
     "gemm256": [],
+    "gemm256w4": [],
     "geom": [],
     "encoder": [],
     "attention": [],

@@ -522,6 +522,13 @@ hipError_t launch_gemm256_bf16(const bf16_t* A, const bf16_t* W, void* out, cons
   using namespace g256;
   if (M <= 0) return hipSuccess;
   if (N % BN != 0 || K % BK != 0 || (ldc & 3)) return hipErrorInvalidValue;
+  // default: the four-wave kernel (gemm256w4.hip: 128x128 wave tiles, hand-placed main loop; 4-5 % faster on the block
+  // linears, r02); this eight-wave kernel stays for odd K-tile counts and for A/B runs (ESMDIFF_GEMM_W4=0)
+  static const int w4 = [] {
+    const char* e = getenv("ESMDIFF_GEMM_W4");
+    return e ? atoi(e) : 1;
+  }();
+  if (w4 && K % (2 * BK) == 0 && K >= 6 * BK) return launch_gemm256w4_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
   const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
   // persistent grid: one workgroup per CU (LDS allows no more), each walking tiles b, b + G, ...  G must be a
   // multiple of 8 (XCD-contiguous tile runs).  ESMDIFF_GEMM_PERSIST=0 launches one workgroup per tile instead.

@@ -39,6 +39,10 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
 hipError_t launch_gemm256_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
                                int K, int ldc, float alpha, int epilogue, hipStream_t stream);
 
+// gemm256w4.hip: the same tile with 4 waves x 128x128 wave tiles, hand-placed main loop, accumulators in AGPRs; K % 128 == 0
+hipError_t launch_gemm256w4_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
+                                 int K, int ldc, float alpha, int epilogue, hipStream_t stream);
+
 // ---- norm.hip --------------------------------------------------------------------------------
 hipError_t launch_layernorm_bf16(const float* x, const float* w, const float* b, bf16_t* y, int M, int D,
                                  hipStream_t stream);
