@@ -258,7 +258,8 @@ def test_layernorm():
         assert float((err - ref.abs() * 2 ** -8).max()) < 1e-4
 
 
-@pytest.mark.parametrize("B,L", [(2, 60), (1, 258), (3, 130), (2, 129), (2, 257), (2, 259), (1, 64), (1, 65), (2, 33)])
+@pytest.mark.parametrize("B,L", [(2, 60), (1, 258), (3, 130), (2, 129), (2, 257), (2, 259), (1, 64), (1, 65), (2, 33), (2, 128),
+                                 (1, 256), (1, 192), (2, 32), (1, 31), (1, 1)])
 def test_attention_block(tiny, B, L):
     """q/k LayerNorm + rotary + softmax(QK^T/8)V against the oracle's MultiHeadAttentionRef internals."""
     cfg, sd, eng, net, _ = tiny
