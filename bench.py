@@ -255,12 +255,12 @@ def main():
                             + 2 * cfg.d_model * cfg.d_model + 2 * cfg.d_model * cfg.n_structure_heads)
         n_fwd = n_fwd_sample                                     # the breakdown pass is one step
         traffic, traffic_note = None, "no PMC pass on record"
-        tp = ROOT / "profiles" / "r01_gemm_traffic.json"
+        tp = ROOT / "profiles" / "r02_gemm_traffic.json"
         if tp.exists() and not args.tiny:   # separate rocprofv3 --pmc passes of this same kernel at this M
             tj = json.loads(tp.read_text())
             rec = tj.get("by_rows", {}).get(str(M // parts))
             if rec:
-                traffic, traffic_note = rec["traffic_bytes_per_launch"], ("profiles/r01_gemm_traffic.json: FETCH_SIZE x2 "
+                traffic, traffic_note = rec["traffic_bytes_per_launch"], ("profiles/r02_gemm_traffic.json: FETCH_SIZE x2 "
                                                                            "(gfx950 correction) + WRITE_SIZE, fabric-level")
         out = {
             "metric": ("conformation samples/sec (256-res, 25 steps)" if (args.mode, args.residues, T) == ("ddpm", 256, 25) and not args.inpaint
@@ -276,7 +276,7 @@ def main():
                                        "single process, one GPU, no process group (nothing crosses RCCL at N=1)")},
             "flop_per_sample": f_sample,
             "mfma_frac_whole_job": round(value / world * f_sample / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "g256::gemm256_kernel<SWIGLU> (FFN-up, M=%d N=%d K=%d)" % (M // parts, 2 * cfg.ffn_hidden, cfg.d_model),
+            "roofline": {"bound": "mfma", "kernel": "g4::gemm256w4_kernel<SWIGLU> (FFN-up, M=%d N=%d K=%d)" % (M // parts, 2 * cfg.ffn_hidden, cfg.d_model),
                          "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
