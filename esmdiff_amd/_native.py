@@ -43,7 +43,7 @@ EXPORTS = [
     "esmdiff_gemm_bf16_timed", "esmdiff_layernorm_bf16", "esmdiff_attention_bf16", "esmdiff_set_profiling",
     "esmdiff_get_profile", "esmdiff_set_frames", "esmdiff_gemm_bf16_ws", "esmdiff_decoder_create",
     "esmdiff_decoder_decode", "esmdiff_metrics_js_pwd", "esmdiff_metrics_js_rg", "esmdiff_metrics_validity",
-    "esmdiff_metrics_bonding_validity", "esmdiff_encoder_create", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error",
+    "esmdiff_metrics_bonding_validity", "esmdiff_metrics_pwd", "esmdiff_metrics_js_columns", "esmdiff_encoder_create", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error",
     "esmdiff_encoder_encode",
 ]
 
@@ -85,8 +85,10 @@ def lib():
     L.esmdiff_decoder_create.argtypes = L.esmdiff_engine_create.argtypes
     L.esmdiff_decoder_decode.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
     f64, f64p = ctypes.c_double, ctypes.POINTER(ctypes.c_double)
-    L.esmdiff_metrics_js_pwd.argtypes = [vp, i32, vp, i32, i32, i32, i32, f64p, vp]
-    L.esmdiff_metrics_js_rg.argtypes = [vp, i32, vp, i32, i32, i32, f64p, vp]
+    L.esmdiff_metrics_js_pwd.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, f64p, vp]
+    L.esmdiff_metrics_js_rg.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, f64p, vp]
+    L.esmdiff_metrics_pwd.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.esmdiff_metrics_js_columns.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, f64p, vp]
     L.esmdiff_metrics_validity.argtypes = [vp, i32, i32, f64, f64, i32, f64p, vp]
     L.esmdiff_metrics_bonding_validity.argtypes = [vp, i32, vp, i32, i32, f64p, vp]
     L.esmdiff_encoder_create.argtypes = [i32] * 8 + [ctypes.POINTER(Weight), i32, i32, ctypes.POINTER(vp)]

@@ -2,7 +2,8 @@
 //
 // What the reference computes with numpy / scipy on the host after decoding
 // (/root/reference/slm/utils/eval_utils.py): pairwise_distance_ca :90-102, radius_of_gyration :105-129,
-// _steric_clash / validity :132-173, bonding_validity :176-188, js_pwd :227-255, js_rg :290-316.  The arithmetic is
+// _steric_clash / validity :132-173, bonding_validity :176-188, js_pwd :227-255, js_rg :290-316 (per-frame `weights` and the
+// kl=True variants included), and the histogram / JS tail of js_tica :258-289 (esmdiff_metrics_js_columns).  The arithmetic is
 // restated step by step — including numpy.histogram's equal-width binning with its edge correction and
 // scipy.spatial.distance.jensenshannon — in oracle/metrics_ref.py, which reproduces the reference's own outputs
 // (tests/golden/g9_metrics.npz) to 1e-16; these kernels follow the same steps in f64 (compiled with
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(256) void col_minmax_kernel(const double* __restric
 // numpy.histogram(x[:, d], bins = n_bins, range = (lo[d], hi[d])) + pseudo count; counts [n_bins, D]
 __global__ __launch_bounds__(256) void col_hist_kernel(const double* __restrict__ x, int N, int D,
                                                        const double* __restrict__ lo, const double* __restrict__ hi,
-                                                       int n_bins, double pseudo, double* __restrict__ counts) {
+                                                       int n_bins, double pseudo, const double* __restrict__ w,
+                                                       double* __restrict__ counts) {
   const int d = blockIdx.x * 256 + threadIdx.x;
   if (d >= D) return;
   double first = lo[d], last = hi[d];
@@ -80,8 +82,22 @@ __global__ __launch_bounds__(256) void col_hist_kernel(const double* __restrict_
     if (idx == n_bins) idx -= 1;
     if (v < edge(idx)) idx -= 1;
     if (v >= edge(idx + 1) && idx != n_bins - 1) idx += 1;
-    counts[(int64_t)idx * D + d] += 1.0;
+    counts[(int64_t)idx * D + d] += w ? w[n] : 1.0;  // numpy.histogram(weights=): per-frame weights, accumulated in frame order
   }
+}
+
+// scipy.special.kl_div(p, q) = p log(p / q) - p + q on the (un-normalised, pseudo-counted) histograms, summed per column;
+// the reference takes .mean() over all n_bins x D elements (eval_utils.py:247-249, :305-307)
+__global__ __launch_bounds__(256) void col_kl_kernel(const double* __restrict__ p, const double* __restrict__ q, int n_bins,
+                                                     int D, double* __restrict__ kl) {
+  const int d = blockIdx.x * 256 + threadIdx.x;
+  if (d >= D) return;
+  double acc = 0;
+  for (int b = 0; b < n_bins; ++b) {
+    const double a = p[(int64_t)b * D + d], c = q[(int64_t)b * D + d];
+    acc += (a * log(a / c) - a) + c;
+  }
+  kl[d] = acc;
 }
 
 // scipy.spatial.distance.jensenshannon(p, q, axis = 0) per column
@@ -160,22 +176,24 @@ int pairs_to_device(Scratch& s, int L, int k, int** row, int** col, int* D) {
 }
 
 // mean over columns of JS(hist(model col), hist(ref col)); x arrays are [N, D] on the device
-int js_columns(Scratch& s, const double* xm, int nm, const double* xr, int nr, int D, int n_bins, double* out, hipStream_t st) {
+int js_columns(Scratch& s, const double* xm, int nm, const double* wm, const double* xr, int nr, const double* wr, int D,
+               int n_bins, int kl, double* out, hipStream_t st) {
   if (D <= 0 || n_bins <= 0) return ESMDIFF_E_INVALID;
   double *lo = s.get<double>(D), *hi = s.get<double>(D), *cm = s.get<double>((size_t)n_bins * D),
          *cr = s.get<double>((size_t)n_bins * D), *js = s.get<double>(D);
   if (!lo || !hi || !cm || !cr || !js) return ESMDIFF_E_HIP;
   const dim3 g((D + 255) / 256), b(256);
   hipLaunchKernelGGL(col_minmax_kernel, g, b, 0, st, xr, nr, D, lo, hi);
-  hipLaunchKernelGGL(col_hist_kernel, g, b, 0, st, xm, nm, D, lo, hi, n_bins, 1e-6, cm);
-  hipLaunchKernelGGL(col_hist_kernel, g, b, 0, st, xr, nr, D, lo, hi, n_bins, 1e-6, cr);
-  hipLaunchKernelGGL(col_js_kernel, g, b, 0, st, cm, cr, n_bins, D, js);
+  hipLaunchKernelGGL(col_hist_kernel, g, b, 0, st, xm, nm, D, lo, hi, n_bins, 1e-6, wm, cm);
+  hipLaunchKernelGGL(col_hist_kernel, g, b, 0, st, xr, nr, D, lo, hi, n_bins, 1e-6, wr, cr);
+  if (kl) hipLaunchKernelGGL(col_kl_kernel, g, b, 0, st, cm, cr, n_bins, D, js);
+  else hipLaunchKernelGGL(col_js_kernel, g, b, 0, st, cm, cr, n_bins, D, js);
   std::vector<double> h(D);
   if (hipMemcpyAsync(h.data(), js, (size_t)D * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
     return ESMDIFF_E_HIP;
   double acc = 0;
   for (double v : h) acc += v;
-  *out = acc / D;
+  *out = kl ? acc / ((double)D * n_bins) : acc / D;
   return 0;
 }
 
@@ -186,8 +204,9 @@ using namespace ed;
 
 extern "C" {
 
-int esmdiff_metrics_js_pwd(const double* ca_model, int32_t n_model, const double* ca_ref, int32_t n_ref, int32_t L,
-                           int32_t n_bins, int32_t pwd_offset, double* js_out, void* stream) {
+int esmdiff_metrics_js_pwd(const double* ca_model, int32_t n_model, const double* w_model, const double* ca_ref,
+                           int32_t n_ref, const double* w_ref, int32_t L, int32_t n_bins, int32_t pwd_offset, int32_t kl,
+                           double* js_out, void* stream) {
   if (!ca_model || !ca_ref || !js_out || n_model <= 0 || n_ref <= 0 || L <= 0 || pwd_offset < 0) return ESMDIFF_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   Scratch s;
@@ -198,11 +217,31 @@ int esmdiff_metrics_js_pwd(const double* ca_model, int32_t n_model, const double
   if (!pm || !pr) return ESMDIFF_E_HIP;
   hipLaunchKernelGGL(pwd_kernel, dim3((D + 255) / 256, n_model), dim3(256), 0, st, ca_model, row, col, L, D, pm);
   hipLaunchKernelGGL(pwd_kernel, dim3((D + 255) / 256, n_ref), dim3(256), 0, st, ca_ref, row, col, L, D, pr);
-  return js_columns(s, pm, n_model, pr, n_ref, D, n_bins, js_out, st);
+  return js_columns(s, pm, n_model, w_model, pr, n_ref, w_ref, D, n_bins, kl, js_out, st);
 }
 
-int esmdiff_metrics_js_rg(const double* ca_model, int32_t n_model, const double* ca_ref, int32_t n_ref, int32_t L,
-                          int32_t n_bins, double* js_out, void* stream) {
+int esmdiff_metrics_pwd(const double* ca, int32_t n, int32_t L, int32_t pwd_offset, double* out, void* stream) {
+  if (!ca || !out || n <= 0 || L <= 0 || pwd_offset < 0) return ESMDIFF_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  Scratch s;
+  int *row, *col, D;
+  if (int r = pairs_to_device(s, L, pwd_offset, &row, &col, &D)) return r;
+  if (D == 0) return ESMDIFF_E_INVALID;
+  hipLaunchKernelGGL(pwd_kernel, dim3((D + 255) / 256, n), dim3(256), 0, st, ca, row, col, L, D, out);
+  return hipStreamSynchronize(st) == hipSuccess ? 0 : ESMDIFF_E_HIP;  // row / col are freed on return
+}
+
+int esmdiff_metrics_js_columns(const double* x_model, int32_t n_model, const double* w_model, const double* x_ref,
+                               int32_t n_ref, const double* w_ref, int32_t D, int32_t n_bins, int32_t kl, double* out,
+                               void* stream) {
+  if (!x_model || !x_ref || !out || n_model <= 0 || n_ref <= 0) return ESMDIFF_E_INVALID;
+  Scratch s;
+  return js_columns(s, x_model, n_model, w_model, x_ref, n_ref, w_ref, D, n_bins, kl, out, (hipStream_t)stream);
+}
+
+int esmdiff_metrics_js_rg(const double* ca_model, int32_t n_model, const double* w_model, const double* ca_ref,
+                          int32_t n_ref, const double* w_ref, int32_t L, int32_t n_bins, int32_t kl, double* js_out,
+                          void* stream) {
   if (!ca_model || !ca_ref || !js_out || n_model <= 0 || n_ref <= 0 || L <= 0) return ESMDIFF_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   Scratch s;
@@ -210,7 +249,7 @@ int esmdiff_metrics_js_rg(const double* ca_model, int32_t n_model, const double*
   if (!gm || !gr) return ESMDIFF_E_HIP;
   hipLaunchKernelGGL(rg_kernel, dim3((n_model + 255) / 256), dim3(256), 0, st, ca_model, L, n_model, gm);
   hipLaunchKernelGGL(rg_kernel, dim3((n_ref + 255) / 256), dim3(256), 0, st, ca_ref, L, n_ref, gr);
-  return js_columns(s, gm, n_model, gr, n_ref, 1, n_bins, js_out, st);
+  return js_columns(s, gm, n_model, w_model, gr, n_ref, w_ref, 1, n_bins, kl, js_out, st);
 }
 
 int esmdiff_metrics_validity(const double* ca, int32_t n, int32_t L, double ca_vdw_radius, double allowable_overlap,

@@ -1,12 +1,20 @@
 """Ensemble metrics on the device, with the reference's call shapes
-(/root/reference/slm/utils/eval_utils.py: js_pwd :227-255, js_rg :290-316, validity :158-173, bonding_validity :176-188):
-dictionaries {name: CA coordinates (n_frames, L, 3)} in, dictionaries {name: value rounded to 4 decimals} out, the entry
-`ref_key` being the reference ensemble.  The arithmetic runs in csrc/metrics.hip (float64); there is no CPU fallback.
-Not covered: js_tica (needs deeptime's TICA fit), per-frame weights, the kl=True variants."""
+(/root/reference/slm/utils/eval_utils.py: js_pwd :227-255, js_tica :258-289, js_rg :290-316, validity :158-173,
+bonding_validity :176-188): dictionaries {name: CA coordinates (n_frames, L, 3)} in, dictionaries {name: value rounded to
+4 decimals} out, the entry `ref_key` being the reference ensemble; per-frame `weights=` dictionaries and the `kl=True`
+variants included.  The arithmetic runs in csrc/metrics.hip (float64); there is no CPU fallback.
+
+js_tica: the reference fits deeptime's TICA(dim=2, lagtime=20) on the reference ensemble's pairwise distances.  deeptime is
+not in the reference tree and not installable here, so the fit is restated ([DEEPTIME-RECALL], PARITY UNPINNED): reversible
+(symmetrised) instantaneous / time-lagged covariances of the mean-free features, rank truncation of the instantaneous
+covariance at `epsilon = 1e-6`, symmetric eigenproblem in the whitened space, the two leading eigenvectors.  The Jensen-Shannon
+value only depends on the two TIC *directions*: the histogram range follows the reference projection, so sign and
+kinetic-map scaling cancel.  Dense f64 linear algebra (covariances, eigh) goes through torch on the GPU (rocBLAS / rocSOLVER:
+plain library calls, off the hot path); features, histograms and JS are the kernels of csrc/metrics.hip."""
 from __future__ import annotations
 
 import ctypes
-from typing import Dict
+from typing import Dict, Optional
 
 import numpy as np
 import torch
@@ -23,6 +31,19 @@ def _dev(ca) -> torch.Tensor:
     return t.to(device="cuda", dtype=torch.float64).contiguous()
 
 
+def _wdev(weights: Optional[dict], key, n: int) -> Optional[torch.Tensor]:
+    """The reference fills missing keys with ones (eval_utils.py:236-238); None keeps the unit-weight fast path."""
+    if weights is None or key not in weights:
+        return None
+    w = torch.as_tensor(np.asarray(weights[key], dtype=np.float64)).to("cuda").contiguous()
+    assert w.shape == (n,), f"weights[{key!r}] must have one entry per frame ({n}), got {tuple(w.shape)}"
+    return w
+
+
+def _p(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -35,25 +56,83 @@ def _call(fn, *args) -> float:
     return float(out.value)
 
 
+def _round(res: dict, rounded: bool) -> dict:
+    return {k: float(np.around(v, decimals=4)) if rounded else v for k, v in res.items()}
+
+
 def js_pwd(ca_coords_dict: Dict[str, np.ndarray], ref_key: str = "target", n_bins: int = 50, pwd_offset: int = 3,
-           rounded: bool = True) -> Dict[str, float]:
+           weights: Optional[dict] = None, kl: bool = False, rounded: bool = True) -> Dict[str, float]:
     L_ = N.lib()
     dev = {k: _dev(v) for k, v in ca_coords_dict.items()}
     ref = dev[ref_key]
-    res = {k: _call(L_.esmdiff_metrics_js_pwd, v.data_ptr(), v.shape[0], ref.data_ptr(), ref.shape[0], ref.shape[1], n_bins,
-                    pwd_offset) for k, v in dev.items() if k != ref_key}
+    wr = _wdev(weights, ref_key, ref.shape[0])
+    res = {k: _call(L_.esmdiff_metrics_js_pwd, _p(v), v.shape[0], _p(_wdev(weights, k, v.shape[0])), _p(ref), ref.shape[0],
+                    _p(wr), ref.shape[1], n_bins, pwd_offset, int(kl)) for k, v in dev.items() if k != ref_key}
     res[ref_key] = 0.0
-    return {k: float(np.around(v, decimals=4)) if rounded else v for k, v in res.items()}
+    return _round(res, rounded)
 
 
-def js_rg(ca_coords_dict, ref_key: str = "target", n_bins: int = 50, rounded: bool = True) -> Dict[str, float]:
+def js_rg(ca_coords_dict, ref_key: str = "target", n_bins: int = 50, weights: Optional[dict] = None, kl: bool = False,
+          rounded: bool = True) -> Dict[str, float]:
     L_ = N.lib()
     dev = {k: _dev(v) for k, v in ca_coords_dict.items()}
     ref = dev[ref_key]
-    res = {k: _call(L_.esmdiff_metrics_js_rg, v.data_ptr(), v.shape[0], ref.data_ptr(), ref.shape[0], ref.shape[1], n_bins)
-           for k, v in dev.items() if k != ref_key}
+    wr = _wdev(weights, ref_key, ref.shape[0])
+    res = {k: _call(L_.esmdiff_metrics_js_rg, _p(v), v.shape[0], _p(_wdev(weights, k, v.shape[0])), _p(ref), ref.shape[0],
+                    _p(wr), ref.shape[1], n_bins, int(kl)) for k, v in dev.items() if k != ref_key}
     res[ref_key] = 0.0
-    return {k: float(np.around(v, decimals=4)) if rounded else v for k, v in res.items()}
+    return _round(res, rounded)
+
+
+def pairwise_distance_ca(ca, k: int = 1) -> torch.Tensor:
+    """eval_utils.py:90-102 on the device: (n, L, 3) -> (n, D) CA distances of the pairs (i, j >= i + k), triu order."""
+    d = _dev(ca)
+    n, L = d.shape[:2]
+    D = (L - k) * (L - k + 1) // 2
+    out = torch.empty(n, D, dtype=torch.float64, device="cuda")
+    code = N.lib().esmdiff_metrics_pwd(_p(d), n, L, k, _p(out), _stream())
+    if code != 0:
+        raise RuntimeError(f"libesmdiff_hip metrics call failed ({code})")
+    return out
+
+
+def tica_fit(x: torch.Tensor, lagtime: int, dim: int = 2, epsilon: float = 1e-6):
+    """[DEEPTIME-RECALL] TICA(dim, lagtime).fit(x) restated (module docstring): -> (mean (D,), directions (D, dim))."""
+    n = x.shape[0]
+    if n <= lagtime:
+        raise ValueError(f"TICA needs more than lagtime = {lagtime} frames in the reference ensemble, got {n}")
+    x0, xt = x[:-lagtime], x[lagtime:]
+    mean = 0.5 * (x0.mean(0) + xt.mean(0))                       # reversible estimator: one mean for both windows
+    a, b = x0 - mean, xt - mean
+    m = a.shape[0]
+    c00 = (a.T @ a + b.T @ b) / (2.0 * m)
+    c0t = (a.T @ b + b.T @ a) / (2.0 * m)
+    s, u = torch.linalg.eigh(c00)
+    keep = s > epsilon                                           # rank truncation of the instantaneous covariance
+    if int(keep.sum()) < dim:
+        raise ValueError("reference ensemble has fewer than `dim` directions above the TICA rank cut-off")
+    wh = u[:, keep] / torch.sqrt(s[keep])                        # whitening: wh^T c00 wh = I
+    lam, v = torch.linalg.eigh(wh.T @ c0t @ wh)
+    order = torch.argsort(lam.abs(), descending=True)[:dim]
+    return mean, wh @ v[:, order]
+
+
+def js_tica(ca_coords_dict, ref_key: str = "target", n_bins: int = 50, lagtime: int = 20, return_tic: bool = True,
+            weights: Optional[dict] = None, rounded: bool = True):
+    """eval_utils.py:258-289: coordinates -> pairwise distances (k = 1) -> two TICs fitted on the reference -> JS."""
+    L_ = N.lib()
+    pwd = {k: pairwise_distance_ca(v) for k, v in ca_coords_dict.items()}
+    mean, comp = tica_fit(pwd[ref_key], lagtime)
+    dr = {k: ((v - mean) @ comp).contiguous() for k, v in pwd.items()}
+    ref = dr[ref_key]
+    wr = _wdev(weights, ref_key, ref.shape[0])
+    res = {k: _call(L_.esmdiff_metrics_js_columns, _p(v), v.shape[0], _p(_wdev(weights, k, v.shape[0])), _p(ref), ref.shape[0],
+                    _p(wr), 2, n_bins, 0) for k, v in dr.items() if k != ref_key}
+    res[ref_key] = 0.0
+    res = _round(res, rounded)
+    if return_tic:
+        return res, {k: v.cpu().numpy() for k, v in dr.items()}
+    return res
 
 
 def validity(ca_coords_dict, ca_vdw_radius: float = 1.7, allowable_overlap: float = 0.4, k_exclusion: int = 0,
@@ -65,7 +144,7 @@ def validity(ca_coords_dict, ca_vdw_radius: float = 1.7, allowable_overlap: floa
         assert not bool(torch.isnan(d).any()), "coords should not contain nan"
         res[k] = _call(L_.esmdiff_metrics_validity, d.data_ptr(), d.shape[0], d.shape[1], float(ca_vdw_radius),
                        float(allowable_overlap), int(k_exclusion))
-    return {k: float(np.around(v, decimals=4)) if rounded else v for k, v in res.items()}
+    return _round(res, rounded)
 
 
 def bonding_validity(ca_coords_dict, ref_key: str = "target", rounded: bool = True) -> Dict[str, float]:
@@ -74,4 +153,4 @@ def bonding_validity(ca_coords_dict, ref_key: str = "target", rounded: bool = Tr
     ref = dev[ref_key]
     res = {k: _call(L_.esmdiff_metrics_bonding_validity, v.data_ptr(), v.shape[0], ref.data_ptr(), ref.shape[0], ref.shape[1])
            for k, v in dev.items()}
-    return {k: float(np.around(v, decimals=4)) if rounded else v for k, v in res.items()}
+    return _round(res, rounded)

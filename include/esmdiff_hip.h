@@ -241,11 +241,22 @@ int esmdiff_encoder_encode(esmdiff_encoder* enc, const float* ca, const float* r
  * histograms, bins spanning the reference's range, pseudo count 1e-6, mean over pairs), js_rg :290-316, validity
  * :158-173 (fraction of frames without a CA-CA distance below 2*radius - overlap among pairs |i-j| > k_exclusion),
  * bonding_validity :176-188 (fraction of frames whose adjacent CA distances all stay below the reference's maximum
- * + 1e-6).  ca_*: f64 [n, L, 3].  Values are returned unrounded (the reference rounds to 4 decimals last). */
-int esmdiff_metrics_js_pwd(const double* ca_model, int32_t n_model, const double* ca_ref, int32_t n_ref, int32_t L,
-                           int32_t n_bins, int32_t pwd_offset, double* js_out, void* stream);
-int esmdiff_metrics_js_rg(const double* ca_model, int32_t n_model, const double* ca_ref, int32_t n_ref, int32_t L,
-                          int32_t n_bins, double* js_out, void* stream);
+ * + 1e-6).  ca_*: f64 [n, L, 3].  Values are returned unrounded (the reference rounds to 4 decimals last).
+ * w_model / w_ref: per-frame histogram weights f64 [n] or NULL (the reference's `weights=` dictionaries, default ones);
+ * kl != 0: mean of scipy.special.kl_div over all bins and columns instead of the mean JS distance (`kl=True`).
+ * esmdiff_metrics_pwd: the pairwise-distance features alone, out f64 [n, D], D = pairs (i, j >= i + offset) in
+ * numpy.triu_indices order (eval_utils.py:90-102) — what js_tica (:258-289) feeds its TICA fit; esmdiff_metrics_js_columns:
+ * the histogram + JS / KL tail on any feature matrix [n, D] (js_tica: D = 2 projected coordinates). */
+int esmdiff_metrics_js_pwd(const double* ca_model, int32_t n_model, const double* w_model, const double* ca_ref,
+                           int32_t n_ref, const double* w_ref, int32_t L, int32_t n_bins, int32_t pwd_offset, int32_t kl,
+                           double* js_out, void* stream);
+int esmdiff_metrics_js_rg(const double* ca_model, int32_t n_model, const double* w_model, const double* ca_ref,
+                          int32_t n_ref, const double* w_ref, int32_t L, int32_t n_bins, int32_t kl, double* js_out,
+                          void* stream);
+int esmdiff_metrics_pwd(const double* ca, int32_t n, int32_t L, int32_t pwd_offset, double* out, void* stream);
+int esmdiff_metrics_js_columns(const double* x_model, int32_t n_model, const double* w_model, const double* x_ref,
+                               int32_t n_ref, const double* w_ref, int32_t D, int32_t n_bins, int32_t kl, double* out,
+                               void* stream);
 int esmdiff_metrics_validity(const double* ca, int32_t n, int32_t L, double ca_vdw_radius, double allowable_overlap,
                              int32_t k_exclusion, double* out, void* stream);
 int esmdiff_metrics_bonding_validity(const double* ca_model, int32_t n_model, const double* ca_ref, int32_t n_ref,

@@ -3,7 +3,9 @@
 :132-155, validity :158-173, bonding_validity :176-188, js_pwd :227-255, js_rg :290-316), written out step by step
 (numpy.histogram's equal-width binning and scipy's jensenshannon included) the way csrc/metrics.hip computes them.
 PINNED: reproduces tests/golden/g9_metrics.npz, which the reference's own functions produced
-(tests/golden/make_goldens_metrics.py).  Values are returned UNROUNDED; the reference rounds to 4 decimals last."""
+(tests/golden/make_goldens_metrics.py) — js_pwd / js_rg incl. weights= and kl=True (g9b), validity, bonding_validity.
+js_tica (:258-289) is NOT pinned: deeptime's TICA is absent from the reference tree and from this image; its fit is
+restated here and in esmdiff_amd/metrics.py ([DEEPTIME-RECALL]).  Values are returned UNROUNDED; the reference rounds to 4 decimals last."""
 from __future__ import annotations
 
 import numpy as np
@@ -24,19 +26,21 @@ def radius_of_gyration(coords: np.ndarray) -> np.ndarray:
     return ((centered ** 2).sum(-1) * (np.ones(L) / L)).sum(-1) ** 0.5
 
 
-def histogram_equal_width(x: np.ndarray, n_bins: int, first: float, last: float) -> np.ndarray:
-    """numpy.histogram(x, bins=n_bins, range=(first, last))[0] for unit weights, as numpy 2.x computes it."""
+def histogram_equal_width(x: np.ndarray, n_bins: int, first: float, last: float, weights=None) -> np.ndarray:
+    """numpy.histogram(x, bins=n_bins, range=(first, last), weights=weights)[0], as numpy 2.x computes it."""
     if first == last:
         first, last = first - 0.5, last + 0.5
     edges = np.arange(0, n_bins + 1) * ((last - first) / n_bins) + first
     edges[-1] = last
-    x = x[(x >= first) & (x <= last)]
+    inside = (x >= first) & (x <= last)
+    weights = None if weights is None else np.asarray(weights, dtype=np.float64)[inside]
+    x = x[inside]
     idx = (((x - first) / (last - first)) * n_bins).astype(np.intp)
     idx[idx == n_bins] -= 1
     idx[x < edges[idx]] -= 1
     inc = (x >= edges[idx + 1]) & (idx != n_bins - 1)
     idx[inc] += 1
-    return np.bincount(idx, minlength=n_bins).astype(np.float64)
+    return np.bincount(idx, weights=weights, minlength=n_bins).astype(np.float64)
 
 
 def jensenshannon(p: np.ndarray, q: np.ndarray) -> float:
@@ -47,22 +51,53 @@ def jensenshannon(p: np.ndarray, q: np.ndarray) -> float:
     return float(np.sqrt((left.sum() + right.sum()) / 2.0))
 
 
-def js_columns(model: np.ndarray, ref: np.ndarray, n_bins: int) -> float:
-    """mean over columns of JS(hist(model[:, d]), hist(ref[:, d])), bins spanning the reference's [min, max] per column."""
+def kl_div(p: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """scipy.special.kl_div for positive arguments (the histograms carry a pseudo count)."""
+    return (p * np.log(p / q) - p) + q
+
+
+def js_columns(model: np.ndarray, ref: np.ndarray, n_bins: int, w_model=None, w_ref=None, kl: bool = False) -> float:
+    """mean over columns of JS(hist(model[:, d]), hist(ref[:, d])), bins spanning the reference's [min, max] per column;
+    kl=True: mean of kl_div over all bins and columns (eval_utils.py:247-249)."""
     out = []
     for d in range(ref.shape[1]):
         lo, hi = ref[:, d].min(), ref[:, d].max()
-        out.append(jensenshannon(histogram_equal_width(model[:, d], n_bins, lo, hi) + PSEUDO_C,
-                                 histogram_equal_width(ref[:, d], n_bins, lo, hi) + PSEUDO_C))
-    return float(np.mean(out))
+        hm = histogram_equal_width(model[:, d], n_bins, lo, hi, w_model) + PSEUDO_C
+        hr = histogram_equal_width(ref[:, d], n_bins, lo, hi, w_ref) + PSEUDO_C
+        out.append(kl_div(hm, hr).sum() if kl else jensenshannon(hm, hr))
+    return float(np.sum(out) / (ref.shape[1] * n_bins)) if kl else float(np.mean(out))
 
 
-def js_pwd(model_ca, ref_ca, n_bins=50, pwd_offset=3) -> float:
-    return js_columns(pairwise_distance_ca(model_ca, pwd_offset), pairwise_distance_ca(ref_ca, pwd_offset), n_bins)
+def js_pwd(model_ca, ref_ca, n_bins=50, pwd_offset=3, w_model=None, w_ref=None, kl=False) -> float:
+    return js_columns(pairwise_distance_ca(model_ca, pwd_offset), pairwise_distance_ca(ref_ca, pwd_offset), n_bins,
+                      w_model, w_ref, kl)
 
 
-def js_rg(model_ca, ref_ca, n_bins=50) -> float:
-    return js_columns(radius_of_gyration(model_ca)[:, None], radius_of_gyration(ref_ca)[:, None], n_bins)
+def js_rg(model_ca, ref_ca, n_bins=50, w_model=None, w_ref=None, kl=False) -> float:
+    return js_columns(radius_of_gyration(model_ca)[:, None], radius_of_gyration(ref_ca)[:, None], n_bins, w_model, w_ref, kl)
+
+
+def tica_fit(x: np.ndarray, lagtime: int, dim: int = 2, epsilon: float = 1e-6):
+    """[DEEPTIME-RECALL, PARITY UNPINNED] deeptime.decomposition.TICA(dim, lagtime).fit(x) as eval_utils.py:266 calls it,
+    restated with scipy: reversible covariances, rank cut at epsilon, generalised symmetric eigenproblem."""
+    import scipy.linalg
+    x0, xt = x[:-lagtime], x[lagtime:]
+    mean = 0.5 * (x0.mean(0) + xt.mean(0))
+    a, b = x0 - mean, xt - mean
+    c00 = (a.T @ a + b.T @ b) / (2.0 * len(a))
+    c0t = (a.T @ b + b.T @ a) / (2.0 * len(a))
+    s, u = scipy.linalg.eigh(c00)
+    keep = s > epsilon
+    wh = u[:, keep] / np.sqrt(s[keep])
+    lam, v = scipy.linalg.eigh(wh.T @ c0t @ wh)
+    order = np.argsort(-np.abs(lam))[:dim]
+    return mean, wh @ v[:, order], lam[order]
+
+
+def js_tica(model_ca, ref_ca, n_bins=50, lagtime=20, w_model=None, w_ref=None) -> float:
+    pm, pr = pairwise_distance_ca(model_ca, 1), pairwise_distance_ca(ref_ca, 1)
+    mean, comp, _ = tica_fit(pr, lagtime)
+    return js_columns((pm - mean) @ comp, (pr - mean) @ comp, n_bins, w_model, w_ref)
 
 
 def validity(ca, ca_vdw_radius=1.7, allowable_overlap=0.4, k_exclusion=0) -> float:

@@ -64,6 +64,24 @@ def main():
     for name in funcs:
         print(name, dict(zip(keys, out[name + "_raw"])))
 
+    # g9b (r02): the weights= and kl=True arguments of js_pwd / js_rg (eval_utils.py:227, :290), same ensembles
+    w = {"target": rng.uniform(0.2, 2.0, size=len(ens["target"])), "model_a": rng.uniform(0.2, 2.0, size=len(ens["model_a"]))}
+    outb = {"w_target": w["target"], "w_model_a": w["model_a"]}          # model_b: no entry -> the reference fills in ones
+    funcs_b = {"js_pwd_w": lambda: E.js_pwd(dict(ens), weights=dict(w)), "js_rg_w": lambda: E.js_rg(dict(ens), weights=dict(w)),
+               "js_pwd_kl": lambda: E.js_pwd(dict(ens), kl=True), "js_rg_kl": lambda: E.js_rg(dict(ens), kl=True),
+               "js_pwd_w_kl_b20": lambda: E.js_pwd(dict(ens), n_bins=20, weights=dict(w), kl=True)}
+    for name, fn in funcs_b.items():
+        keep = np.around
+        np.around = lambda v, decimals=0: v
+        try:
+            raw = fn()
+        finally:
+            np.around = keep
+        outb[name + "_raw"] = np.array([float(raw[k]) for k in keys])
+        print(name, dict(zip(keys, outb[name + "_raw"])))
+    outb["keys"] = np.array(keys)
+    np.savez_compressed(HERE / "g9b_metrics_weights.npz", **outb)
+
 
 if __name__ == "__main__":
     main()

@@ -78,3 +78,73 @@ def test_device_metrics_follow_the_oracle(L, n_ref, n_model):
         assert abs(M.bonding_validity(ens, rounded=False)[name] - R.bonding_validity(ens[name], ref)) < TOL
     with pytest.raises(AssertionError):
         M.js_pwd({"target": ref[0], "m": mod})
+
+
+# ---------------------------------------------------------------------------------------------------
+# r02: weights= / kl=True (pinned to the reference's own outputs, g9b) and js_tica (deeptime absent: unpinned)
+GB = np.load(Path(__file__).parent / "golden" / "g9b_metrics_weights.npz")
+W = {"target": GB["w_target"], "model_a": GB["w_model_a"]}        # model_b has no entry: the reference fills in ones
+
+
+def test_g9b_oracle_reproduces_reference_weights_and_kl():
+    for i, k in enumerate(KEYS):
+        if k == "target":
+            continue
+        wm = W.get(k)
+        assert abs(R.js_pwd(ENS[k], ENS["target"], w_model=wm, w_ref=W["target"]) - GB["js_pwd_w_raw"][i]) < TOL
+        assert abs(R.js_rg(ENS[k], ENS["target"], w_model=wm, w_ref=W["target"]) - GB["js_rg_w_raw"][i]) < TOL
+        assert abs(R.js_pwd(ENS[k], ENS["target"], kl=True) - GB["js_pwd_kl_raw"][i]) < 1e-11
+        assert abs(R.js_rg(ENS[k], ENS["target"], kl=True) - GB["js_rg_kl_raw"][i]) < 1e-11
+        assert abs(R.js_pwd(ENS[k], ENS["target"], 20, 3, wm, W["target"], True) - GB["js_pwd_w_kl_b20_raw"][i]) < 1e-11
+
+
+def _trajectory(rng, L, n, lag_corr=0.97):
+    """A slowly breathing, slowly bending chain: two slow collective coordinates + fast noise (what TICA should find)."""
+    steps = rng.normal(size=(L, 3)) + np.array([2.0, 0, 0])
+    base = np.cumsum(3.8 * steps / np.linalg.norm(steps, axis=-1, keepdims=True), 0)
+    c = base.mean(0)
+    s = np.zeros((n, 2))
+    for t in range(1, n):
+        s[t] = lag_corr * s[t - 1] + np.sqrt(1 - lag_corr ** 2) * rng.normal(size=2)
+    bend = np.linspace(-1, 1, L)[:, None] ** 2 * np.array([0.0, 0.0, 6.0])
+    return c + (base - c)[None] * (1 + 0.06 * s[:, :1, None]) + s[:, 1:, None] * bend[None] + rng.normal(size=(n, L, 3)) * 0.15
+
+
+def test_tica_restatement_finds_the_slow_coordinates():
+    rng = np.random.default_rng(3)
+    x = R.pairwise_distance_ca(_trajectory(rng, 14, 600), 1)
+    mean, comp, lam = R.tica_fit(x, 20)
+    assert comp.shape == (x.shape[1], 2) and lam[0] >= lam[1] > 0.2       # two slow modes survive a lag of 20 frames
+    y = (x - mean) @ comp
+    for j in range(2):                                                     # unit variance, autocorrelation = eigenvalue
+        a, b = y[:-20, j], y[20:, j]
+        assert abs(0.5 * (a @ a + b @ b) / len(a) - 1.0) < 1e-8 and abs((a @ b) / len(a) - lam[j]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_g9b_device_weights_and_kl_reproduce_reference():
+    from esmdiff_amd import metrics as M
+    got = {"js_pwd_w": M.js_pwd(ENS, weights=dict(W), rounded=False), "js_rg_w": M.js_rg(ENS, weights=dict(W), rounded=False),
+           "js_pwd_kl": M.js_pwd(ENS, kl=True, rounded=False), "js_rg_kl": M.js_rg(ENS, kl=True, rounded=False),
+           "js_pwd_w_kl_b20": M.js_pwd(ENS, n_bins=20, weights=dict(W), kl=True, rounded=False)}
+    for name, res in got.items():
+        for i, k in enumerate(KEYS):
+            assert abs(res[k] - GB[name + "_raw"][i]) < 1e-11, (name, k, res[k], GB[name + "_raw"][i])
+
+
+@pytest.mark.gpu
+def test_device_js_tica_follows_the_oracle_and_is_sign_scale_free():
+    from esmdiff_amd import metrics as M
+    rng = np.random.default_rng(5)
+    ref = _trajectory(rng, 14, 600)
+    mod = _trajectory(rng, 14, 300, lag_corr=0.9) * 1.02
+    res, tic = M.js_tica({"target": ref, "m": mod}, lagtime=20, rounded=False)
+    want = R.js_tica(mod, ref, 50, 20)
+    assert res["target"] == 0.0 and abs(res["m"] - want) < 1e-6, (res, want)   # eigenvectors agree to ~1e-9 -> a few bin flips at most
+    assert tic["target"].shape == (600, 2) and tic["m"].shape == (300, 2)
+    w = {"m": rng.uniform(0.5, 1.5, 300)}
+    rw = M.js_tica({"target": ref, "m": mod}, lagtime=20, return_tic=False, weights=w, rounded=False)["m"]
+    assert abs(rw - R.js_tica(mod, ref, 50, 20, w_model=w["m"])) < 1e-6
+    with pytest.raises(ValueError, match="lagtime"):
+        M.js_tica({"target": ref[:15], "m": mod}, lagtime=20)
+    assert M.js_tica({"target": ref, "m": mod}, lagtime=20, return_tic=False)["m"] == float(np.around(res["m"], 4))
