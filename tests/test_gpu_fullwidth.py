@@ -249,3 +249,44 @@ def test_structure_encoder_full_size_margin(B, L):
     assert float(rel.max()) < NOISE, rec                       # never a clearly farther code
     assert bool(agree[gap12 > 2 * NOISE].all()), rec           # clear winners always agree
     assert rec["agree"] > 0.95, rec                            # measured 0.984 / 0.991
+
+
+# ---------------------------------------------------------------------------------------------------
+# (d) BASELINE configs[3] and [4] token counts on the FULL model (a few reverse-diffusion steps; size-independent properties)
+def test_full_model_configs_3_and_4_token_counts():
+    """configs[3]: 32 x 1024 residues (L_tok 1026: tiled-key attention, 32 832 rows through the two-stream forward);
+    configs[4]: 100 x 256 residues with an inpainting prior (64 residues masked, the rest carried through input_prior).
+    Full ESM3-open-sized engine, num_steps cut to 3 (the step count only repeats the same launches); what must hold at
+    any size: no MASK left, ids in range, known tokens untouched, determinism, and independence of the batch composition
+    (a sample drawn alone at its global index equals the same sample drawn inside the batch: Philox by global index and
+    row-independent kernels)."""
+    from esmdiff_amd.config import ESM3_OPEN
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    sd = random_init_state_dict(ESM3_OPEN, seed=3, device="cuda")
+    eng = Engine(ESM3_OPEN, sd, max_batch=100, max_len=1026)
+    del sd
+    g = torch.Generator().manual_seed(9)
+    sch = ddpm_schedule(3)
+    # configs[3]
+    B, L = 32, 1026
+    seq = _seq(B, L, g).cuda()
+    out = eng.ddpm_sample(seq, sch, seed=21, sample_offset=0).cpu()
+    assert out.shape == (B, L) and int((out == MASK).sum()) == 0 and int(out.max()) <= 4100 and int(out.min()) >= 0
+    again = eng.ddpm_sample(seq, sch, seed=21, sample_offset=0).cpu()
+    assert torch.equal(out, again)
+    half = eng.ddpm_sample(seq[16:], sch, seed=21, sample_offset=16).cpu()       # 16 x 1026 = 16 416 tokens: still two streams
+    agree = float((half == out[16:]).float().mean())
+    assert agree > 0.999, agree                                                   # same kernels -> same ids (ties aside)
+    # configs[4]
+    B, L = 100, 258
+    seq = _seq(B, L, g).cuda()
+    prior = torch.randint(0, 4096, (1, L), generator=g).repeat(B, 1)
+    prior[:, 0], prior[:, -1] = 4098, 4097
+    prior[:, 96:160] = MASK
+    out = eng.ddpm_sample(seq, sch, seed=5, input_prior=prior.cuda()).cpu()
+    keep = prior != MASK
+    assert torch.equal(out[keep], prior[keep]) and int((out == MASK).sum()) == 0
+    assert len({tuple(r) for r in out[:, 96:160].tolist()}) > 90                  # the masked stretch really is sampled per sample
+    eng.close()
