@@ -81,6 +81,7 @@ struct esmdiff_engine {
   std::vector<hipEvent_t> ev_join;
   hipEvent_t ev_fork = nullptr;
   int64_t dual_min_tokens = 12288, dual_small_max_tokens = 6400;
+  int debug_skip = 0;  // ESMDIFF_DEBUG_SKIP bits (timing experiments only, results are wrong): 1 rope, 2 attention, 4 / 8 the two add+LN
   ed::GemmWorkspace gemm_ws[4] = {};  // split-K partials of the small-M GEMM path, one per launch queue
   // profiling
   int profiling = 0;  // 0 off, 1 every launch, 2 only the dominant kernel (FFN-up GEMM)
@@ -316,10 +317,10 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   bool pending = false;
   for (int i = 0; i < c.n_layers; ++i) {
     const Layer& ly = e->layers[i];
-    EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
+    if (!(e->debug_skip & 4) || i == 0) EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
     EACH(S_QKV, launch_gemm_bf16(w.h, ly.w_qkv, w.qkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
-    EACH(S_QKROPE, launch_qk_norm_rope(w.qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.q, w.k, w.B, L, H, w.st));
-    EACH(S_ATTN, launch_attention(w.q, w.k, w.qkv, w.ctx, w.B, L, H, w.st));
+    if (!(e->debug_skip & 1) || i == 0) EACH(S_QKROPE, launch_qk_norm_rope(w.qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.q, w.k, w.B, L, H, w.st));
+    if (!(e->debug_skip & 2) || i == 0) EACH(S_ATTN, launch_attention(w.q, w.k, w.qkv, w.ctx, w.B, L, H, w.st));
     EACH(S_OUT, launch_gemm_bf16(w.ctx, ly.w_out, w.dlt2, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
     if (i == 0 && geom) {
       // x += dA; s = s_norm(x); p = proj(s); geometric attention; dG = out_proj(.) / scale  (block 0 only; the FFN-side
@@ -329,7 +330,7 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
       EACH(S_ATTN, launch_geom_attention(w.gp, w.f_rot, w.f_trans, w.f_mask, e->g_wrot, e->g_wdist, w.gctx, w.B, L, VH, w.st));
       EACH(S_ATTN, launch_gemm_bf16(w.gctx, e->g_out, w.dlt2, nullptr, M, D, 3 * VH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
     }
-    EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, w.dlt2, 1, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
+    if (!(e->debug_skip & 8) || i == 0) EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, w.dlt2, 1, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
     EACH(S_FFN_UP, launch_gemm_bf16(w.h, ly.w_up, w.mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, w.st, w.gws));
     EACH(S_FFN_DOWN, launch_gemm_bf16(w.mid, ly.w_down, w.dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
     pending = true;
@@ -609,6 +610,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       e->side.push_back(sd);
       e->ev_join.push_back(ev);
     }
+    if (const char* ds = getenv("ESMDIFF_DEBUG_SKIP")) e->debug_skip = atoi(ds);
     if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_MIN_TOKENS")) e->dual_min_tokens = atoll(mt);
     if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_SMALL_MAX_TOKENS")) e->dual_small_max_tokens = atoll(mt);
   }
