@@ -166,4 +166,18 @@ hipError_t launch_dim6_to_backbone(const float* v, int ld, float* out, int M, fl
   return hipGetLastError();
 }
 
+// One wave that does nothing for `us` microseconds (s_memtime is the 100 MHz constant clock on gfx9: 100 ticks per us):
+// delays everything enqueued behind it on its stream without occupying the machine (engine.hip: phase offset of the second
+// sub-batch stream).
+__global__ void delay_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  while (__builtin_readcyclecounter() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+hipError_t launch_delay_us(int us, hipStream_t stream) {
+  if (us <= 0) return hipSuccess;
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, stream, (unsigned long long)us * 100ull);
+  return hipGetLastError();
+}
+
 }  // namespace ed

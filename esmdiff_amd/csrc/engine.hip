@@ -81,6 +81,7 @@ struct esmdiff_engine {
   std::vector<hipEvent_t> ev_join;
   hipEvent_t ev_fork = nullptr;
   int64_t dual_min_tokens = 12288, dual_small_max_tokens = 6400;
+  int stream_offset_us = 0;  // phase offset of the second sub-batch stream (ESMDIFF_STREAM_OFFSET_US), see forward()
   int debug_skip = 0;  // ESMDIFF_DEBUG_SKIP bits (timing experiments only, results are wrong): 1 rope, 2 attention, 4 / 8 the two add+LN
   ed::GemmWorkspace gemm_ws[4] = {};  // split-K partials of the small-M GEMM path, one per launch queue
   // profiling
@@ -289,7 +290,10 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   }
   if (np > 1) {
     HIP_TRY(e, hipEventRecord(e->ev_fork, st));
-    for (int pi = 1; pi < np; ++pi) HIP_TRY(e, hipStreamWaitEvent(e->side[pi - 1], e->ev_fork, 0));
+    for (int pi = 1; pi < np; ++pi) {
+      HIP_TRY(e, hipStreamWaitEvent(e->side[pi - 1], e->ev_fork, 0));
+      HIP_TRY(e, launch_delay_us(e->stream_offset_us * pi, e->side[pi - 1]));
+    }
   }
 #define EACH(section, expr)                \
   for (int pi = 0; pi < np; ++pi) {        \
@@ -611,6 +615,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       e->ev_join.push_back(ev);
     }
     if (const char* ds = getenv("ESMDIFF_DEBUG_SKIP")) e->debug_skip = atoi(ds);
+    if (const char* so = getenv("ESMDIFF_STREAM_OFFSET_US")) e->stream_offset_us = atoi(so);
     if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_MIN_TOKENS")) e->dual_min_tokens = atoll(mt);
     if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_SMALL_MAX_TOKENS")) e->dual_small_max_tokens = atoll(mt);
   }

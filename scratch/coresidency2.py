@@ -3,7 +3,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from esmdiff_amd import _native as N
 from esmdiff_amd.engine import gemm_bf16
-M = 12900
+M = int(os.environ.get("MM", 12900))
 g = torch.Generator(device="cuda").manual_seed(0)
 A = (torch.rand(M, 1536, generator=g, device="cuda") * 2 - 1).to(torch.bfloat16)
 Wt = ((torch.rand(8192, 1536, generator=g, device="cuda") * 2 - 1) / 39).to(torch.bfloat16)
