@@ -243,6 +243,49 @@ def test_gemm_epilogues():
     assert float((o[:, :nv] - ref[:, :nv]).abs().max()) < 2e-4
 
 
+@pytest.mark.parametrize("K", [768, 1536])
+def test_gemm256w4_epilogues_large_m(K):
+    """Every epilogue of the four-wave 256x256 kernel (the large-M default: >= 128 tiles) against f32 torch, ragged last
+    row tile (M % 256 = 37), 12 and 24 K-tiles, the head's ragged 4101-of-4352 columns — the shapes the forward only
+    reaches at benchmark size."""
+    from esmdiff_amd import _native as Nn
+    from esmdiff_amd.engine import gemm_bf16
+    g = torch.Generator(device="cuda").manual_seed(K)
+    M = 32 * 256 + 37
+    A = _bf(torch.randn(M, K, generator=g, device="cuda"))
+    W = _bf(torch.randn(1536, K, generator=g, device="cuda") / K ** 0.5)
+    ref = A.float() @ W.float().t()
+    out = gemm_bf16(A, W, Nn.EPI_BF16, alpha=0.866)
+    err = (out.float() - ref * 0.866).abs()
+    assert float((err - ref.abs() * 2 ** -8).max()) < 4e-3
+    x0 = torch.randn(M, 1536, generator=g, device="cuda")
+    x = x0.clone()
+    gemm_bf16(A, W, Nn.EPI_RESID_F32, out=x, alpha=0.5)
+    assert float((x - (x0 + ref * 0.5)).abs().max()) < 1e-3
+    bias = torch.randn(1536, generator=g, device="cuda")
+    out = gemm_bf16(A, W, Nn.EPI_BIAS_GELU_BF16, bias=bias)
+    r2 = torch.nn.functional.gelu(ref + bias)
+    e2 = (out.float() - r2).abs()                      # bf16 store: 2^-8 relative, plus the bf16-operand noise of the sum
+    assert float((e2 - r2.abs() * 2 ** -7).max()) < 1e-2 and float(e2.mean()) < 2e-3
+    H = 1024
+    Wg = _bf(torch.randn(H, K, generator=g, device="cuda") / K ** 0.5)
+    Wu = _bf(torch.randn(H, K, generator=g, device="cuda") / K ** 0.5)
+    Wi = torch.stack([Wg.view(H // 32, 32, K), Wu.view(H // 32, 32, K)], 1).reshape(2 * H, K).contiguous()
+    out = gemm_bf16(A, Wi, Nn.EPI_SWIGLU_BF16)
+    r3 = torch.nn.functional.silu(A.float() @ Wg.float().t()) * (A.float() @ Wu.float().t())
+    e3 = (out.float() - r3).abs()
+    assert out.shape == (M, H) and float((e3 - r3.abs() * 2 ** -7).max()) < 1e-2 and float(e3.mean()) < 2e-3
+    Wh = torch.zeros(4352, K, dtype=torch.bfloat16, device="cuda")
+    Wh[:4101] = _bf(torch.randn(4101, K, generator=g, device="cuda") / K ** 0.5)
+    bh = torch.zeros(4352, device="cuda")
+    bh[:4101] = torch.randn(4101, generator=g, device="cuda")
+    o = torch.full((M, 4104), -7.0, device="cuda")
+    gemm_bf16(A, Wh, Nn.EPI_BIAS_F32, out=o, bias=bh, n_valid=4101)
+    r4 = A.float() @ Wh[:4101].float().t() + bh[:4101]
+    assert float((o[:, :4101] - r4).abs().max()) < 1e-3
+    assert bool((o[-5:, :4101] != -7.0).all())                 # the ragged last rows were written
+
+
 def test_layernorm():
     from esmdiff_amd.engine import layernorm_bf16
     g = torch.Generator().manual_seed(2)
