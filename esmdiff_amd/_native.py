@@ -39,7 +39,7 @@ class Rng(ctypes.Structure):
 EXPORTS = [
     "esmdiff_abi_version", "esmdiff_engine_create", "esmdiff_engine_destroy", "esmdiff_last_error",
     "esmdiff_forward_logits", "esmdiff_ddpm_step", "esmdiff_ddpm_sample", "esmdiff_gibbs_step",
-    "esmdiff_gibbs_sample", "esmdiff_gemm_bf16",
+    "esmdiff_gibbs_sample", "esmdiff_gemm_bf16", "esmdiff_debug_graph_ab", "esmdiff_branch_linear_layernorm",
     "esmdiff_gemm_bf16_timed", "esmdiff_layernorm_bf16", "esmdiff_attention_bf16", "esmdiff_set_profiling",
     "esmdiff_get_profile", "esmdiff_set_frames", "esmdiff_gemm_bf16_ws", "esmdiff_decoder_create",
     "esmdiff_decoder_decode", "esmdiff_metrics_js_pwd", "esmdiff_metrics_js_rg", "esmdiff_metrics_validity",
@@ -77,6 +77,8 @@ def lib():
     L.esmdiff_gibbs_sample.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, ctypes.POINTER(i32), ctypes.POINTER(Rng), vp]
     L.esmdiff_gemm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     L.esmdiff_gemm_bf16_timed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, c_f32p, vp]
+    L.esmdiff_debug_graph_ab.argtypes = [vp, vp, vp, i32, i32, i32, c_f32p, c_f32p]
+    L.esmdiff_branch_linear_layernorm.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, ctypes.POINTER(i32), vp]
     L.esmdiff_layernorm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.esmdiff_attention_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
     L.esmdiff_set_profiling.argtypes = [vp, i32]

@@ -84,6 +84,8 @@ struct esmdiff_engine {
   int stream_offset_us = 0;  // phase offset of the second sub-batch stream (ESMDIFF_STREAM_OFFSET_US), see forward()
   int debug_skip = 0;  // ESMDIFF_DEBUG_SKIP bits (timing experiments only, results are wrong): 1 rope, 2 attention, 4 / 8 the two add+LN
   ed::GemmWorkspace gemm_ws[4] = {};  // split-K partials of the small-M GEMM path, one per launch queue
+  ed::GemmWorkspace gemm_ws2[4] = {}; // ... a second set: the out-projection's K slices stay live next to the FFN-down's
+  int small_fused = 1;                // ESMDIFF_SMALL_FUSED=0: branch linears write bf16 deltas at every size (A/B runs)
   // profiling
   int profiling = 0;  // 0 off, 1 every launch, 2 only the dominant kernel (FFN-up GEMM)
   std::vector<hipEvent_t> ev;
@@ -228,6 +230,7 @@ struct Part {
   int B;
   hipStream_t st;
   const ed::GemmWorkspace* gws;
+  const ed::GemmWorkspace* gws2;
 };
 
 Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float* logits, int ld, int b0, int nb, int L,
@@ -239,7 +242,8 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
               e->gp ? e->gp + t0 * 15 * e->v_heads : nullptr, e->gctx ? e->gctx + t0 * 3 * e->v_heads : nullptr,
               e->f_rot ? e->f_rot + t0 * 9 : nullptr, e->f_trans ? e->f_trans + t0 * 3 : nullptr,
               e->f_mask ? e->f_mask + t0 : nullptr, nb, st,
-              e->gemm_ws[queue].partial ? &e->gemm_ws[queue] : nullptr};
+              e->gemm_ws[queue].partial ? &e->gemm_ws[queue] : nullptr,
+              e->gemm_ws2[queue].partial ? &e->gemm_ws2[queue] : nullptr};
 }
 
 // The whole network: tokens -> f32 logits [M, ld].
@@ -250,8 +254,9 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
 // rounds); with two independent launch queues the hardware scheduler fills those tails and the gaps around the
 // small LayerNorm / rotary / attention kernels with the other sub-batch's work (measured: -4.4 % per forward).
 // When: batches of >= 12 288 tokens (both halves still run the 256x256 GEMM) and small batches of <= 6 400 tokens
-// (1 024 .. 6 400: everything is on the 128x128 path either way and the kernels are latency-bound, so two queues simply
-// overlap them; below ~1 000 tokens it is a wash: B = 4, L_tok = 60 32.4 / 32.0).
+// (768 .. 6 400: everything is on the 128-column-tile path either way and the kernels are latency-bound, so two queues
+// simply overlap them; r02, L_tok = 60, one stream / two: B = 16 89.1 / 99.1 samples/s, B = 8 70.5 / 70.3, B = 4
+// 44.5 / 41.8 — below ~700 tokens the halves' GEMMs each stream the whole weight matrix for half the rows and lose).
 // In between the halves would fall below the 128-tile switch of the GEMM dispatch and lose more than the overlap gives
 // (samples/s at L_tok = 258, one stream / two: B = 8 29.4 / 31.7, 16 36.9 / 39.7, 24 43.1 / 44.1, 32 45.8 / 45.8,
 // 40 49.7 / 46.8, 48 47.4 / 51.9, 64 49.2 / 52.2, 100 50.7 / 53.0).
@@ -282,7 +287,7 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   int np = 1;
   const int64_t tokens = (int64_t)B * L;
   if (!e->side.empty() && e->profiling != 1 && B >= 2 &&
-      (tokens >= e->dual_min_tokens || (tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(1024, e->dual_min_tokens))))
+      (tokens >= e->dual_min_tokens || (tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(768, e->dual_min_tokens))))
     np = std::min<int>({(int)e->side.size() + 1, B, 4});
   for (int pi = 0; pi < np; ++pi) {
     const int b0 = (int)((int64_t)B * pi / np), b1 = (int)((int64_t)B * (pi + 1) / np);
@@ -295,14 +300,16 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
       HIP_TRY(e, launch_delay_us(e->stream_offset_us * pi, e->side[pi - 1]));
     }
   }
-#define EACH(section, expr)                \
-  for (int pi = 0; pi < np; ++pi) {        \
-    const Part& w = parts[pi];             \
-    const int M = w.B * L;                 \
-    (void)M;                               \
-    p.s = w.st;                            \
-    RUN(section, expr);                    \
-  }
+#define EACH(section, expr)                  \
+  do {                                       \
+    for (int pi = 0; pi < np; ++pi) {        \
+      const Part& w = parts[pi];             \
+      const int M = w.B * L;                 \
+      (void)M;                               \
+      p.s = w.st;                            \
+      RUN(section, expr);                    \
+    }                                        \
+  } while (0)
 
   if (e->kind == 1) {
     EACH(S_EMBED, launch_gather_rows(w.xtok, e->e_struct, w.x, M, D, ESMDIFF_VOCAB, w.st));
@@ -319,27 +326,51 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
     return fail(e, ESMDIFF_E_INVALID, "frames were set for B=%d L=%d, forward called with B=%d L=%d", e->frames_B, e->frames_L, B, L);
   const int VH = e->v_heads;
   bool pending = false;
+  // Small batches (a sub-batch of < 1024 rows): the two branch linears leave their products as raw f32 K-slice planes
+  // (gemm.hip: launch_gemm_partials) and the LayerNorm that follows sums the planes into x — x += dF before the
+  // attention-side LayerNorm, x += dA before the FFN-side one: the same two additions in the same order — so neither a
+  // split-K reduce pass nor a bf16 delta round trip runs.  Sub-batches of one forward are all on the same side of the
+  // switch or results would depend on how the batch was cut; parts differ by at most one sample, so test part 0's rows.
+  const bool small = e->small_fused && parts[0].gws && parts[0].gws2 && (int64_t)parts[np - 1].B * L < 1024 &&
+                     (int64_t)parts[0].B * L < 1024;
+  ed::GemmPartials PF[4] = {}, PA[4] = {};
   for (int i = 0; i < c.n_layers; ++i) {
     const Layer& ly = e->layers[i];
-    if (!(e->debug_skip & 4) || i == 0) EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
+    if (small) {
+      if (pending) EACH(S_LN, launch_add_partials_layernorm_bf16(w.x, PF[pi], D, inv_scale, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
+      else EACH(S_LN, launch_add_layernorm_bf16(w.x, nullptr, nullptr, 0, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
+    } else if (!(e->debug_skip & 4) || i == 0) {
+      EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
+    }
     EACH(S_QKV, launch_gemm_bf16(w.h, ly.w_qkv, w.qkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
     if (!(e->debug_skip & 1) || i == 0) EACH(S_QKROPE, launch_qk_norm_rope(w.qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.q, w.k, w.B, L, H, w.st));
     if (!(e->debug_skip & 2) || i == 0) EACH(S_ATTN, launch_attention(w.q, w.k, w.qkv, w.ctx, w.B, L, H, w.st));
-    EACH(S_OUT, launch_gemm_bf16(w.ctx, ly.w_out, w.dlt2, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
-    if (i == 0 && geom) {
+    if (small) EACH(S_OUT, launch_gemm_partials(w.ctx, ly.w_out, w.gws2, M, D, D, w.st, &PA[pi]));
+    else EACH(S_OUT, launch_gemm_bf16(w.ctx, ly.w_out, w.dlt2, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
+    const bool geom_here = i == 0 && geom;
+    if (geom_here) {
       // x += dA; s = s_norm(x); p = proj(s); geometric attention; dG = out_proj(.) / scale  (block 0 only; the FFN-side
       // LayerNorm below then adds dG instead of dA)
-      EACH(S_LN, launch_add_layernorm_bf16(w.x, nullptr, w.dlt2, 1, e->g_snorm_w, nullptr, w.h, M, D, w.st));
+      if (small) EACH(S_LN, launch_add_partials_layernorm_bf16(w.x, PA[pi], D, inv_scale, e->g_snorm_w, nullptr, w.h, M, D, w.st));
+      else EACH(S_LN, launch_add_layernorm_bf16(w.x, nullptr, w.dlt2, 1, e->g_snorm_w, nullptr, w.h, M, D, w.st));
       EACH(S_ATTN, launch_gemm_bf16(w.h, e->g_proj, w.gp, nullptr, M, 15 * VH, D, 15 * VH, 15 * VH, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
       EACH(S_ATTN, launch_geom_attention(w.gp, w.f_rot, w.f_trans, w.f_mask, e->g_wrot, e->g_wdist, w.gctx, w.B, L, VH, w.st));
       EACH(S_ATTN, launch_gemm_bf16(w.gctx, e->g_out, w.dlt2, nullptr, M, D, 3 * VH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
     }
-    if (!(e->debug_skip & 8) || i == 0) EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, w.dlt2, 1, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
+    if (small && !geom_here) {
+      EACH(S_LN, launch_add_partials_layernorm_bf16(w.x, PA[pi], D, inv_scale, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
+    } else if (small) {  // x already holds x + dF + dA; the geometric branch came back as a bf16 delta
+      EACH(S_LN, launch_add_layernorm_bf16(w.x, nullptr, w.dlt2, 1, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
+    } else if (!(e->debug_skip & 8) || i == 0) {
+      EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, w.dlt2, 1, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
+    }
     EACH(S_FFN_UP, launch_gemm_bf16(w.h, ly.w_up, w.mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, w.st, w.gws));
-    EACH(S_FFN_DOWN, launch_gemm_bf16(w.mid, ly.w_down, w.dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
+    if (small) EACH(S_FFN_DOWN, launch_gemm_partials(w.mid, ly.w_down, w.gws, M, D, FH, w.st, &PF[pi]));
+    else EACH(S_FFN_DOWN, launch_gemm_bf16(w.mid, ly.w_down, w.dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
     pending = true;
   }
-  EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, e->final_ln_w, nullptr, w.h, M, D, w.st));
+  if (small && pending) EACH(S_LN, launch_add_partials_layernorm_bf16(w.x, PF[pi], D, inv_scale, e->final_ln_w, nullptr, w.h, M, D, w.st));
+  else EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, e->final_ln_w, nullptr, w.h, M, D, w.st));
   EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w0, w.h2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, w.st, w.gws));
   // decoder: the pLDDT head reads the same normalised hidden state (w.h) before the structure head's LayerNorm reuses it;
   // its intermediates live in ctx / q, which are free after the last block
@@ -594,6 +625,8 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
         for (int q = 0; q < 4; ++q) {
           e->gemm_ws[q].partial_floats = rows * 12288;
           TRY(dalloc(e, &e->gemm_ws[q].partial, e->gemm_ws[q].partial_floats));
+          e->gemm_ws2[q].partial_floats = rows * 12288;
+          TRY(dalloc(e, &e->gemm_ws2[q].partial, e->gemm_ws2[q].partial_floats));
         }
       }
     }
@@ -616,6 +649,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     }
     if (const char* ds = getenv("ESMDIFF_DEBUG_SKIP")) e->debug_skip = atoi(ds);
     if (const char* so = getenv("ESMDIFF_STREAM_OFFSET_US")) e->stream_offset_us = atoi(so);
+    if (const char* sf = getenv("ESMDIFF_SMALL_FUSED")) e->small_fused = atoi(sf);
     if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_MIN_TOKENS")) e->dual_min_tokens = atoll(mt);
     if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_SMALL_MAX_TOKENS")) e->dual_small_max_tokens = atoll(mt);
   }
@@ -740,6 +774,54 @@ int esmdiff_gibbs_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout
   return 0;
 }
 
+// Measurement aid: the same forward `n` times as plain launches and as `n` replays of ONE captured hipGraph of it, on an
+// engine-owned stream; milliseconds per forward of each into ms_direct / ms_graph [host].
+int esmdiff_debug_graph_ab(esmdiff_engine* e, const int64_t* seq, const int64_t* x, int32_t B, int32_t L, int32_t n,
+                           float* ms_direct, float* ms_graph) {
+  if (!e || !seq || !x || !ms_direct || !ms_graph || n <= 0) return ESMDIFF_E_INVALID;
+  if (int r = check_bl(e, B, L)) return r;
+  hipStream_t st;
+  HIP_TRY(e, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  const float* tf = e->cfg.time_conditioning ? e->tfreq : nullptr;
+  const int prof = e->profiling;
+  e->profiling = 0;
+  int r = forward(e, seq, x, tf, e->logits, e->ld_logits, B, L, st);
+  hipEventRecord(a, st);
+  for (int i = 0; i < n && r == 0; ++i) r = forward(e, seq, x, tf, e->logits, e->ld_logits, B, L, st);
+  hipEventRecord(b, st);
+  hipEventSynchronize(b);
+  hipEventElapsedTime(ms_direct, a, b);
+  *ms_direct /= n;
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  if (r == 0) {
+    HIP_TRY(e, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    r = forward(e, seq, x, tf, e->logits, e->ld_logits, B, L, st);
+    hipError_t ce = hipStreamEndCapture(st, &g);
+    if (r == 0 && ce != hipSuccess) r = fail(e, ESMDIFF_E_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+  }
+  if (r == 0) HIP_TRY(e, hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  if (r == 0) {
+    hipGraphLaunch(ge, st);
+    hipEventRecord(a, st);
+    for (int i = 0; i < n; ++i) hipGraphLaunch(ge, st);
+    hipEventRecord(b, st);
+    hipEventSynchronize(b);
+    hipEventElapsedTime(ms_graph, a, b);
+    *ms_graph /= n;
+  }
+  if (ge) hipGraphExecDestroy(ge);
+  if (g) hipGraphDestroy(g);
+  hipEventDestroy(a);
+  hipEventDestroy(b);
+  hipStreamDestroy(st);
+  e->profiling = prof;
+  return r;
+}
+
 int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N, int32_t K,
                       int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream) {
   if (!A || !W || !out) return ESMDIFF_E_INVALID;
@@ -777,6 +859,19 @@ int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float
   hipEventDestroy(a);
   hipEventDestroy(b);
   return r;
+}
+
+int esmdiff_branch_linear_layernorm(esmdiff_engine* e, const void* A, const void* W, float* x, float alpha, const float* w,
+                                    const float* b, void* y, int32_t M, int32_t N, int32_t K, int32_t* splits_out,
+                                    void* stream) {
+  if (!e || !A || !W || !x || !w || !y) return ESMDIFF_E_INVALID;
+  if (!e->gemm_ws[0].partial) return fail(e, ESMDIFF_E_INVALID, "engine has no split-K workspace (ESMDIFF_GEMM_SPLITK=0)");
+  ed::GemmPartials P{};
+  hipError_t s = launch_gemm_partials((const bf16_t*)A, (const bf16_t*)W, &e->gemm_ws[0], M, N, K, (hipStream_t)stream, &P);
+  if (s == hipSuccess) s = launch_add_partials_layernorm_bf16(x, P, N, alpha, w, b, (bf16_t*)y, M, N, (hipStream_t)stream);
+  if (s != hipSuccess) return fail(e, s == hipErrorInvalidValue ? ESMDIFF_E_INVALID : ESMDIFF_E_HIP, "branch linear + layernorm: %s", hipGetErrorString(s));
+  if (splits_out) *splits_out = P.S;
+  return 0;
 }
 
 int esmdiff_layernorm_bf16(const float* x, const float* w, const float* b, void* y, int32_t M, int32_t D, void* stream) {

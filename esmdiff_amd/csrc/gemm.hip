@@ -67,13 +67,19 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // v_cvt_pk
   return u;
 }
 
-template <int EPI, int NST>
+// MI = 32-row blocks per wave: 2 -> 128-row tiles (waves 2x2 of 64x64), 1 -> 64-row tiles (waves 2x2 of 32x64) for the
+// small-M path, where the 128-row grid leaves most CUs idle.  The per-element K order is the same, so the tile height
+// never changes a result bit.
+template <int EPI, int NST, int MI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A,
                                                            const bf16_t* __restrict__ W, void* __restrict__ out,
                                                            const float* __restrict__ bias, int M, int N, int K,
                                                            int ldc, int n_valid, float alpha, int tiles_m,
-                                                           int tiles_n, int ksplit, float* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST stages][A 16K | B 16K]
+                                                           int tiles_n, int ksplit, float* __restrict__ partial,
+                                                           int64_t pstride, int w_row_stride, int w_kt_stride,
+                                                           int64_t w_nblk_stride) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST stages][A 8K*MI | B 16K]
+  constexpr int BM = 64 * MI, A_BYTES = BM * BK * 2, STAGE = A_BYTES + TILE_BYTES;
 
   // ---- tile assignment: XCD-contiguous, 8x8 super-tile raster; K slices are the slow index ------
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -96,38 +102,40 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
   // instruction i covers tile rows (i*4 + wave)*8 .. +8 ; lane -> row + (lane>>3), 16-byte slot lane&7
   const int srow = lane >> 3;
   const int schunk = (lane & 7) ^ (((lane >> 4) + 4 * (wave & 1)) & 7);  // logical chunk stored at slot lane&7
-  const bf16_t* a_src[4];
+  const bf16_t* a_src[2 * MI];
   const bf16_t* w_src[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = (i * 4 + wave) * 8 + srow;
-    const int am = min(m0 + r, M - 1);
-    a_src[i] = A + (int64_t)am * K + schunk * 8;
-    w_src[i] = W + (int64_t)(n0 + r) * K + schunk * 8;
+    if (i < 2 * MI) {
+      const int am = min(m0 + r, M - 1);
+      a_src[i] = A + (int64_t)am * K + schunk * 8;
+    }
+    w_src[i] = W + (int64_t)nt * w_nblk_stride + (int64_t)r * w_row_stride + schunk * 8;
   }
   auto stage = [&](int buf, int kt) {
-    char* base = smem + buf * (2 * TILE_BYTES);
+    char* base = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       char* da = base + (i * 4 + wave) * 1024;
-      glds16(a_src[i] + kt * BK, da);
-      glds16(w_src[i] + kt * BK, da + TILE_BYTES);
+      if (i < 2 * MI) glds16(a_src[i] + kt * BK, da);
+      glds16(w_src[i] + (int64_t)kt * w_kt_stride, da + A_BYTES);
     }
   };
 
   // ---- fragment read offsets ------------------------------------------------------------------
   const int frow = lane & 31, khalf = lane >> 5;
   const int fsw = (frow >> 1) & 7;
-  int a_off[2], b_off[2];
+  int a_off[MI], b_off[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    a_off[i] = (wm * 64 + i * 32 + frow) * 128;
-    b_off[i] = TILE_BYTES + (wn * 64 + i * 32 + frow) * 128;
+    if (i < MI) a_off[i] = (wm * (32 * MI) + i * 32 + frow) * 128;
+    b_off[i] = A_BYTES + (wn * 64 + i * 32 + frow) * 128;
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -136,18 +144,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
   const int nk_per = (K / BK) / ksplit;  // the launcher guarantees divisibility
   const int kt0 = ks_id * nk_per;
   auto compute = [&](int buf) {
-    const char* base = smem + buf * (2 * TILE_BYTES);
+    const char* base = smem + buf * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int coff = ((ks * 2 + khalf) ^ fsw) << 4;
-      bf16x8 a[2], b[2];
+      bf16x8 a[MI], b[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i] + coff);
+        if (i < MI) a[i] = *reinterpret_cast<const bf16x8*>(base + a_off[i] + coff);
         b[i] = *reinterpret_cast<const bf16x8*>(base + b_off[i] + coff);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
@@ -165,32 +173,49 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
       __syncthreads();
     }
   } else {
-    // NST - 1 K-tiles in flight; every tile is 8 LDS-DMA instructions per wave, so "tile i has landed" is
-    // vmcnt(8 * tiles issued after it).  One barrier per K-tile: it publishes tile i and retires buffer (i-1) % NST,
+    // NST - 1 K-tiles in flight; every tile is 8 (MI = 2) or 6 (MI = 1) LDS-DMA instructions per wave, so "tile i has
+    // landed" is vmcnt(that many * tiles issued after it).  One barrier per K-tile: it publishes tile i and retires buffer (i-1) % NST,
     // which the refill issued right after it overwrites.
-    static_assert(NST == 4, "stage ring is written for 4 stages");
+    // (six stages of the 64-row tile, 144 KiB, measured no faster than four: 15.1 vs 14.6 us on the FFN-up shape at M = 240)
+    static_assert(NST == 4, "stage ring is instantiated for 4 stages");
+    constexpr int PER = 2 * MI + 4;  // LDS-DMA instructions per wave and K-tile
 #pragma unroll
     for (int p = 0; p < NST - 1; ++p)
       if (p < nk_per) stage(p, kt0 + p);
+    int cur = 0, fill = NST - 1;  // ring positions of K-tile i and of the K-tile issued in iteration i
     for (int i = 0; i < nk_per; ++i) {
       const int after = min(NST - 2, nk_per - 1 - i);
-      if (after >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-      else if (after == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // vmcnt(PER * after): immediates only
+      if (after >= 4) {
+        if constexpr (NST == 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      } else if (after == 3) {
+        if constexpr (NST == 6) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      } else if (after == 2) {
+        if constexpr (PER == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      } else if (after == 1) {
+        if constexpr (PER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();  // raw barrier: __syncthreads() would add vmcnt(0) and drain the ring
-      if (i + NST - 1 < nk_per) stage((i + NST - 1) & (NST - 1), kt0 + i + NST - 1);
-      compute(i & (NST - 1));
+      if (i + NST - 1 < nk_per) stage(fill, kt0 + i + NST - 1);
+      compute(cur);
+      cur = cur + 1 == NST ? 0 : cur + 1;
+      fill = fill + 1 == NST ? 0 : fill + 1;
     }
     __syncthreads();  // the epilogue slabs alias the stages
   }
 
   // ---- epilogue: registers -> this wave's LDS slab -> whole-row global stores -------------------
-  float* slab = reinterpret_cast<float*>(smem) + wave * (64 * 64);
+  constexpr int WR = 32 * MI;  // rows of a wave's tile
+  float* slab = reinterpret_cast<float*>(smem) + wave * (WR * 64);
   const int ccol = lane & 31, rhalf = lane >> 5;
   if (partial != nullptr) {
     // split-K slice: raw f32 tile -> partial[ks_id][m][n] (row stride N; rows >= M are never written or read)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -201,18 +226,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     const int prow = lane >> 4, pc4 = (lane & 15) * 4;  // 16 lanes per 64-float row, 4 rows per iteration
-    float* pbase = partial + (int64_t)ks_id * ((int64_t)tiles_m * BM * N) + (int64_t)(m0 + wm * 64) * N + n0 + wn * 64;
+    float* pbase = partial + (int64_t)ks_id * pstride + (int64_t)(m0 + wm * WR) * N + n0 + wn * 64;
 #pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < WR / 4; ++it) {
       const int row = it * 4 + prow;
-      if (m0 + wm * 64 + row < M)
+      if (m0 + wm * WR + row < M)
         *reinterpret_cast<f32x4*>(pbase + (int64_t)row * N + pc4) = *reinterpret_cast<const f32x4*>(slab + row * 64 + pc4);
     }
     return;
   }
   constexpr int SW = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? 32 : 64;  // slab width in floats
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < MI; ++i) {
     if constexpr (EPI == ESMDIFF_EPI_SWIGLU_BF16) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -238,9 +263,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
   const int rr_ = lane / LPR, c4 = (lane % LPR) * 4;
   const int ncol0 = (EPI == ESMDIFF_EPI_SWIGLU_BF16) ? (n0 + wn * 64) / 2 : (n0 + wn * 64);
 #pragma unroll 4
-  for (int it = 0; it < 64 / RPI; ++it) {
+  for (int it = 0; it < WR / RPI; ++it) {
     const int row = it * RPI + rr_;
-    const int m = m0 + wm * 64 + row;
+    const int m = m0 + wm * WR + row;
     if (m >= M) continue;
     f32x4 v = *reinterpret_cast<const f32x4*>(slab + row * SW + c4);
     const int n = ncol0 + c4;
@@ -327,6 +352,68 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// One launch of the 128-column-tile kernel.  mi: 32-row blocks per wave (tile height 64 * mi); S > 1: K slices into
+// `partial` (S planes of pstride floats, row stride N), reduced by splitk_reduce_kernel unless keep_partials.
+static hipError_t launch_tiles(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N, int K,
+                               int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream, int mi, int S,
+                               float* partial, int64_t pstride, bool keep_partials) {
+  const int bm = 64 * mi;
+  const int tiles_m = (M + bm - 1) / bm, tiles_n = N / BN;
+  // four-stage ring with one workgroup per CU while everything is resident at once; two stages x two (or more)
+  // workgroups per CU beyond that
+  const bool four = tiles_m * tiles_n * S <= 256;
+  dim3 grid(tiles_m * tiles_n * S), block(256);
+  const int w_rs = K, w_ks = BK;          // W strides: row, K-tile, 128-row block (row-major [N, K])
+  const int64_t w_ns = (int64_t)BN * K;
+#define ED_LAUNCH(E, NST, MI)                                                                                       \
+  do {                                                                                                              \
+    constexpr int lds = NST * (64 * MI * BK * 2 + TILE_BYTES);                                                      \
+    static bool attr_done = false;                                                                                  \
+    if (!attr_done && lds > 65536) {                                                                                \
+      hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, NST, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+      attr_done = true;                                                                                             \
+    }                                                                                                               \
+    hipLaunchKernelGGL((gemm_bf16_kernel<E, NST, MI>), grid, block, lds, stream, A, W, out, bias, M, N, K, ldc,     \
+                       n_valid, alpha, tiles_m, tiles_n, S, partial, pstride, w_rs, w_ks, w_ns);                    \
+  } while (0)
+#define ED_GEMM(E)                                                                                                  \
+  do {                                                                                                              \
+    if (four && mi == 2) ED_LAUNCH(E, 4, 2);                                                                        \
+    else if (four) ED_LAUNCH(E, 4, 1);                                                                              \
+    else if (mi == 2) ED_LAUNCH(E, 2, 2);                                                                           \
+    else ED_LAUNCH(E, 2, 1);                                                                                        \
+    if (S > 1 && !keep_partials) {                                                                                  \
+      const int64_t n_thr = (int64_t)M * ((E == ESMDIFF_EPI_SWIGLU_BF16 ? N / 2 : N) / 4);                          \
+      hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,      \
+                         partial, S, pstride, out, bias, M, N, ldc, alpha);                                         \
+    }                                                                                                               \
+  } while (0)
+  switch (epilogue) {
+    case ESMDIFF_EPI_BF16: ED_GEMM(ESMDIFF_EPI_BF16); break;
+    case ESMDIFF_EPI_RESID_F32: ED_GEMM(ESMDIFF_EPI_RESID_F32); break;
+    case ESMDIFF_EPI_SWIGLU_BF16: ED_GEMM(ESMDIFF_EPI_SWIGLU_BF16); break;
+    case ESMDIFF_EPI_BIAS_GELU_BF16: ED_GEMM(ESMDIFF_EPI_BIAS_GELU_BF16); break;
+    case ESMDIFF_EPI_BIAS_F32: ED_GEMM(ESMDIFF_EPI_BIAS_F32); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef ED_GEMM
+#undef ED_LAUNCH
+  return hipGetLastError();
+}
+
+// Tile height of the small-M path: 64-row tiles while the 128-row grid (x K slices) would leave half the CUs without a
+// workgroup.  The K order per output element is the same, so this never changes a result bit.
+// ESMDIFF_GEMM_SMALL_BM=64|128 forces one (A/B runs).
+static int small_tile_mi(int M, int N, int S) {
+  static const int forced = [] {
+    const char* e = getenv("ESMDIFF_GEMM_SMALL_BM");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 64) return 1;
+  if (forced == 128) return 2;
+  return ((M + 127) / 128) * (N / BN) * S <= 128 ? 1 : 2;
+}
+
 hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
                             int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream,
                             const GemmWorkspace* ws) {
@@ -344,12 +431,13 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
   }();
   if (N % 256 == 0 && (forced == 256 || (forced == 0 && ((M + 255) / 256) * (N / 256) >= 128)))
     return launch_gemm256_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+  const int tiles_n = N / BN;
   // split-K factor, a function of (N, K) only: for K >= 2048 (FFN-down) the largest divisor of K/64 that is <= 8 and
   // keeps tiles_n * S <= 96.  Measured (us per launch, M = 240 / 774): FFN-down K = 4096 S = 8: 42 -> 17 / 41 -> 35;
   // but K = 1536 shapes lose at the larger M (out-proj S = 8: 21 -> 16 / 20 -> 27; QKV S = 2: 21 -> 20 / 22 -> 33) —
   // the f32 partials (S x M x N x 4 B, written and re-read) outweigh the shorter K loop — so they are not split.
   int S = 1;
+  const int64_t pstride = (int64_t)((M + 127) / 128) * 128 * N;
   if (M < 1024 && ws && ws->partial && K >= 2048) {
     const int nk = K / BK;
     for (int c = 8; c >= 2; --c)
@@ -357,45 +445,42 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
         S = c;
         break;
       }
-    if ((size_t)S * tiles_m * BM * N > ws->partial_floats) S = 1;
+    if ((size_t)S * pstride > ws->partial_floats) S = 1;
   }
-  // four-stage ring with one workgroup per CU while everything is resident at once; two stages x two workgroups
-  // per CU beyond that
-  const bool small = tiles_m * tiles_n * S <= 256;
-  float* partial = S > 1 ? ws->partial : nullptr;
-  const int64_t pstride = (int64_t)tiles_m * BM * N;
-  dim3 grid(tiles_m * tiles_n * S), block(256);
-#define ED_GEMM(E)                                                                                                  \
-  do {                                                                                                              \
-    if (small) {                                                                                                    \
-      static bool attr_done = false;                                                                                \
-      if (!attr_done) {                                                                                             \
-        hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                            8 * TILE_BYTES);                                                                        \
-        attr_done = true;                                                                                           \
-      }                                                                                                             \
-      hipLaunchKernelGGL((gemm_bf16_kernel<E, 4>), grid, block, 8 * TILE_BYTES, stream, A, W, out, bias, M, N, K,   \
-                         ldc, n_valid, alpha, tiles_m, tiles_n, S, partial);                                        \
-    } else {                                                                                                        \
-      hipLaunchKernelGGL((gemm_bf16_kernel<E, 2>), grid, block, 4 * TILE_BYTES, stream, A, W, out, bias, M, N, K,   \
-                         ldc, n_valid, alpha, tiles_m, tiles_n, S, partial);                                        \
-    }                                                                                                               \
-    if (S > 1) {                                                                                                    \
-      const int64_t n_thr = (int64_t)M * ((E == ESMDIFF_EPI_SWIGLU_BF16 ? N / 2 : N) / 4);                          \
-      hipLaunchKernelGGL(splitk_reduce_kernel<E>, dim3((unsigned)((n_thr + 255) / 256)), dim3(256), 0, stream,      \
-                         partial, S, pstride, out, bias, M, N, ldc, alpha);                                         \
-    }                                                                                                               \
-  } while (0)
-  switch (epilogue) {
-    case ESMDIFF_EPI_BF16: ED_GEMM(ESMDIFF_EPI_BF16); break;
-    case ESMDIFF_EPI_RESID_F32: ED_GEMM(ESMDIFF_EPI_RESID_F32); break;
-    case ESMDIFF_EPI_SWIGLU_BF16: ED_GEMM(ESMDIFF_EPI_SWIGLU_BF16); break;
-    case ESMDIFF_EPI_BIAS_GELU_BF16: ED_GEMM(ESMDIFF_EPI_BIAS_GELU_BF16); break;
-    case ESMDIFF_EPI_BIAS_F32: ED_GEMM(ESMDIFF_EPI_BIAS_F32); break;
-    default: return hipErrorInvalidValue;
-  }
-#undef ED_GEMM
-  return hipGetLastError();
+  const int mi = M < 1024 ? small_tile_mi(M, N, S) : 2;
+  return launch_tiles(A, W, out, bias, M, N, K, ldc, n_valid, alpha, epilogue, stream, mi, S,
+                      S > 1 ? ws->partial : nullptr, pstride, false);
+}
+
+// ---- residual-branch linears of the small-batch path ------------------------------------------------------------
+// Below 1024 rows the out-projection and FFN-down products are left as S raw f32 K-slice planes; the add+LayerNorm
+// kernel that consumes them (norm.hip: launch_add_partials_layernorm_bf16) sums the planes in the order s = 0..S-1,
+// scales and adds them to the residual stream — so no reduce kernel runs and the K = 1536 out-projection can be sliced
+// as well (with a separate reduce pass its slices did not pay, see above).  S is a function of (N, K) only: the
+// largest divisor of K/64 <= 8 that leaves every slice >= 6 K-tiles and tiles_n * S <= 96 (N = 1536: K = 1536 -> 4,
+// K = 4096 -> 8).  ESMDIFF_GEMM_PSPLIT=<S> overrides (A/B runs; must divide K/64).
+int gemm_partial_splits(int N, int K) {
+  static const int forced = [] {
+    const char* e = getenv("ESMDIFF_GEMM_PSPLIT");
+    return e ? atoi(e) : 0;
+  }();
+  const int nk = K / BK, tiles_n = N / BN;
+  if (forced > 0 && nk % forced == 0) return forced;
+  for (int c = 8; c >= 2; --c)
+    if (nk % c == 0 && nk / c >= 6 && tiles_n * c <= 96) return c;
+  return 1;
+}
+
+hipError_t launch_gemm_partials(const bf16_t* A, const bf16_t* W, const GemmWorkspace* ws, int M, int N, int K,
+                                hipStream_t stream, GemmPartials* res) {
+  if (M <= 0 || M >= 1024 || !ws || !ws->partial || !res || N % BN != 0 || K % BK != 0) return hipErrorInvalidValue;
+  const int S = gemm_partial_splits(N, K);
+  const int64_t pstride = (int64_t)((M + 127) / 128) * 128 * N;
+  if ((size_t)S * pstride > ws->partial_floats) return hipErrorInvalidValue;
+  *res = GemmPartials{ws->partial, S, pstride};
+  // (S = 1 still goes through `partial`: one raw f32 plane)
+  return launch_tiles(A, W, nullptr, nullptr, M, N, K, N, N, 1.f, ESMDIFF_EPI_BF16, stream, small_tile_mi(M, N, S), S,
+                      ws->partial, pstride, true);
 }
 
 }  // namespace ed

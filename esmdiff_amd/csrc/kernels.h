@@ -35,6 +35,17 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
                             int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream,
                             const GemmWorkspace* ws = nullptr);
 
+// Small-batch path (M < 1024): the product as S raw f32 K-slice planes in `ws` (plane stride `stride` floats, row stride
+// N), consumed by launch_add_partials_layernorm_bf16.  S = gemm_partial_splits(N, K), a function of the shape only.
+struct GemmPartials {
+  const float* p;
+  int S;
+  int64_t stride;
+};
+int gemm_partial_splits(int N, int K);
+hipError_t launch_gemm_partials(const bf16_t* A, const bf16_t* W, const GemmWorkspace* ws, int M, int N, int K,
+                                hipStream_t stream, GemmPartials* res);
+
 // gemm256.hip: 256x256x64 tiles, 8 waves, counted-vmcnt pipeline; needs N % 256 == 0 (large-M path)
 hipError_t launch_gemm256_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
                                int K, int ldc, float alpha, int epilogue, hipStream_t stream);
@@ -49,6 +60,10 @@ hipError_t launch_layernorm_bf16(const float* x, const float* w, const float* b,
 // v = (x + delta) + delta2 (bf16 or null each); x = v if write_x; y = LayerNorm(v) * w (+ b)
 hipError_t launch_add_layernorm_bf16(float* x, const bf16_t* delta, const bf16_t* delta2, int write_x, const float* w,
                                      const float* b, bf16_t* y, int M, int D, hipStream_t stream);
+// x += alpha * (P[0] + P[1] + ... + P[S-1]) (f32 K-slice planes of a branch linear); x written back;
+// y = LayerNorm(x) * w (+ b)
+hipError_t launch_add_partials_layernorm_bf16(float* x, const GemmPartials& P, int N, float alpha, const float* w,
+                                              const float* b, bf16_t* y, int M, int D, hipStream_t stream);
 hipError_t launch_layernorm_bf16_in(const bf16_t* x, const float* w, const float* b, bf16_t* y, int M, int D,
                                     hipStream_t stream);
 // qkv bf16 [M,3D] -> q,k bf16 [M,D] token-major (LayerNorm over D, rotary, q pre-scaled); v stays in qkv

@@ -191,6 +191,112 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(float* __restrict__ 
   }
 }
 
+// Small-batch path: the branch linear left its product as S raw f32 K-slice planes (gemm.hip: launch_gemm_partials);
+// x += alpha * (P[0] + ... + P[S-1]), summed in that order; x written back; y = LayerNorm(x) * w (+ b).
+// A few hundred rows at most, so latency is everything: ONE WORKGROUP PER ROW (256 threads, thread t owns float4 t and
+// t + 256 of the row), every plane load of a thread issued before the first add, statistics through 4-wave LDS sums.
+template <int S>
+__global__ __launch_bounds__(256) void add_partials_layernorm_kernel(float* __restrict__ x, const float* __restrict__ P,
+                                                                     int64_t pstride, int ldp, float alpha,
+                                                                     const float* __restrict__ w,
+                                                                     const float* __restrict__ b,
+                                                                     bf16_t* __restrict__ y, int D) {
+  __shared__ float red[2][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int64_t row = blockIdx.x;
+  const int nv4 = D >> 2;
+  const bool has2 = t + 256 < nv4, has1 = t < nv4;
+  float* xr = x + row * D;
+  const float* pr = P + row * ldp;
+  f32x4 xv[2], pv[2][S];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const bool on = c ? has2 : has1;
+    const int col = (t + c * 256) * 4;
+    if (on) {
+      xv[c] = *reinterpret_cast<const f32x4*>(xr + col);
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) pv[c][s2] = *reinterpret_cast<const f32x4*>(pr + s2 * pstride + col);
+    } else {
+      xv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) pv[c][s2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  f32x4 v[2];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    f32x4 acc = pv[c][0];
+#pragma unroll
+    for (int s2 = 1; s2 < S; ++s2) {
+      acc[0] += pv[c][s2][0]; acc[1] += pv[c][s2][1]; acc[2] += pv[c][s2][2]; acc[3] += pv[c][s2][3];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[c][e] = xv[c][e] + acc[e] * alpha;
+    if (c ? has2 : has1) *reinterpret_cast<f32x4*>(xr + (t + c * 256) * 4) = v[c];
+    sum += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+  }
+  sum = wsum(sum);
+  if (lane == 0) red[0][wave] = sum;
+  __syncthreads();
+  const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    if (c ? has2 : has1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[c][e] - mean;
+        q += d * d;
+      }
+    }
+  q = wsum(q);
+  if (lane == 0) red[1][wave] = q;
+  __syncthreads();
+  const float rstd = rsqrtf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)D + 1e-5f);
+  bf16_t* yr = y + row * D;
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+    if (c ? has2 : has1) {
+      const int col = (t + c * 256) * 4;
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(w + col);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[c][e] - mean) * rstd * ww[e];
+      if (b) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += bb[e];
+      }
+      uint2 pk;
+      pk.x = pack2(o[0], o[1]);
+      pk.y = pack2(o[2], o[3]);
+      *reinterpret_cast<uint2*>(yr + col) = pk;
+    }
+}
+
+hipError_t launch_add_partials_layernorm_bf16(float* x, const GemmPartials& P, int N, float alpha, const float* w,
+                                              const float* b, bf16_t* y, int M, int D, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  if ((D & 3) || D > 2048 || !P.p || P.S < 1 || P.S > 8 || N < D) return hipErrorInvalidValue;
+  dim3 grid(M), block(256);
+#define ED_APLN(Sv) \
+  hipLaunchKernelGGL(add_partials_layernorm_kernel<Sv>, grid, block, 0, stream, x, P.p, P.stride, N, alpha, w, b, y, D)
+  switch (P.S) {
+    case 1: ED_APLN(1); break;
+    case 2: ED_APLN(2); break;
+    case 3: ED_APLN(3); break;
+    case 4: ED_APLN(4); break;
+    case 5: ED_APLN(5); break;
+    case 6: ED_APLN(6); break;
+    case 7: ED_APLN(7); break;
+    default: ED_APLN(8); break;
+  }
+#undef ED_APLN
+  return hipGetLastError();
+}
+
 hipError_t launch_add_layernorm_bf16(float* x, const bf16_t* delta, const bf16_t* delta2, int write_x, const float* w,
                                      const float* b, bf16_t* y, int M, int D, hipStream_t stream) {
   if (M <= 0) return hipSuccess;

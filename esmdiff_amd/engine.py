@@ -70,6 +70,22 @@ class Engine:
         self.has_sigma_embedder = any(k.startswith("sigma_embedder.mlp.0.") for k in state_dict)
         self._frames = None
 
+    def branch_linear_layernorm(self, A: torch.Tensor, W: torch.Tensor, x: torch.Tensor, alpha: float, w: torch.Tensor,
+                                b: Optional[torch.Tensor]):
+        """x += alpha * (A @ W^T) in place (f32), returns (LayerNorm(x) * w (+ b) as bf16, K slices used): the small-batch
+        form of a residual branch (esmdiff_branch_linear_layernorm)."""
+        M, K = A.shape
+        Nn = W.shape[0]
+        assert A.dtype == W.dtype == torch.bfloat16 and x.dtype == torch.float32 and x.shape == (M, Nn)
+        assert A.is_contiguous() and W.is_contiguous() and x.is_contiguous()
+        y = torch.empty(M, Nn, dtype=torch.bfloat16, device=A.device)
+        S = ctypes.c_int32(0)
+        self._chk(self._lib.esmdiff_branch_linear_layernorm(self._h, _ptr(A), _ptr(W), _ptr(x), float(alpha),
+                                                            _ptr(w.float().contiguous()),
+                                                            _ptr(None if b is None else b.float().contiguous()), _ptr(y),
+                                                            M, Nn, K, ctypes.byref(S), _stream()))
+        return y, int(S.value)
+
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
             self._lib.esmdiff_engine_destroy(self._h)

@@ -149,6 +149,11 @@ int esmdiff_gibbs_sample(esmdiff_engine* eng, const int64_t* seq, int64_t* x_ino
                          float temperature, float top_p, const int32_t* n_unmask_table, const esmdiff_rng* rng,
                          void* stream);
 
+/* Measurement aid: one forward at (B, L) `n` times as plain launches and as `n` replays of one captured hipGraph of the
+ * same launches (engine-owned stream); milliseconds per forward of each [host]. */
+int esmdiff_debug_graph_ab(esmdiff_engine* eng, const int64_t* seq, const int64_t* x, int32_t B, int32_t L, int32_t n,
+                           float* ms_direct, float* ms_graph);
+
 /* Per-kernel entry points (used by the parity tests and the bench's roofline leg). */
 
 /* C[M,N] (+)= A[M,K] · W[N,K]^T, bf16 in, f32 accumulate.  epilogue: see esmdiff_gemm_epilogue. */
@@ -174,6 +179,14 @@ int esmdiff_gemm_bf16_ws(esmdiff_engine* eng, const void* A, const void* W, void
 int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float* bias, int32_t M,
                             int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha,
                             int32_t epilogue, int32_t iters, float* ms_out, void* stream);
+
+/* The small-batch form of a residual branch (M < 1024 rows; csrc/engine.hip::forward): the branch linear A[M,K] W[N,K]^T
+ * is left as S raw f32 K-slice planes in the engine's workspace (S = *splits_out, a function of N and K only) and the
+ * LayerNorm kernel that follows sums them:  x[M,N] f32 += alpha * (A W^T);  y bf16 [M,N] = LayerNorm(x) * w (+ b).
+ * N = d_model of the engine's shapes (N % 128 == 0, N <= 2048), K % 64 == 0.  Not re-entrant per engine. */
+int esmdiff_branch_linear_layernorm(esmdiff_engine* eng, const void* A, const void* W, float* x, float alpha,
+                                    const float* w, const float* b, void* y, int32_t M, int32_t N, int32_t K,
+                                    int32_t* splits_out, void* stream);
 
 /* y bf16 [M,D] = LayerNorm(x f32 [M,D]) * w (+ b); b may be NULL.  eps = 1e-5. */
 int esmdiff_layernorm_bf16(const float* x, const float* w, const float* b, void* y, int32_t M, int32_t D,

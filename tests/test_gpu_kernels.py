@@ -286,6 +286,28 @@ def test_gemm256w4_epilogues_large_m(K):
     assert bool((o[-5:, :4101] != -7.0).all())                 # the ragged last rows were written
 
 
+@pytest.mark.parametrize("M,K", [(240, 1536), (240, 4096), (517, 1536), (1000, 4096), (3, 1536)])
+def test_branch_linear_layernorm_small_batch(tiny, M, K):
+    """The small-batch residual branch: K-slice planes of the out-projection / FFN-down shapes summed inside the LayerNorm
+    kernel (x += alpha * A W^T; y = LN(x) w + b) against f32 torch; S is the documented function of (N, K)."""
+    _, _, eng, _, _ = tiny
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    D = 1536
+    A = _bf(torch.randn(M, K, generator=g, device="cuda"))
+    W = _bf(torch.randn(D, K, generator=g, device="cuda") / K ** 0.5)
+    x0 = torch.randn(M, D, generator=g, device="cuda") * 3
+    w, b = torch.randn(D, generator=g, device="cuda"), torch.randn(D, generator=g, device="cuda")
+    for bias in (b, None):
+        x = x0.clone()
+        y, S = eng.branch_linear_layernorm(A, W, x, 0.866, w, bias)
+        assert S == {1536: 4, 4096: 8}[K]
+        xr = x0 + 0.866 * (A.float() @ W.float().t())
+        assert float((x - xr).abs().max()) < 2e-4                       # f32 accumulation, only the summation order differs
+        ref = torch.nn.functional.layer_norm(xr, (D,), w, bias, 1e-5)
+        err = (y.float() - ref).abs()
+        assert float((err - ref.abs() * 2 ** -8).max()) < 2e-3
+
+
 def test_layernorm():
     from esmdiff_amd.engine import layernorm_bf16
     g = torch.Generator().manual_seed(2)
