@@ -256,7 +256,8 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
 // When: batches of >= 12 288 tokens (both halves still run the 256x256 GEMM) and small batches of <= 6 400 tokens
 // (768 .. 6 400: everything is on the 128-column-tile path either way and the kernels are latency-bound, so two queues
 // simply overlap them; r02, L_tok = 60, one stream / two: B = 16 89.1 / 99.1 samples/s, B = 8 70.5 / 70.3, B = 4
-// 44.5 / 41.8 — below ~700 tokens the halves' GEMMs each stream the whole weight matrix for half the rows and lose).
+// 44.5 / 41.8 — below ~700 tokens the halves' GEMMs each stream the whole weight matrix for half the rows and lose;
+// the 768-token start needs B >= 8: B = 3, L_tok = 258 cuts into 1 + 2 samples and loses, 18.7 / 17.5).
 // In between the halves would fall below the 128-tile switch of the GEMM dispatch and lose more than the overlap gives
 // (samples/s at L_tok = 258, one stream / two: B = 8 29.4 / 31.7, 16 36.9 / 39.7, 24 43.1 / 44.1, 32 45.8 / 45.8,
 // 40 49.7 / 46.8, 48 47.4 / 51.9, 64 49.2 / 52.2, 100 50.7 / 53.0).
@@ -287,7 +288,7 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   int np = 1;
   const int64_t tokens = (int64_t)B * L;
   if (!e->side.empty() && e->profiling != 1 && B >= 2 &&
-      (tokens >= e->dual_min_tokens || (tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(768, e->dual_min_tokens))))
+      (tokens >= e->dual_min_tokens || (tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(B >= 8 ? 768 : 1024, e->dual_min_tokens))))
     np = std::min<int>({(int)e->side.size() + 1, B, 4});
   for (int pi = 0; pi < np; ++pi) {
     const int b0 = (int)((int64_t)B * pi / np), b1 = (int)((int64_t)B * (pi + 1) / np);

@@ -46,6 +46,12 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
 constexpr int GROUP_M = 8;
 
+// the weight stream with the non-temporal policy (aux = 2): when only a few row tiles re-read a weight tile it lands
+// ~18 % sooner (configs[0]: +3 %); with many row tiles sharing it through L2 it loses (M = 774: -7 %), see launch_tiles
+__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 2);
+}
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst_wave_uniform) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
@@ -77,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
                                                            int ldc, int n_valid, float alpha, int tiles_m,
                                                            int tiles_n, int ksplit, float* __restrict__ partial,
                                                            int64_t pstride, int w_row_stride, int w_kt_stride,
-                                                           int64_t w_nblk_stride) {
+                                                           int64_t w_nblk_stride, int w_nt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST stages][A 8K*MI | B 16K]
   constexpr int BM = 64 * MI, A_BYTES = BM * BK * 2, STAGE = A_BYTES + TILE_BYTES;
 
@@ -119,7 +125,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
     for (int i = 0; i < 4; ++i) {
       char* da = base + (i * 4 + wave) * 1024;
       if (i < 2 * MI) glds16(a_src[i] + kt * BK, da);
-      glds16(w_src[i] + (int64_t)kt * w_kt_stride, da + A_BYTES);
+      if (w_nt) glds16_nt(w_src[i] + (int64_t)kt * w_kt_stride, da + A_BYTES);
+      else glds16(w_src[i] + (int64_t)kt * w_kt_stride, da + A_BYTES);
     }
   };
 
@@ -363,6 +370,7 @@ static hipError_t launch_tiles(const bf16_t* A, const bf16_t* W, void* out, cons
   // workgroups per CU beyond that
   const bool four = tiles_m * tiles_n * S <= 256;
   dim3 grid(tiles_m * tiles_n * S), block(256);
+  const int w_nt = tiles_m <= 8;          // few row tiles per weight tile: stream the weights non-temporally
   const int w_rs = K, w_ks = BK;          // W strides: row, K-tile, 128-row block (row-major [N, K])
   const int64_t w_ns = (int64_t)BN * K;
 #define ED_LAUNCH(E, NST, MI)                                                                                       \
@@ -374,7 +382,7 @@ static hipError_t launch_tiles(const bf16_t* A, const bf16_t* W, void* out, cons
       attr_done = true;                                                                                             \
     }                                                                                                               \
     hipLaunchKernelGGL((gemm_bf16_kernel<E, NST, MI>), grid, block, lds, stream, A, W, out, bias, M, N, K, ldc,     \
-                       n_valid, alpha, tiles_m, tiles_n, S, partial, pstride, w_rs, w_ks, w_ns);                    \
+                       n_valid, alpha, tiles_m, tiles_n, S, partial, pstride, w_rs, w_ks, w_ns, w_nt);              \
   } while (0)
 #define ED_GEMM(E)                                                                                                  \
   do {                                                                                                              \
