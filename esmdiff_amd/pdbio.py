@@ -56,11 +56,42 @@ def read_pdb_backbone(path, chain: Optional[str] = None) -> Tuple[str, np.ndarra
     return "".join(seq), np.stack(coords)
 
 
-def write_backbone_pdb(path, sequence: str, coords: np.ndarray, bfactor: Optional[np.ndarray] = None) -> None:
-    """N/CA/C backbone as ATOM records (used once a structure decoder supplies coordinates)."""
+_O_LOCAL = np.array([0.6240, -1.0613, 0.0103], dtype=np.float64)   # [ESM-RECALL: esm ProteinChain.infer_oxygen]
+
+
+def infer_oxygen(coords: np.ndarray) -> np.ndarray:
+    """Carbonyl O from N/CA/C, as the reference's decode path places it (`chain.infer_oxygen()`,
+    /root/reference/slm/models/utils.py:78-79; esm ProteinChain.infer_oxygen): residue i's O is a fixed vector in the
+    Gram-Schmidt frame with origin C_i, x axis CA_i -> C_i and the N_{i+1} side of the plane as +y; the last residue has
+    no following N and gets NaN.  coords [L, >=3, 3] (N, CA, C first) -> [L, 3].
+    The local vector gives |C=O| = 1.231 A, CA-C-O = 120.5 deg, O-C-N(+1) = 123.5 deg in the peptide plane."""
+    xyz = np.asarray(coords, dtype=np.float64)
+    L = xyz.shape[0]
+    out = np.full((L, 3), np.nan)
+    if L < 2:
+        return out.astype(np.float32)
+    ca, c, n_next = xyz[:-1, 1], xyz[:-1, 2], xyz[1:, 0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        e0 = c - ca
+        e0 = e0 / np.linalg.norm(e0, axis=-1, keepdims=True)
+        v = n_next - c
+        e1 = v - e0 * np.sum(e0 * v, axis=-1, keepdims=True)
+        e1 = e1 / np.linalg.norm(e1, axis=-1, keepdims=True)
+        e2 = np.cross(e0, e1)
+        out[:-1] = c + _O_LOCAL[0] * e0 + _O_LOCAL[1] * e1 + _O_LOCAL[2] * e2
+    return out.astype(np.float32)
+
+
+def write_backbone_pdb(path, sequence: str, coords: np.ndarray, bfactor: Optional[np.ndarray] = None,
+                       with_oxygen: bool = True) -> None:
+    """N/CA/C backbone (+ the inferred carbonyl O, as the reference's decoded chains carry it) as ATOM records."""
     lines, serial = [], 1
+    coords = np.asarray(coords)
+    if with_oxygen and coords.shape[0] == len(sequence) and coords.shape[0] > 0:
+        coords = np.concatenate([coords[:, :3], infer_oxygen(coords)[:, None]], axis=1)
+    atoms = (("N", "N"), ("CA", "C"), ("C", "C"), ("O", "O"))[:coords.shape[1] if coords.ndim == 3 else 3]
     for i, aa in enumerate(sequence):
-        for j, (name, elem) in enumerate((("N", "N"), ("CA", "C"), ("C", "C"))):
+        for j, (name, elem) in enumerate(atoms):
             x, y, z = (float(v) for v in coords[i, j])
             if not np.isfinite([x, y, z]).all():
                 continue

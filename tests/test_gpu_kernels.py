@@ -903,7 +903,7 @@ def test_cli_writes_multi_model_pdb_with_decoder(tmp_path):
     # (the reference's merge closes single-model inputs twice at the very end — eval_utils.py:437-492, golden g8)
     assert sum(l.startswith("MODEL") for l in text) == 4 and sum(l.startswith("ENDMDL") for l in text) in (4, 5)
     assert text[-1].startswith("END") and all(len(l) == 80 for l in text)
-    assert sum(l.startswith("ATOM") for l in text) == 4 * 30 * 3
+    assert sum(l.startswith("ATOM") for l in text) == 4 * (30 * 3 + 29)     # N, CA, C + the inferred O (none on the last residue)
     ca = [l for l in text if l.startswith("ATOM") and l[12:16].strip() == "CA"]
     assert len(ca) == 120
 

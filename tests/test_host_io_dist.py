@@ -47,6 +47,40 @@ def test_pdb_reader_and_tokenizer(tmp_path):
     assert bf[:3] == [0.25] * 3 and bf[-1] == 0.88
 
 
+def test_infer_oxygen_geometry(tmp_path):
+    """Carbonyl O as the reference's decode path adds it (models/utils.py:78-79, esm infer_oxygen; constants from memory,
+    so the test pins the chemistry they imply): |C=O| = 1.231 A, CA-C-O = 120.5 deg, O opposite N(+1) across the CA->C
+    axis and in the peptide plane; none on the last residue; rigid motions commute; the PDB writer emits it."""
+    from esmdiff_amd.pdbio import infer_oxygen, read_pdb_backbone, write_backbone_pdb
+    g = np.random.default_rng(3)
+    L = 12
+    ca = np.cumsum(g.normal(size=(L, 3)) * 2.2, 0)
+    xyz = np.stack([ca + g.normal(size=ca.shape) * 0.8, ca, ca + g.normal(size=ca.shape) * 0.8], 1).astype(np.float32)
+    o = infer_oxygen(xyz)
+    assert o.shape == (L, 3) and np.isnan(o[-1]).all() and np.isfinite(o[:-1]).all()
+    c, n1 = xyz[:-1, 2], xyz[1:, 0]
+    co, cca, cn = o[:-1] - c, xyz[:-1, 1] - c, n1 - c
+    np.testing.assert_allclose(np.linalg.norm(co, axis=-1), 1.2312, atol=2e-3)
+    cosang = (co * cca).sum(-1) / (np.linalg.norm(co, axis=-1) * np.linalg.norm(cca, axis=-1))
+    np.testing.assert_allclose(np.degrees(np.arccos(cosang)), 120.46, atol=0.1)
+    normal = np.cross(cca, cn)
+    normal /= np.linalg.norm(normal, axis=-1, keepdims=True)
+    assert np.abs((co * normal).sum(-1)).max() < 0.02                      # in the CA-C-N(+1) plane (0.0103 A off)
+    e0 = -cca / np.linalg.norm(cca, axis=-1, keepdims=True)
+    perp = lambda v: v - e0 * (v * e0).sum(-1, keepdims=True)
+    assert ((perp(co) * perp(cn)).sum(-1) < 0).all()                        # O and N(+1) on opposite sides of the axis
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]], np.float32)
+    np.testing.assert_allclose(infer_oxygen(xyz @ R.T + 5.0)[:-1], o[:-1] @ R.T + 5.0, atol=2e-4)
+    write_backbone_pdb(tmp_path / "o.pdb", "A" * L, xyz)
+    lines = [ln for ln in (tmp_path / "o.pdb").read_text().splitlines() if ln.startswith("ATOM")]
+    assert len(lines) == 4 * L - 1 and sum(ln[12:16].strip() == "O" and ln[76:78].strip() == "O" for ln in lines) == L - 1
+    seq, back = read_pdb_backbone(tmp_path / "o.pdb")
+    assert seq == "A" * L and np.abs(back - xyz).max() < 1e-3
+    write_backbone_pdb(tmp_path / "n.pdb", "A" * L, xyz, with_oxygen=False)
+    assert sum(ln.startswith("ATOM") for ln in (tmp_path / "n.pdb").read_text().splitlines()) == 3 * L
+
+
 def test_merge_pdbfiles_matches_reference_golden(golden_dir, tmp_path):
     from esmdiff_amd.pdbio import merge_pdbfiles
     g = json.loads((golden_dir / "g8_merge_pdb.json").read_text())
@@ -188,7 +222,8 @@ def test_cli_drivers_shard_decode_gather_gloo_world2(tmp_path):
         assert meta["world_size"] == 2 and meta["num_samples"] == N
         text = (d / "t.pdb").read_text().splitlines()
         assert sum(ln.startswith("MODEL") for ln in text) == N
-        atoms = [ln for ln in text if ln.startswith("ATOM")]
+        assert sum(ln.startswith("ATOM") and ln[12:16].strip() == "O" for ln in text) == N * (L - 1)   # inferred carbonyl O
+        atoms = [ln for ln in text if ln.startswith("ATOM") and ln[12:16].strip() != "O"]
         assert len(atoms) == N * L * 3
         # sample i, residue j: x of atom N = token * 1e-3 + 0; B-factor = (token % 100) / 100
         for i in (0, 3, 6):
