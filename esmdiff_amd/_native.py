@@ -85,7 +85,7 @@ def lib():
     L.esmdiff_get_profile.argtypes = [vp, c_f32p, ctypes.POINTER(i32)]
     L.esmdiff_set_frames.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.esmdiff_decoder_create.argtypes = L.esmdiff_engine_create.argtypes
-    L.esmdiff_decoder_decode.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
+    L.esmdiff_decoder_decode.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp]
     f64, f64p = ctypes.c_double, ctypes.POINTER(ctypes.c_double)
     L.esmdiff_metrics_js_pwd.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, i32, f64p, vp]
     L.esmdiff_metrics_js_rg.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, f64p, vp]
@@ -103,7 +103,7 @@ def lib():
     for n in EXPORTS:
         if n not in ("esmdiff_engine_destroy", "esmdiff_last_error", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error"):
             getattr(L, n).restype = ctypes.c_int
-    if L.esmdiff_abi_version() != 2:
+    if L.esmdiff_abi_version() != 3:
         raise RuntimeError("libesmdiff_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -30,6 +30,7 @@ UNITS = {
     "attention": [],
     "norm": [],
     "embed": [],
+    "pairwise": [],
     "convert": [],
     "sampler": ["-ffp-contract=off"],
     "gibbs": ["-ffp-contract=off"],

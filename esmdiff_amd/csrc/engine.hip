@@ -59,6 +59,14 @@ struct esmdiff_engine {
   bool has_plddt = false;
   int plddt_bins = 0, ld_plddt = 0;
   bf16_t *pl_w0 = nullptr, *pl_w3 = nullptr;
+  // decoder only: esm's pairwise_classification_head (PairwisePredictionHead(d, 128, 128, 224 bins, no bias)); only the
+  // 64 predicted-aligned-error bins (rows 160..223 of linear2) are evaluated: pTM and the PAE matrix (csrc/pairwise.hip)
+  bool has_pair = false;
+  bf16_t *pw_down = nullptr, *pw_l1 = nullptr, *pw_l2 = nullptr, *pair_qk = nullptr;
+  float *pw_ln_w = nullptr, *pw_ln_b = nullptr, *zeros128 = nullptr, *tm_rows = nullptr, *ptm_dev = nullptr;
+  bf16_t *pair_x = nullptr, *pair_h = nullptr;   // pair rows of a chunk of samples (allocated on first use)
+  float* pair_logits = nullptr;
+  int64_t pair_rows_cap = 0;
   float *pl_b0 = nullptr, *pl_ln_w = nullptr, *pl_ln_b = nullptr, *pl_b3 = nullptr, *pl_logits = nullptr;
   // block 0 geometric attention (optional weights; live only while frames are set)
   bool has_geom = false;
@@ -376,6 +384,8 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   // decoder: the pLDDT head reads the same normalised hidden state (w.h) before the structure head's LayerNorm reuses it;
   // its intermediates live in ctx / q, which are free after the last block
   if (e->has_plddt) EACH(S_HEAD, launch_gemm_bf16(w.h, e->pl_w0, w.ctx, e->pl_b0, M, D, D, D, D, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, w.st, w.gws));
+  // ... and so does the pairwise head's down-projection (q | k, 64 + 64 columns per token)
+  if (e->has_pair) EACH(S_HEAD, launch_gemm_bf16(w.h, e->pw_down, e->pair_qk + (w.h - e->h) / D * 128, nullptr, M, 128, D, 128, 128, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
   EACH(S_LN, launch_layernorm_bf16_in(w.h2, e->head_ln_w, e->head_ln_b, w.h, M, D, w.st));
   if (e->has_plddt) EACH(S_LN, launch_layernorm_bf16_in(w.ctx, e->pl_ln_w, e->pl_ln_b, w.q, M, D, w.st));
   EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w3, w.logits, e->head_b3, M, e->vocab_pad, D, ld, c.vocab_out, 1.f, ESMDIFF_EPI_BIAS_F32, w.st, w.gws));
@@ -505,6 +515,17 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       if (launch_to_f32(w->data, w->dtype, e->pl_b3, nb, 0) != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "to_f32 failed"));
       e->has_plddt = true;
     }
+    if (t.find("pairwise_classification_head.linear2.weight")) {
+      const std::string ph = "pairwise_classification_head.";
+      TRY(load_bf16(e, t, ph + "downproject.weight", {128, D}, &e->pw_down));
+      TRY(load_bf16(e, t, ph + "linear1.weight", {128, 128}, &e->pw_l1));
+      TRY(load_f32(e, t, ph + "norm.weight", {128}, &e->pw_ln_w));
+      TRY(load_f32(e, t, ph + "norm.bias", {128}, &e->pw_ln_b));
+      // rows [distogram 64 | direction 96 | PAE 64]; padded so that the 128-row GEMM tile starting at row 160 stays inside
+      TRY(load_bf16(e, t, ph + "linear2.weight", {224, 128}, &e->pw_l2, 384));
+      TRY(dalloc(e, &e->zeros128, (size_t)128, true));
+      e->has_pair = true;
+    }
   } else {
     TRY(load_f32(e, t, "encoder.sequence_embed.weight", {64, D}, &e->e_seq));
     TRY(load_f32(e, t, "encoder.structure_tokens_embed.weight", {ESMDIFF_VOCAB, D}, &e->e_struct));
@@ -612,6 +633,11 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(dalloc(e, &e->mid, Mx * FH));
     TRY(dalloc(e, &e->logits, Mx * e->ld_logits));
     if (e->has_plddt) TRY(dalloc(e, &e->pl_logits, Mx * e->ld_plddt));
+    if (e->has_pair) {
+      TRY(dalloc(e, &e->pair_qk, Mx * 128));
+      TRY(dalloc(e, &e->tm_rows, Mx));
+      TRY(dalloc(e, &e->ptm_dev, (size_t)cfg->max_batch));
+    }
     TRY(dalloc(e, &e->cond, (size_t)D));
     TRY(dalloc(e, &e->sig_hidden, (size_t)D));
     e->tfreq_rows = 1026;
@@ -674,17 +700,53 @@ int esmdiff_decoder_create(const esmdiff_config* cfg, const esmdiff_weight* tabl
   return create_engine(&c, table, n, device, 1, out);
 }
 
-int esmdiff_decoder_decode(esmdiff_engine* e, const int64_t* tokens, float* bb_coords, float* plddt, int32_t B, int32_t L,
-                           float trans_scale, void* stream) {
+// pTM (and optionally the PAE matrix) of the samples just decoded: pair rows of whole samples at a time through
+// linear1 -> GELU -> LayerNorm -> linear2[PAE bins] on the MFMA GEMM, then the bin reduction (csrc/pairwise.hip).
+static int pairwise_confidence(esmdiff_engine* e, const int64_t* tokens, float* ptm, float* pae, int B, int L, hipStream_t st) {
+  const int64_t LL = (int64_t)L * L;
+  // chunk of whole samples: ~1.5 GB of pair rows at most (768 B per row: features, hidden, 64 f32 logits)
+  int cb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(1536ll << 20) / (LL * 768)));
+  if (e->pair_rows_cap < (int64_t)cb * LL) {
+    HIP_TRY(e, hipStreamSynchronize(st));
+    for (void* p : {(void*)e->pair_x, (void*)e->pair_h, (void*)e->pair_logits})
+      if (p) hipFree(p);
+    e->pair_x = e->pair_h = nullptr;
+    e->pair_logits = nullptr;
+    e->pair_rows_cap = 0;
+    const size_t rows = (size_t)cb * LL;
+    if (hipMalloc(&e->pair_x, rows * 128 * 2) != hipSuccess || hipMalloc(&e->pair_h, rows * 128 * 2) != hipSuccess ||
+        hipMalloc(&e->pair_logits, rows * 64 * 4) != hipSuccess)
+      return fail(e, ESMDIFF_E_HIP, "pairwise head workspace for %d x %d^2 pair rows: out of memory", cb, L);
+    e->pair_rows_cap = (int64_t)rows;
+  }
+  for (int b0 = 0; b0 < B; b0 += cb) {
+    const int nb = std::min(cb, B - b0);
+    const int64_t rows = (int64_t)nb * LL;
+    if (rows > 0x7fffffffll) return fail(e, ESMDIFF_E_INVALID, "pairwise head: too many pair rows in one chunk");
+    HIP_TRY(e, launch_pair_features(e->pair_qk + (int64_t)b0 * L * 128, e->pair_x, nb, L, st));
+    HIP_TRY(e, launch_gemm_bf16(e->pair_x, e->pw_l1, e->pair_h, e->zeros128, (int)rows, 128, 128, 128, 128, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, st));
+    HIP_TRY(e, launch_layernorm_bf16_in(e->pair_h, e->pw_ln_w, e->pw_ln_b, e->pair_x, (int)rows, 128, st));
+    HIP_TRY(e, launch_gemm_bf16(e->pair_x, e->pw_l2 + 160 * 128, e->pair_logits, e->zeros128, (int)rows, 128, 128, 64, 64, 1.f, ESMDIFF_EPI_BIAS_F32, st));
+    HIP_TRY(e, launch_pae_tm(e->pair_logits, tokens + (int64_t)b0 * L, e->tm_rows + (int64_t)b0 * L, pae ? pae + (int64_t)b0 * LL : nullptr,
+                             ptm + b0, nb, L, 31.0f, st));
+  }
+  return 0;
+}
+
+int esmdiff_decoder_decode(esmdiff_engine* e, const int64_t* tokens, float* bb_coords, float* plddt, float* ptm, float* pae,
+                           int32_t B, int32_t L, float trans_scale, void* stream) {
   if (!e || !tokens || !bb_coords) return ESMDIFF_E_INVALID;
   if (e->kind != 1) return fail(e, ESMDIFF_E_INVALID, "not a decoder engine");
   if (plddt && !e->has_plddt) return fail(e, ESMDIFF_E_MISSING, "plddt requested but the weight table had no plddt_head.* tensors");
+  if ((ptm || pae) && !e->has_pair) return fail(e, ESMDIFF_E_MISSING, "ptm / pae requested but the weight table had no pairwise_classification_head.* tensors");
+  if (pae && !ptm) return fail(e, ESMDIFF_E_INVALID, "pae is produced together with ptm: pass both");
   if (int r = check_bl(e, B, L)) return r;
   HIP_TRY(e, hipSetDevice(e->device));
   hipStream_t st = (hipStream_t)stream;
   if (int r = forward(e, tokens, tokens, nullptr, e->logits, e->ld_logits, B, L, st)) return r;
   HIP_TRY(e, launch_dim6_to_backbone(e->logits, e->ld_logits, bb_coords, B * L, trans_scale, st));
   if (plddt) HIP_TRY(e, launch_plddt_mean(e->pl_logits, e->ld_plddt, e->plddt_bins, plddt, B * L, st));
+  if (ptm) return pairwise_confidence(e, tokens, ptm, pae, B, L, st);
   return 0;
 }
 

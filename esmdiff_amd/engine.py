@@ -304,6 +304,7 @@ class StructureDecoder:
         del keep
         self.max_batch, self.max_len = max_batch, max_len
         self.has_plddt = any(k == "plddt_head.3.weight" for k in state_dict)
+        self.has_ptm = any(k == "pairwise_classification_head.linear2.weight" for k in state_dict)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -316,20 +317,31 @@ class StructureDecoder:
         except Exception:
             pass
 
-    def decode(self, structure_tokens: torch.Tensor, return_plddt: bool = False):
+    def decode(self, structure_tokens: torch.Tensor, return_plddt: bool = False, return_ptm: bool = False,
+               return_pae: bool = False):
         """structure_tokens (B, L) int64 including BOS / EOS -> backbone coordinates (B, L - 2, 3, 3) float32 (N, CA, C);
-        with return_plddt also the per-residue pLDDT (B, L - 2) in [0, 1] (None when the weights carry no plddt_head)."""
+        with return_plddt also the per-residue pLDDT (B, L - 2) in [0, 1] (None when the weights carry no plddt_head);
+        with return_ptm / return_pae also pTM (B,) and the predicted aligned error (B, L, L, BOS / EOS rows kept, as esm
+        returns it) — None when the weights carry no pairwise_classification_head.  Return order: coords[, plddt][, ptm][, pae]."""
         B, L = structure_tokens.shape
         tok = structure_tokens.to(device=self.device, dtype=torch.int64).contiguous()
         if int(tok.min()) < 0 or int(tok.max()) >= STRUCTURE_VOCAB:
             raise ValueError(f"structure token id out of range 0..{STRUCTURE_VOCAB - 1}")
         out = torch.empty(B, L, 3, 3, dtype=torch.float32, device=self.device)
         pl = torch.empty(B, L, dtype=torch.float32, device=self.device) if (return_plddt and self.has_plddt) else None
-        N.check(self._lib.esmdiff_decoder_decode(self._h, _ptr(tok), _ptr(out), _ptr(pl), B, L, float(self.cfg.trans_scale),
-                                                 _stream()), self._h)
+        want_pair = (return_ptm or return_pae) and self.has_ptm
+        ptm = torch.empty(B, dtype=torch.float32, device=self.device) if want_pair else None
+        pae = torch.empty(B, L, L, dtype=torch.float32, device=self.device) if (return_pae and self.has_ptm) else None
+        N.check(self._lib.esmdiff_decoder_decode(self._h, _ptr(tok), _ptr(out), _ptr(pl), _ptr(ptm), _ptr(pae), B, L,
+                                                 float(self.cfg.trans_scale), _stream()), self._h)
+        res = [out[:, 1:-1]]
         if return_plddt:
-            return out[:, 1:-1], (None if pl is None else pl[:, 1:-1])
-        return out[:, 1:-1]
+            res.append(None if pl is None else pl[:, 1:-1])
+        if return_ptm:
+            res.append(ptm)
+        if return_pae:
+            res.append(pae)
+        return res[0] if len(res) == 1 else tuple(res)
 
 
 class StructureEncoder:

@@ -99,11 +99,13 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
                                  sample_offset=sample_offset).cpu()
     if any(has_xyz):
         eng.set_frames(None)
-    coords = plddt = None
-    if decoder is not None:                        # esm: client.decode(tensor) -> ESMProtein with coordinates and pLDDT
+    coords = plddt = ptm = None
+    if decoder is not None:                        # esm: client.decode(tensor) -> ESMProtein with coordinates, pLDDT, pTM
         from .sample_esmdiff import decode_tokens
-        coords, plddt = decode_tokens(out_x[:, 1:-1], decoder)
+        coords, plddt, ptm = decode_tokens(out_x[:, 1:-1], decoder, return_ptm=True)
         coords, plddt = coords.cpu(), (None if plddt is None else plddt.cpu())
+        ptm = None if ptm is None else ptm.cpu()
     return [ESMProtein(sequence=p.sequence, coordinates=None if coords is None else coords[b],
-                       structure_tokens=out_x[b, 1:-1].clone(), plddt=None if plddt is None else plddt[b])
+                       structure_tokens=out_x[b, 1:-1].clone(), plddt=None if plddt is None else plddt[b],
+                       ptm=None if ptm is None else ptm[b])
             for b, p in enumerate(proteins)]

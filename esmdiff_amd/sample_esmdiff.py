@@ -65,24 +65,32 @@ def engine_capacity(lengths, per_rank: int, n_max_residue_square: int, mode: str
 
 
 @torch.no_grad()
-def decode_tokens(tokens: torch.Tensor, decoder, chunk: int = 0):
+def decode_tokens(tokens: torch.Tensor, decoder, chunk: int = 0, return_ptm: bool = False):
     """sample_esmdiff.py:40-61 without the file: structure tokens (n, L) WITHOUT BOS/EOS -> (coords (n, L, 3, 3) float32,
     plddt (n, L) float32 or None) on the decoder's device.  The reference decodes one sample per esm3.decode call; the
-    decoder engine takes them `chunk` (default: its max_batch) at a time."""
+    decoder engine takes them `chunk` (default: its max_batch) at a time.  return_ptm: a third value, pTM (n,) or None
+    (decoder_output["ptm"], /root/reference/slm/models/utils.py:73-76) when the decoder carries the pairwise head."""
     n, L_ = tokens.shape
     dev = decoder.device
     chunk = chunk or getattr(decoder, "max_batch", 64)
+    want_ptm = return_ptm and getattr(decoder, "has_ptm", False)
     if n == 0:
-        return torch.empty(0, L_, 3, 3, device=dev), (torch.empty(0, L_, device=dev) if decoder.has_plddt else None)
+        empty = (torch.empty(0, L_, 3, 3, device=dev), (torch.empty(0, L_, device=dev) if decoder.has_plddt else None))
+        return empty + ((torch.empty(0, device=dev) if want_ptm else None),) if return_ptm else empty
     t = tokens.to(dev, torch.int64)
     full = torch.cat([torch.full((n, 1), C.STRUCTURE_BOS_TOKEN, dtype=torch.int64, device=dev), t,
                       torch.full((n, 1), C.STRUCTURE_EOS_TOKEN, dtype=torch.int64, device=dev)], 1)
-    cs, ps = [], []
+    cs, ps, ts = [], [], []
     for i in range(0, n, chunk):
-        c, pl = decoder.decode(full[i:i + chunk], return_plddt=True)
+        if want_ptm:
+            c, pl, tm = decoder.decode(full[i:i + chunk], return_plddt=True, return_ptm=True)
+            ts.append(tm.clone())
+        else:
+            c, pl = decoder.decode(full[i:i + chunk], return_plddt=True)
         cs.append(c.clone())
         ps.append(None if pl is None else pl.clone())
-    return torch.cat(cs, 0), (None if ps[0] is None else torch.cat(ps, 0))
+    out = (torch.cat(cs, 0), (None if ps[0] is None else torch.cat(ps, 0)))
+    return out + ((torch.cat(ts, 0) if want_ptm else None),) if return_ptm else out
 
 
 def write_models_pdb(coords, plddt, sequence: str, save_to: Path, sample_basename: str):

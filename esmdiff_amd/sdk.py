@@ -38,6 +38,7 @@ class ESMProtein:
     coordinates: Optional[torch.Tensor] = None   # (L, 3 | 37, 3)
     structure_tokens: Optional[torch.Tensor] = None  # (L,) ids without BOS/EOS (this engine's output)
     plddt: Optional[torch.Tensor] = None
+    ptm: Optional[torch.Tensor] = None           # scalar, from the decoder's pairwise head (esm: ESMProtein.ptm)
 
     @classmethod
     def from_pdb(cls, path, chain_id: Optional[str] = None) -> "ESMProtein":

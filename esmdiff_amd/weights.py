@@ -79,7 +79,8 @@ def random_init_state_dict(cfg: ModelConfig, seed: int = 0, prefix: str = "net."
     return sd
 
 
-def random_init_decoder_state_dict(cfg, seed: int = 0, device: str = "cpu", with_plddt: bool = True) -> Dict[str, torch.Tensor]:
+def random_init_decoder_state_dict(cfg, seed: int = 0, device: str = "cpu", with_plddt: bool = True,
+                                   with_pairwise: bool = True) -> Dict[str, torch.Tensor]:
     """Random weights with the key layout of esm's StructureTokenDecoder: embed, decoder_stack.*,
     affine_output_projection.* — for tests and offline plumbing (the real esm3_structure_decoder_v0 cannot be fetched)."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -115,6 +116,12 @@ def random_init_decoder_state_dict(cfg, seed: int = 0, device: str = "cpu", with
         sd["plddt_head.0.weight"], sd["plddt_head.0.bias"] = linear(D, D, True)
         sd["plddt_head.2.weight"], sd["plddt_head.2.bias"] = 1.0 + 0.1 * randn(D), 0.05 * randn(D)
         sd["plddt_head.3.weight"], sd["plddt_head.3.bias"] = linear(50, D, True)
+    if with_pairwise:    # esm PairwisePredictionHead(d, 128, 128, 64 + 96 + 64, bias=False): the pTM / PAE head
+        p = "pairwise_classification_head."
+        sd[p + "downproject.weight"] = linear(128, D, False)[0]
+        sd[p + "linear1.weight"] = linear(128, 128, False)[0] * 4.0      # spread the PAE logits (a flat softmax tests nothing)
+        sd[p + "norm.weight"], sd[p + "norm.bias"] = 1.0 + 0.1 * randn(128), 0.05 * randn(128)
+        sd[p + "linear2.weight"] = linear(224, 128, False)[0] * 4.0
     return sd
 
 

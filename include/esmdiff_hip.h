@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESMDIFF_ABI_VERSION 2
+#define ESMDIFF_ABI_VERSION 3
 
 /* structure-track vocabulary: esm constants mirrored at model.py:380-381 */
 #define ESMDIFF_VOCAB 4101
@@ -221,11 +221,18 @@ int esmdiff_set_frames(esmdiff_engine* eng, const float* rot, const float* trans
  * esmdiff_decoder_decode: tokens int64 [B,L] INCLUDING BOS (4098) / EOS (4097); bb_coords f32 [B,L,3,3] = N, CA, C
  * per position (rows 0 and L-1 belong to BOS/EOS and are to be dropped); plddt f32 [B,L] or NULL = mean of the
  * categorical mixture over the 50 bins of [0,1] (what ESMProtein.to_pdb writes into the B-factor column,
- * sample_esmdiff.py:56-61); trans_scale = 10 in esm.  The pTM / PAE pairwise head is not built. */
+ * sample_esmdiff.py:56-61); trans_scale = 10 in esm.
+ * Optional: pairwise_classification_head.{downproject,linear1,linear2}.weight + .norm.{weight,bias} (esm's
+ * PairwisePredictionHead(d, 128, 128, 64 + 96 + 64 bins, bias=False)) enables `ptm` f32 [B] and `pae` f32 [B,L,L]
+ * (NULL to skip; pae needs ptm): decoder_output["ptm"] / ["predicted_aligned_error"] of the reference's decode path
+ * (/root/reference/slm/models/utils.py:64-76) — softmax over the 64 predicted-aligned-error bins (max bin 31 A) of every
+ * token pair, PAE = expected bin centre, pTM = max_i mean_j E[1 / (1 + (e / d0)^2)] over non-special tokens; pairs with
+ * BOS/EOS/special tokens carry the uniform-distribution value in `pae`, as esm leaves them.  Only the PAE slice of
+ * linear2 is evaluated (the distogram / direction slices are training targets). */
 int esmdiff_decoder_create(const esmdiff_config* cfg, const esmdiff_weight* table, int32_t n_weights,
                            int32_t device, esmdiff_engine** out);
-int esmdiff_decoder_decode(esmdiff_engine* dec, const int64_t* tokens, float* bb_coords, float* plddt, int32_t B,
-                           int32_t L, float trans_scale, void* stream);
+int esmdiff_decoder_decode(esmdiff_engine* dec, const int64_t* tokens, float* bb_coords, float* plddt, float* ptm,
+                           float* pae, int32_t B, int32_t L, float trans_scale, void* stream);
 
 /* VQ-VAE structure-token ENCODER: backbone frames -> structure tokens.  Replaces `model.encode(ESMProtein(coordinates))`
  * as protseq_to_data calls it for the DDPM inpainting prior (/root/reference/slm/models/utils.py:136-137,

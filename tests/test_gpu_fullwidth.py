@@ -207,6 +207,13 @@ def test_structure_decoder_production_width():
         err = (got - ref).norm(dim=-1)
         rec[f"B{B}_L{L}"] = {"mean_A": float(err.mean()), "max_A": float(err.max())}
         assert float(err.mean()) < 0.08 and float(err.max()) < 0.3, rec       # measured 0.038 / 0.107 A
+        with torch.no_grad():
+            ptm_ref, pae_ref = ref_net.confidence(tok)
+        _, ptm, pae = dec.decode(tok.cuda(), return_ptm=True, return_pae=True)
+        e_pae = (pae.cpu() - pae_ref).abs()
+        rec[f"B{B}_L{L}"].update(ptm_err=float((ptm.cpu() - ptm_ref).abs().max()), pae_max_A=float(e_pae.max()),
+                                 pae_mean_A=float(e_pae.mean()))
+        assert rec[f"B{B}_L{L}"]["ptm_err"] < 3e-3 and float(e_pae.max()) < 0.8 and float(e_pae.mean()) < 0.06, rec
     _record("decoder1280_3blocks", rec)
     dec.close()
 

@@ -481,6 +481,20 @@ def test_structure_decoder_vs_oracle(B, L):
     # translations are 10 x a head output computed from bf16 GEMM operands: a few hundredths of an Angstrom
     err = (got - ref).norm(dim=-1)
     assert float(err.mean()) < 0.08 and float(err.max()) < 0.6, (float(err.mean()), float(err.max()))
+    # pairwise confidence head: predicted aligned error and pTM (decoder_output["ptm"], models/utils.py:73-76)
+    tok2 = tok.clone()
+    tok2[0, 5] = 4096                                                      # a special token inside: its pairs are masked out
+    with torch.no_grad():
+        ptm_ref, pae_ref = ref_net.confidence(tok2)
+    _, ptm, pae = dec.decode(tok2.cuda(), return_ptm=True, return_pae=True)
+    ptm, pae = ptm.cpu(), pae.cpu()
+    assert ptm.shape == (B,) and pae.shape == (B, L, L)
+    assert float(pae_ref[:, 1:-1, 1:-1].std()) > 1.0                       # the fixture's PAE is not flat
+    assert float((pae[:, 0] - 16.0).abs().max()) < 1e-4 and float((pae[0, :, 5] - 16.0).abs().max()) < 1e-4   # masked: uniform
+    e_pae = (pae - pae_ref).abs()
+    assert float(e_pae.max()) < 0.6 and float(e_pae.mean()) < 0.05, (float(e_pae.max()), float(e_pae.mean()))
+    assert float((ptm - ptm_ref).abs().max()) < 3e-3, (ptm, ptm_ref)
+    assert 0 < float(ptm.min()) and float(ptm.max()) < 1
     with pytest.raises(RuntimeError, match="decoder"):
         dec._lib.esmdiff_forward_logits  # noqa: B018  (attribute exists)
         from esmdiff_amd import _native as Nn
@@ -851,6 +865,7 @@ def test_gibbs_iterative_sampling_raw_and_cli(tiny, tmp_path):
     o3 = iterative_sampling_raw(eng, prots, cfgs, seed=5, decoder=dec)
     assert all(torch.equal(a.structure_tokens, b.structure_tokens) for a, b in zip(o3, out))
     assert all(o.coordinates.shape == (58, 3, 3) and o.plddt.shape == (58,) for o in o3)
+    assert all(o.ptm is not None and 0.0 < float(o.ptm) < 1.0 for o in o3)          # ESMProtein.ptm, from the pairwise head
     o3[1].to_pdb(tmp_path / "one.pdb")
     back = ESMProtein.from_pdb(tmp_path / "one.pdb")
     assert back.sequence == seqs and float((back.coordinates - o3[1].coordinates).abs().max()) < 1e-3
