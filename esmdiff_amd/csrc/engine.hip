@@ -412,6 +412,8 @@ void esmdiff_engine_destroy(esmdiff_engine* e) {
   hipSetDevice(e->device);
   hipDeviceSynchronize();
   for (void* p : e->allocs) hipFree(p);
+  for (void* p : {(void*)e->pair_x, (void*)e->pair_h, (void*)e->pair_logits})  // the pairwise head's lazily sized workspace
+    if (p) hipFree(p);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   for (hipEvent_t ev : e->ev_join) hipEventDestroy(ev);
