@@ -117,6 +117,64 @@ def workload_name(args, world):
             + f", {world} GPU(s), " + base)
 
 
+class PowerSampler:
+    """Package power and shader clock of THIS rank's GPU from the amdgpu hwmon files, sampled every 50 ms by a thread
+    while the timed region runs (a report beside the number: this workload sits at the package power cap).
+    Silent when the files are not there."""
+
+    def __init__(self, device_index: int):
+        import glob
+        import threading
+        self.dir = None
+        self.samples = []
+        self._stop = threading.Event()
+        self._thread = None
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(d)).startswith(want):
+                    hw = glob.glob(os.path.join(d, "hwmon", "hwmon*"))
+                    if hw and os.path.exists(os.path.join(hw[0], "power1_input")):
+                        self.dir = hw[0]
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        with open(os.path.join(self.dir, name)) as fh:
+            return float(fh.read().strip())
+
+    def _loop(self):
+        while not self._stop.wait(0.05):
+            try:
+                self.samples.append((self._read("power1_input") * 1e-6, self._read("freq1_input") * 1e-6))
+            except Exception:
+                return
+
+    def start(self):
+        if self.dir is not None:
+            import threading
+            self._thread = threading.Thread(target=self._loop, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        if self._thread is None:
+            return None
+        self._stop.set()
+        self._thread.join()
+        if not self.samples:
+            return None
+        w = [a for a, _ in self.samples]
+        f = [b for _, b in self.samples]
+        try:
+            cap = self._read("power1_cap") * 1e-6
+        except Exception:
+            cap = None
+        return {"cap_w": cap, "mean_w": round(sum(w) / len(w), 1), "max_w": round(max(w), 1),
+                "mean_sclk_mhz": round(sum(f) / len(f), 1), "samples": len(w),
+                "source": "amdgpu hwmon power1_input / freq1_input every 50 ms over the timed region"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,11 +269,14 @@ def main():
     # HIP events on the launch stream around the dominant kernel only (96 per forward: <0.1 % overhead; bracketing
     # every launch costs 2.3 %), collected after the region
     eng.set_profiling(0 if args.no_profile else 2)
+    power = PowerSampler(local_rank)
+    power.start()
     t0 = time.perf_counter()
     for k in range(args.steps):
         ids = one_step(k)
     sync()
     t1 = time.perf_counter()
+    power_rec = power.stop()
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -291,6 +352,7 @@ def main():
             "sections_ms_per_forward": {k: round(v["ms"] / n_fwd, 3) for k, v in prof.items()},
             "sections_note": "per-launch HIP events of one extra untimed step; roofline.launch_ms is from the timed region",
             "device_ms_per_forward": round(tot_ms / n_fwd, 3),
+            "power": power_rec,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
