@@ -110,14 +110,17 @@ def write_models_pdb(coords, plddt, sequence: str, save_to: Path, sample_basenam
         merge_pdbfiles(saved, save_to, verbose=False)
 
 
-def decode_shard_and_gather(local_tokens: torch.Tensor, decoder, num_samples: int):
-    """Multi-GPU tail: EVERY rank decodes the samples it drew, then one all_gather of coordinates (+ pLDDT) — the
-    decode time stays 1/N of the ensemble instead of rank 0 decoding all N shards after the id gather."""
+def decode_shard_and_gather(local_tokens: torch.Tensor, decoder, num_samples: int, return_ptm: bool = False):
+    """Multi-GPU tail: EVERY rank decodes the samples it drew, then one all_gather of coordinates (+ pLDDT, + pTM with
+    return_ptm) — the decode time stays 1/N of the ensemble instead of rank 0 decoding all N shards after the id gather."""
     from .dist import gather_rows
-    coords, plddt = decode_tokens(local_tokens, decoder)
+    coords, plddt, ptm = decode_tokens(local_tokens, decoder, return_ptm=True)
     coords = gather_rows(coords.contiguous(), num_samples)
     plddt = None if plddt is None else gather_rows(plddt.contiguous(), num_samples)
-    return coords, plddt
+    if not return_ptm:
+        return coords, plddt
+    ptm = None if ptm is None else gather_rows(ptm.reshape(-1, 1).contiguous(), num_samples)[:, 0]
+    return coords, plddt, ptm
 
 
 @torch.no_grad()
@@ -186,16 +189,17 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     sample_t = time() - start_t
-    coords = plddt = None
+    coords = plddt = ptm = None
     if decoder is not None:                                   # every rank: decode the local shard, then one gather
-        coords, plddt = decode_shard_and_gather(local[:, 1:-1], decoder, num_samples)
+        coords, plddt, ptm = decode_shard_and_gather(local[:, 1:-1], decoder, num_samples, return_ptm=True)
     if rank == 0:
         print(f"Sampling token time: {sample_t:.2f}s")
         output_dir.mkdir(parents=True, exist_ok=True)
         np.save(save_to, tokens.cpu().numpy().astype(np.int16))
         (output_dir / f"{sample_basename}.json").write_text(json.dumps(
             {"sequence": sequence, "num_steps": num_steps, "num_samples": num_samples, "eps": eps, "seed": seed,
-             "noise": noise, "world_size": world, "sampling_seconds": round(sample_t, 3)}, indent=1))
+             "noise": noise, "world_size": world, "sampling_seconds": round(sample_t, 3),
+             **({} if ptm is None else {"ptm": [round(float(v), 4) for v in ptm.cpu()]})}, indent=1))
         if coords is not None:
             write_models_pdb(coords, plddt, sequence, output_dir / f"{sample_basename}.pdb", sample_basename)
         print(f"Total time: {time() - start_t:.2f}s")
@@ -259,10 +263,13 @@ def minibatch_gibbs_by_esm(protseq, esm3_model, output_dir: Path, sample_basenam
     out_tokens = [o.structure_tokens for o in out_list]
     local = (torch.stack(out_tokens) if out_tokens else torch.empty(0, len(protseq), dtype=torch.int64)).to(dev)
     tokens = gather_ids(local, num_samples)
-    coords = plddt = None
+    coords = plddt = ptm = None
     if decoder is not None:       # the proteins already carry the coordinates their rank decoded (iterative_sampling_raw)
         from .dist import gather_rows
         Lr = len(protseq)
+        if getattr(decoder, "has_ptm", False):
+            lt = torch.stack([torch.as_tensor(o.ptm) for o in out_list]).reshape(-1, 1) if out_list else torch.empty(0, 1)
+            ptm = gather_rows(lt.to(dev, torch.float32).contiguous(), num_samples)[:, 0]
         lc = torch.stack([torch.as_tensor(o.coordinates) for o in out_list]) if out_list else torch.empty(0, Lr, 3, 3)
         coords = gather_rows(lc.to(dev, torch.float32).contiguous(), num_samples)
         if decoder.has_plddt:
@@ -275,7 +282,8 @@ def minibatch_gibbs_by_esm(protseq, esm3_model, output_dir: Path, sample_basenam
         (output_dir / f"{sample_basename}.json").write_text(json.dumps(
             {"sequence": protseq, "mode": "gibbs", "num_steps": num_steps, "num_samples": num_samples,
              "temperature": temperature, "top_p": top_p, "seed": seed, "world_size": world,
-             "sampling_seconds": round(time() - start_t, 3)}, indent=1))
+             "sampling_seconds": round(time() - start_t, 3),
+             **({} if ptm is None else {"ptm": [round(float(v), 4) for v in ptm.cpu()]})}, indent=1))
         if coords is not None:
             write_models_pdb(coords, plddt, protseq, output_dir / f"{sample_basename}.pdb", sample_basename)
     return out_list

@@ -921,6 +921,14 @@ def test_cli_writes_multi_model_pdb_with_decoder(tmp_path):
     assert sum(l.startswith("ATOM") for l in text) == 4 * (30 * 3 + 29)     # N, CA, C + the inferred O (none on the last residue)
     ca = [l for l in text if l.startswith("ATOM") and l[12:16].strip() == "CA"]
     assert len(ca) == 120
+    import json
+    meta = json.loads((d / "synthetic30.json").read_text())             # pTM of every sample, from the decoder's pairwise head
+    assert len(meta["ptm"]) == 4 and all(0.0 < v < 1.0 for v in meta["ptm"])
+    # the default (gibbs) driver writes them too
+    main(["--random_init", "--tiny", "--random_init_decoder", "--synthetic_len", "30", "--num_samples", "3", "--num_steps", "4",
+          "--output", str(tmp_path), "--no_timestamp"])
+    meta = json.loads((tmp_path / "T1.4_step4_topp0.9_N3" / "synthetic30.json").read_text())
+    assert len(meta["ptm"]) == 3 and all(0.0 < v < 1.0 for v in meta["ptm"])
 
 
 def test_cli_gibbs_inpainting_from_pdb(tmp_path):
