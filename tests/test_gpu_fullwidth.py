@@ -218,6 +218,36 @@ def test_structure_decoder_production_width():
     dec.close()
 
 
+def test_structure_decoder_full_depth():
+    """The shipped decoder: d 1280 / 20 heads / ALL 30 blocks (esm3_structure_decoder_v0's shape, random weights) for one
+    batch — backbone, pLDDT, pTM and PAE against the f32 oracle, i.e. the error after the whole stack, not after 3 blocks."""
+    from esmdiff_amd.config import DecoderConfig
+    from esmdiff_amd.engine import StructureDecoder
+    from esmdiff_amd.weights import random_init_decoder_state_dict
+    from oracle.decoder_ref import build_decoder_from_state_dict
+    cfg = DecoderConfig()
+    assert (cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden) == (1280, 20, 30, 3584)
+    sd = random_init_decoder_state_dict(cfg, seed=6)
+    ref_net = build_decoder_from_state_dict(cfg, sd)
+    B, L = 2, 130
+    g = torch.Generator().manual_seed(9)
+    tok = torch.randint(0, 4096, (B, L), generator=g)
+    tok[:, 0], tok[:, -1] = 4098, 4097
+    with torch.no_grad():
+        ref, pl_ref = ref_net(tok, return_plddt=True)
+        ptm_ref, pae_ref = ref_net.confidence(tok)
+    dec = StructureDecoder(cfg, sd, max_batch=B, max_len=L)
+    got, pl, ptm, pae = dec.decode(tok.cuda(), return_plddt=True, return_ptm=True, return_pae=True)
+    err = (got.cpu() - ref).norm(dim=-1)
+    e_pae = (pae.cpu() - pae_ref).abs()
+    rec = {"mean_A": float(err.mean()), "max_A": float(err.max()), "plddt_err": float((pl.cpu() - pl_ref).abs().max()),
+           "ptm_err": float((ptm.cpu() - ptm_ref).abs().max()), "pae_max_A": float(e_pae.max()), "pae_mean_A": float(e_pae.mean())}
+    _record("decoder1280_30blocks_B2_L130", rec)
+    assert rec["mean_A"] < 0.15 and rec["max_A"] < 0.8, rec
+    assert rec["plddt_err"] < 1e-2 and rec["ptm_err"] < 5e-3 and rec["pae_mean_A"] < 0.12, rec
+    dec.close()
+
+
 @pytest.mark.parametrize("B,L", [(2, 60), (1, 258)])
 def test_structure_encoder_full_size_margin(B, L):
     """The encoder at its shipped size (d 1024, 2 blocks, v_heads 128, 4096 codes).  A nearest-code search after bf16
