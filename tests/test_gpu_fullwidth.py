@@ -180,6 +180,40 @@ def test_forward_full_depth_vs_oracle(full, B, L):
     _record(f"full48_B{B}_L{L}", out)
 
 
+def test_gibbs_first_step_full_depth(full):
+    """The default ("gibbs") mode on the 48-block instance: one forward without time conditioning, then the first
+    entropy-ordered unmasking step — engine logits -> gibbs.hip vs oracle logits -> C oracle with the same Philox noise.
+    Which positions get unmasked is a top-k over per-position entropies, so bf16 logit noise can swap near-ties at the
+    cut; the test reports how many of the chosen positions and ids coincide."""
+    from esmdiff_amd.gibbs import unmask_schedule
+    from oracle import c_oracle
+    cfg, eng, net, emb = full
+    B, L = 2, 258
+    g = torch.Generator().manual_seed(77)
+    seq = _seq(B, L, g)
+    x0 = torch.full((B, L), MASK, dtype=torch.int64)
+    x0[:, 0], x0[:, -1] = 4098, 4097
+    k0 = unmask_schedule(L - 2, 2)[0]                                 # 2 steps: 75 of the 256 positions in the first one
+    n_un = torch.full((B,), k0, dtype=torch.int32)
+    with torch.no_grad():
+        ref = net(structure_tokens=x0, sequence_tokens=seq).structure_logits
+    lg = eng.forward_logits(x0.cuda(), seq.cuda(), None)
+    s = _stats(lg.float().cpu(), ref)
+    got = eng.gibbs_step(x0.clone().cuda(), seq.cuda(), lg, 1.4, 0.9, n_un, seed=9).cpu().numpy()
+    own = c_oracle.gibbs_step(x0.numpy(), seq.numpy(), lg.float().cpu().numpy(), 1.4, 0.9, n_un.numpy(), seed=9, vocab=cfg.n_structure_heads)
+    assert np.array_equal(got, own)                                   # the kernel is bit-exact on its own logits at this width
+    want = c_oracle.gibbs_step(x0.numpy(), seq.numpy(), ref.numpy(), 1.4, 0.9, n_un.numpy(), seed=9, vocab=cfg.n_structure_heads)
+    ch_g, ch_w = got != x0.numpy(), want != x0.numpy()
+    assert ch_g.sum(1).tolist() == ch_w.sum(1).tolist() == [k0] * B
+    both = ch_g & ch_w
+    s["positions_chosen"] = int(ch_w.sum())
+    s["positions_agree"] = float(both.sum() / ch_w.sum())
+    s["ids_agree_on_common_positions"] = float((got == want)[both].mean()) if both.any() else 1.0
+    _record("full48_gibbs_first_step_B2_L258", s)
+    assert s["cos"] > 0.9999 and s["max_err"] < 0.04, s
+    assert s["positions_agree"] >= 0.7 and s["ids_agree_on_common_positions"] >= 0.9, s
+
+
 # ---------------------------------------------------------------------------------------------------
 # (c) decoder and encoder at the shipped widths
 def test_structure_decoder_production_width():
