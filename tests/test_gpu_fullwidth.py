@@ -119,6 +119,43 @@ def test_attention_production_heads(wide):
         assert float(per_head.max()) < 6e-2, per_head
 
 
+@pytest.mark.parametrize("B,L", [(2, 60), (2, 258)])
+def test_forward_with_coordinates_production_width(B, L):
+    """Coordinate conditioning as the inpainting path uses it (sample_esmdiff.py:88-96), at the shipped geometry: 256
+    vector heads (projection 3840 wide, 768-wide output), d 1536, 3 blocks — engine (esmdiff_set_frames + geom.hip) vs
+    oracle/geom_ref.py inside the whole network, partly masked (Inf) coordinates, NaN at BOS / EOS."""
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.geometry import build_affine3d_from_coordinates
+    from esmdiff_amd.weights import random_init_state_dict
+    from oracle.esm3_ref import build_from_state_dict
+    cfg = ModelConfig(n_layers=3)
+    assert cfg.v_heads == 256
+    sd = random_init_state_dict(cfg, seed=8, with_geom=True)
+    net, _ = build_from_state_dict(cfg, sd)
+    g = torch.Generator().manual_seed(L + 1)
+    ca = torch.cumsum(torch.randn(B, L, 3, generator=g) * 2.2, 1)
+    xyz = torch.stack([ca + torch.randn(B, L, 3, generator=g) * 0.8, ca, ca + torch.randn(B, L, 3, generator=g) * 0.8], 2)
+    xyz[:, 0], xyz[:, -1] = float("nan"), float("nan")
+    xyz[:, L // 3:L // 3 + 12] = float("inf")
+    seq = _seq(B, L, g)
+    x = torch.full((B, L), MASK, dtype=torch.int64)
+    x[:, 5:20] = torch.randint(0, 4096, (B, 15), generator=g)
+    with torch.no_grad():
+        ref = net(structure_tokens=x, sequence_tokens=seq, structure_coords=xyz).structure_logits
+        ref0 = net(structure_tokens=x, sequence_tokens=seq).structure_logits
+    eng = Engine(cfg, sd, max_batch=B, max_len=L)
+    eng.set_frames(*build_affine3d_from_coordinates(xyz))
+    got = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu()
+    eng.close()
+    s = _stats(got, ref)
+    s["conditioning_effect_max"] = float((ref - ref0).abs().max())
+    _record(f"wide3_coords_B{B}_L{L}", s)
+    assert s["conditioning_effect_max"] > 5e-2                           # the coordinates matter in the oracle itself
+    assert s["cos"] > 0.999 and s["max_err"] < 0.12 and s["mean_err"] < 1.2e-2, s
+    assert s["max_err"] < 0.5 * s["conditioning_effect_max"], s
+
+
 # ---------------------------------------------------------------------------------------------------
 # (b) the full model: 48 blocks
 @pytest.fixture(scope="module")
