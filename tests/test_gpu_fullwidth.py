@@ -98,6 +98,30 @@ def test_forward_production_width_vs_oracle(wide, B, L):
     assert s["argmax_agree"] > 0.9, s
 
 
+def test_forward_production_width_long_chain(wide):
+    """configs[3]'s length (1024 residues, L_tok = 1026: 17 key tiles, rotary table to position 1025) at d 1536 / 24 heads /
+    3 blocks against the f32 oracle."""
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    cfg, sd, _, net, emb = wide
+    B, L = 1, 1026
+    g = torch.Generator().manual_seed(L)
+    seq = _seq(B, L, g)
+    x = torch.full((B, L), MASK, dtype=torch.int64)
+    x[:, 100:400] = torch.randint(0, 4096, (B, 300), generator=g)
+    sch = ddpm_schedule(25)
+    i = 9
+    with torch.no_grad():
+        cond = torch.tile(emb(sch.sigma_t[i] * torch.ones(B))[:, None, :], (1, L, 1))
+        ref = net(structure_tokens=x, sequence_tokens=seq, auxiliary_embeddings=cond).structure_logits
+    eng = Engine(cfg, sd, max_batch=B, max_len=L)
+    got = eng.forward_logits(x.cuda(), seq.cuda(), sch.t_freq[i]).float().cpu()
+    eng.close()
+    s = _stats(got, ref)
+    _record(f"wide3_B{B}_L{L}", s)
+    assert s["cos"] > 0.999 and s["max_err"] < 0.12 and s["mean_err"] < 1.2e-2 and s["argmax_agree"] > 0.9, s
+
+
 def test_attention_production_heads(wide):
     """q/k LayerNorm over 1536 columns (three 512-column slabs) + rotary + 24-head attention vs f32 SDPA."""
     cfg, sd, eng, net, _ = wide
