@@ -1009,3 +1009,31 @@ def test_engine_error_behaviour(tiny):
     # the engine keeps working after errors
     out = eng.ddpm_sample(torch.tensor([[0, 5, 6, 7, 2]]).cuda(), ddpm_schedule(2), seed=0)
     assert out.shape == (1, 5) and int((out == MASK).sum()) == 0
+
+
+def test_bench_line_contract(tmp_path):
+    """bench.py's single JSON line as the driver reads it (small model, seconds): every field of the contract, the roofline
+    and cpu_baseline objects, and that nothing else is printed on stdout."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--tiny", "--steps", "2", "--warmup", "1",
+                        "--samples-per-gpu", "6", "--residues", "40"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["dtype"] == "bf16" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 6 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-2          # value = samples / time of the region
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and rf["peak"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and "traffic" in rf
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and isinstance(cb["sample"], str)
+    assert "power" in d                                                     # hwmon sample or null, never missing
