@@ -88,7 +88,7 @@ struct esmdiff_engine {
   std::vector<hipStream_t> side;
   std::vector<hipEvent_t> ev_join;
   hipEvent_t ev_fork = nullptr;
-  int64_t dual_min_tokens = 12288, dual_small_max_tokens = 6400;
+  int64_t dual_min_tokens = 12288, dual_small_max_tokens = int64_t(1) << 40;  // (r02: no single-stream window in between any more)
   int stream_offset_us = 0;  // phase offset of the second sub-batch stream (ESMDIFF_STREAM_OFFSET_US), see forward()
   int debug_skip = 0;  // ESMDIFF_DEBUG_SKIP bits (timing experiments only, results are wrong): 1 rope, 2 attention, 4 / 8 the two add+LN
   ed::GemmWorkspace gemm_ws[4] = {};  // split-K partials of the small-M GEMM path, one per launch queue
@@ -261,14 +261,13 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
 // persistent one-workgroup-per-CU kernel whose last round leaves CUs idle (N=1536: 606 tiles on 256 CUs = 2.37
 // rounds); with two independent launch queues the hardware scheduler fills those tails and the gaps around the
 // small LayerNorm / rotary / attention kernels with the other sub-batch's work (measured: -4.4 % per forward).
-// When: batches of >= 12 288 tokens (both halves still run the 256x256 GEMM) and small batches of <= 6 400 tokens
-// (768 .. 6 400: everything is on the 128-column-tile path either way and the kernels are latency-bound, so two queues
-// simply overlap them; r02, L_tok = 60, one stream / two: B = 16 89.1 / 99.1 samples/s, B = 8 70.5 / 70.3, B = 4
-// 44.5 / 41.8 — below ~700 tokens the halves' GEMMs each stream the whole weight matrix for half the rows and lose;
-// the 768-token start needs B >= 8: B = 3, L_tok = 258 cuts into 1 + 2 samples and loses, 18.7 / 17.5).
-// In between the halves would fall below the 128-tile switch of the GEMM dispatch and lose more than the overlap gives
-// (samples/s at L_tok = 258, one stream / two: B = 8 29.4 / 31.7, 16 36.9 / 39.7, 24 43.1 / 44.1, 32 45.8 / 45.8,
-// 40 49.7 / 46.8, 48 47.4 / 51.9, 64 49.2 / 52.2, 100 50.7 / 53.0).
+// When: from 1 024 tokens up (768 at B >= 8).  Below that the halves' GEMMs each stream the whole weight matrix for half the
+// rows and lose (r02, L_tok = 60, one stream / two: B = 4 44.5 / 41.8 samples/s, B = 8 70.5 / 70.3, B = 16 89.1 / 99.1;
+// B = 3 at L_tok = 258 cuts into 1 + 2 samples: 18.7 / 17.5).  r01 kept one stream between 6 400 and 12 288 tokens
+// because the halves' N = 1536 linears fell below the 128-tile switch onto the slower 128-column kernel; with the r02
+// dispatch rule (gemm.hip: 256x256 from 72 tiles at >= 12 row tiles) two streams win or tie there too — L_tok = 258, one
+// stream / two: B = 26 46.7 / 47.9, 28 45.9 / 47.2, 32 47.7 / 48.1, 36 51.2 / 52.3, 40 52.0 / 52.2, 44 46.8 / 52.1,
+// 48 47.8 / 53.1, 100 52.3 / 55.0.
 int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const float* t_freq_dev, float* logits,
             int ld, int B, int L, hipStream_t st) {
   const esmdiff_config& c = e->cfg;

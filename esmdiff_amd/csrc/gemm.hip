@@ -437,7 +437,15 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
     const char* e = getenv("ESMDIFF_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
-  if (N % 256 == 0 && (forced == 256 || (forced == 0 && ((M + 255) / 256) * (N / 256) >= 128)))
+  static const int min_tiles = [] {
+    const char* e = getenv("ESMDIFF_GEMM_256_MIN_TILES");
+    return e ? atoi(e) : 128;
+  }();
+  // (r02, inside the two-stream forward: the N = 1536 linears of a 2 817 .. 5 376-row sub-batch — 72 .. 126 tiles — also
+  // run better on the persistent 256x256 kernel, which leaves the other CUs to the other stream: B = 24 .. 40 at L_tok = 258
+  // +1 .. 3 %; at 7 - 8 row tiles (QKV of a 1 548-row sub-batch, 126 tiles) the 128-column kernel still wins, B = 12 -3 %)
+  const int t256m = (M + 255) / 256, t256 = t256m * (N / 256);
+  if (N % 256 == 0 && (forced == 256 || (forced == 0 && (t256 >= min_tiles || (t256 >= 72 && t256m >= 12)))))
     return launch_gemm256_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
   const int tiles_n = N / BN;
   // split-K factor, a function of (N, K) only: for K >= 2048 (FFN-down) the largest divisor of K/64 that is <= 8 and
