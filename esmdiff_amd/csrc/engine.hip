@@ -88,7 +88,7 @@ struct esmdiff_engine {
   std::vector<hipStream_t> side;
   std::vector<hipEvent_t> ev_join;
   hipEvent_t ev_fork = nullptr;
-  int64_t dual_min_tokens = 12288, dual_small_max_tokens = int64_t(1) << 40;  // (r02: no single-stream window in between any more)
+  int64_t dual_min_tokens = 2200, dual_small_max_tokens = 1024;  // two streams from / small window up to (tokens), see forward()
   int stream_offset_us = 0;  // phase offset of the second sub-batch stream (ESMDIFF_STREAM_OFFSET_US), see forward()
   int debug_skip = 0;  // ESMDIFF_DEBUG_SKIP bits (timing experiments only, results are wrong): 1 rope, 2 attention, 4 / 8 the two add+LN
   ed::GemmWorkspace gemm_ws[4] = {};  // split-K partials of the small-M GEMM path, one per launch queue
@@ -261,13 +261,18 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
 // persistent one-workgroup-per-CU kernel whose last round leaves CUs idle (N=1536: 606 tiles on 256 CUs = 2.37
 // rounds); with two independent launch queues the hardware scheduler fills those tails and the gaps around the
 // small LayerNorm / rotary / attention kernels with the other sub-batch's work (measured: -4.4 % per forward).
-// When: from 1 024 tokens up (768 at B >= 8).  Below that the halves' GEMMs each stream the whole weight matrix for half the
-// rows and lose (r02, L_tok = 60, one stream / two: B = 4 44.5 / 41.8 samples/s, B = 8 70.5 / 70.3, B = 16 89.1 / 99.1;
-// B = 3 at L_tok = 258 cuts into 1 + 2 samples: 18.7 / 17.5).  r01 kept one stream between 6 400 and 12 288 tokens
-// because the halves' N = 1536 linears fell below the 128-tile switch onto the slower 128-column kernel; with the r02
-// dispatch rule (gemm.hip: 256x256 from 72 tiles at >= 12 row tiles) two streams win or tie there too — L_tok = 258, one
-// stream / two: B = 26 46.7 / 47.9, 28 45.9 / 47.2, 32 47.7 / 48.1, 36 51.2 / 52.3, 40 52.0 / 52.2, 44 46.8 / 52.1,
-// 48 47.8 / 53.1, 100 52.3 / 55.0.
+// When (r02, re-measured over B at L_tok = 60 / 128 / 258, ms per batch one stream / two):
+//   * from 2 200 tokens up.  r01 kept one stream between 6 400 and 12 288 tokens because the halves' N = 1536 linears fell
+//     below the 128-tile switch onto the slower 128-column kernel; with the r02 dispatch rule (gemm.hip: 256x256 from 72
+//     tiles at >= 12 row tiles) two streams win or tie there too — L_tok = 258, samples/s: B = 26 46.7 / 47.9, 28 45.9 /
+//     47.2, 32 47.7 / 48.1, 36 51.2 / 52.3, 40 52.0 / 52.2, 44 46.8 / 52.1, 48 47.8 / 53.1, 100 52.3 / 55.0;
+//   * NOT between ~1 100 and 2 200 tokens: the halves would drop onto the small-batch path (< 1 152 rows), which per row
+//     is slower than the regular path is at 1 200 - 2 000 rows — L_tok = 60: B = 24 202 / 226 ms, 32 230 / 266, 40 276 / 266;
+//     L_tok = 128: B = 12 211 / 237, 16 241 / 262, 20 289 / 276; L_tok = 258: B = 5 205 / 227, 6 216 / 243, 7 238 / 255,
+//     8 278 / 271;
+//   * 768 .. 1 024 tokens at B >= 8: everything is small either way and two queues overlap the launch floors — L_tok = 60
+//     B = 16 185 / 167 ms, L_tok = 128 B = 8 188 / 176; below ~700 tokens the halves' GEMMs each stream the whole weight
+//     matrix for half the rows and lose (B = 4 at L_tok = 60: 87.0 / 95.8 ms), and B = 3 at L_tok = 258 cuts into 1 + 2.
 int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const float* t_freq_dev, float* logits,
             int ld, int B, int L, hipStream_t st) {
   const esmdiff_config& c = e->cfg;
@@ -295,7 +300,7 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   int np = 1;
   const int64_t tokens = (int64_t)B * L;
   if (!e->side.empty() && e->profiling != 1 && B >= 2 &&
-      (tokens >= e->dual_min_tokens || (tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(B >= 8 ? 768 : 1024, e->dual_min_tokens))))
+      (tokens >= e->dual_min_tokens || (B >= 8 && tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(768, e->dual_min_tokens))))
     np = std::min<int>({(int)e->side.size() + 1, B, 4});
   for (int pi = 0; pi < np; ++pi) {
     const int b0 = (int)((int64_t)B * pi / np), b1 = (int)((int64_t)B * (pi + 1) / np);
@@ -334,13 +339,13 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
     return fail(e, ESMDIFF_E_INVALID, "frames were set for B=%d L=%d, forward called with B=%d L=%d", e->frames_B, e->frames_L, B, L);
   const int VH = e->v_heads;
   bool pending = false;
-  // Small batches (a sub-batch of < 1024 rows): the two branch linears leave their products as raw f32 K-slice planes
+  // Small batches (a sub-batch of < 1 152 rows, ed::small_max_rows()): the two branch linears leave their products as raw f32 K-slice planes
   // (gemm.hip: launch_gemm_partials) and the LayerNorm that follows sums the planes into x — x += dF before the
   // attention-side LayerNorm, x += dA before the FFN-side one: the same two additions in the same order — so neither a
   // split-K reduce pass nor a bf16 delta round trip runs.  Sub-batches of one forward are all on the same side of the
   // switch or results would depend on how the batch was cut; parts differ by at most one sample, so test part 0's rows.
-  const bool small = e->small_fused && parts[0].gws && parts[0].gws2 && (int64_t)parts[np - 1].B * L < 1024 &&
-                     (int64_t)parts[0].B * L < 1024;
+  const bool small = e->small_fused && parts[0].gws && parts[0].gws2 && (int64_t)parts[np - 1].B * L < ed::small_max_rows() &&
+                     (int64_t)parts[0].B * L < ed::small_max_rows();
   ed::GemmPartials PF[4] = {}, PA[4] = {};
   for (int i = 0; i < c.n_layers; ++i) {
     const Layer& ly = e->layers[i];
@@ -646,10 +651,10 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(dalloc(e, &e->g_entropy, Mx));
     TRY(dalloc(e, &e->g_sampled, Mx));
     TRY(dalloc(e, &e->g_nunmask, (size_t)e->tfreq_rows * cfg->max_batch));
-    {  // split-K workspaces: S * N <= 12288 for every shape the launcher splits; rows up to the 1024-row switch
+    {  // split-K workspaces: S * N <= 12288 for every shape the launcher splits; rows up to the small-batch switch
       const char* sk = getenv("ESMDIFF_GEMM_SPLITK");
       if (!(sk && sk[0] == '0')) {
-        const size_t rows = (size_t)round_up((int)std::min<size_t>(Mx, 1024), 128);
+        const size_t rows = (size_t)round_up((int)std::min<size_t>(Mx, ed::small_max_rows()), 128);
         for (int q = 0; q < 4; ++q) {
           e->gemm_ws[q].partial_floats = rows * 12288;
           TRY(dalloc(e, &e->gemm_ws[q].partial, e->gemm_ws[q].partial_floats));

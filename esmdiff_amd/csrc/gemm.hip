@@ -22,7 +22,7 @@
 // run of tiles) and rasterised in 8x8 super-tiles so the 64 tiles resident on an XCD share 8 A panels
 // and 8 W panels in that XCD's L2.
 //
-// Small M (< 1024 rows: a handful of short sequences).  There are then only tiles_n..8*tiles_n tiles, so most CUs
+// Small M (< 1 152 rows, small_max_rows(): a handful of short sequences).  There are then only tiles_n..8*tiles_n tiles, so most CUs
 // idle while a few stream whole weight matrices, and with two stages each workgroup waits one full HBM latency per
 // K-tile (M = 240, N = 1536, K = 4096: 24 workgroups, 63 us for 12.6 MB).  Two changes on this path:
 //   NST = 4  four LDS stages (128 KiB, one workgroup per CU), three K-tiles in flight, counted vmcnt waits;
@@ -454,7 +454,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
   // the f32 partials (S x M x N x 4 B, written and re-read) outweigh the shorter K loop — so they are not split.
   int S = 1;
   const int64_t pstride = (int64_t)((M + 127) / 128) * 128 * N;
-  if (M < 1024 && ws && ws->partial && K >= 2048) {
+  if (M < small_max_rows() && ws && ws->partial && K >= 2048) {
     const int nk = K / BK;
     for (int c = 8; c >= 2; --c)
       if (nk % c == 0 && tiles_n * c <= 96) {
@@ -463,13 +463,13 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
       }
     if ((size_t)S * pstride > ws->partial_floats) S = 1;
   }
-  const int mi = M < 1024 ? small_tile_mi(M, N, S) : 2;
+  const int mi = M < small_max_rows() ? small_tile_mi(M, N, S) : 2;
   return launch_tiles(A, W, out, bias, M, N, K, ldc, n_valid, alpha, epilogue, stream, mi, S,
                       S > 1 ? ws->partial : nullptr, pstride, false);
 }
 
 // ---- residual-branch linears of the small-batch path ------------------------------------------------------------
-// Below 1024 rows the out-projection and FFN-down products are left as S raw f32 K-slice planes; the add+LayerNorm
+// Below small_max_rows() (1 152) rows the out-projection and FFN-down products are left as S raw f32 K-slice planes; the add+LayerNorm
 // kernel that consumes them (norm.hip: launch_add_partials_layernorm_bf16) sums the planes in the order s = 0..S-1,
 // scales and adds them to the residual stream — so no reduce kernel runs and the K = 1536 out-projection can be sliced
 // as well (with a separate reduce pass its slices did not pay, see above).  S is a function of (N, K) only: the
@@ -489,7 +489,7 @@ int gemm_partial_splits(int N, int K) {
 
 hipError_t launch_gemm_partials(const bf16_t* A, const bf16_t* W, const GemmWorkspace* ws, int M, int N, int K,
                                 hipStream_t stream, GemmPartials* res) {
-  if (M <= 0 || M >= 1024 || !ws || !ws->partial || !res || N % BN != 0 || K % BK != 0) return hipErrorInvalidValue;
+  if (M <= 0 || M >= small_max_rows() || !ws || !ws->partial || !res || N % BN != 0 || K % BK != 0) return hipErrorInvalidValue;
   const int S = gemm_partial_splits(N, K);
   const int64_t pstride = (int64_t)((M + 127) / 128) * 128 * N;
   if ((size_t)S * pstride > ws->partial_floats) return hipErrorInvalidValue;

@@ -1,6 +1,7 @@
 // kernels.h — internal launch functions of libesmdiff_hip.so (gfx950 only).
 // Every function enqueues on `stream` and returns the hipError_t of the launch.
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -35,7 +36,17 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
                             int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream,
                             const GemmWorkspace* ws = nullptr);
 
-// Small-batch path (M < 1024): the product as S raw f32 K-slice planes in `ws` (plane stride `stride` floats, row stride
+// Row count below which a (sub-)batch takes the small-batch path.  ESMDIFF_SMALL_MAX_ROWS overrides (A/B runs).
+inline int small_max_rows() {
+  static const int v = [] {
+    const char* e = getenv("ESMDIFF_SMALL_MAX_ROWS");
+    const int x = e ? atoi(e) : 1152;  // r02: 1 024 -> 1 152 (+4 % at 1 032 - 1 080 rows; 2 048 loses 5 - 20 % from 1 440 rows)
+    return x < 128 ? 128 : (x > 8192 ? 8192 : x);
+  }();
+  return v;
+}
+
+// Small-batch path (M < small_max_rows()): the product as S raw f32 K-slice planes in `ws` (plane stride `stride` floats, row stride
 // N), consumed by launch_add_partials_layernorm_bf16.  S = gemm_partial_splits(N, K), a function of the shape only.
 struct GemmPartials {
   const float* p;

@@ -168,7 +168,7 @@ typedef enum {
 int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N,
                       int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream);
 
-/* The same GEMM as the engine issues it: with the engine's split-K workspace, so the small-M path (M < 1024 rows,
+/* The same GEMM as the engine issues it: with the engine's split-K workspace, so the small-M path (M < 1152 rows,
  * K >= 2048: FFN-down) runs as K slices + a fixed-order reduce kernel (csrc/gemm.hip).  Not re-entrant per engine. */
 int esmdiff_gemm_bf16_ws(esmdiff_engine* eng, const void* A, const void* W, void* out, const float* bias, int32_t M,
                          int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue,
@@ -180,7 +180,7 @@ int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float
                             int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha,
                             int32_t epilogue, int32_t iters, float* ms_out, void* stream);
 
-/* The small-batch form of a residual branch (M < 1024 rows; csrc/engine.hip::forward): the branch linear A[M,K] W[N,K]^T
+/* The small-batch form of a residual branch (M < 1152 rows; csrc/engine.hip::forward): the branch linear A[M,K] W[N,K]^T
  * is left as S raw f32 K-slice planes in the engine's workspace (S = *splits_out, a function of N and K only) and the
  * LayerNorm kernel that follows sums them:  x[M,N] f32 += alpha * (A W^T);  y bf16 [M,N] = LayerNorm(x) * w (+ b).
  * N = d_model of the engine's shapes (N % 128 == 0, N <= 2048), K % 64 == 0.  Not re-entrant per engine. */
