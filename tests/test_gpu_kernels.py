@@ -373,8 +373,10 @@ def test_attention_long_chain():
 
 # ---------------------------------------------------------------------------------------------------
 # whole forward + sampling loop
-@pytest.mark.parametrize("B,L", [(2, 60), (3, 258)])
+@pytest.mark.parametrize("B,L", [(2, 60), (3, 258), (8, 110), (8, 290), (5, 258)])
 def test_forward_logits_vs_oracle(tiny, B, L):
+    # (8,110): 880 tokens, two streams of small-batch halves; (8,290): 2320 tokens, two streams on the regular path;
+    # (5,258): 1290 tokens, one stream on the regular path — the engine's stream / path switches (engine.hip::forward)
     from esmdiff_amd.schedule import ddpm_schedule
     cfg, sd, eng, net, emb = tiny
     g = torch.Generator().manual_seed(L)
