@@ -29,11 +29,25 @@ def cosine_schedule(t: float) -> float:
     return math.cos(t * math.pi / 2)
 
 
-def unmask_schedule(total_to_sample: int, num_steps: int) -> List[int]:
+# fraction of the positions still masked after a step at progress t in (0, 1]: esm.utils.noise_schedules
+# NOISE_SCHEDULE_REGISTRY [ESM-RECALL]; the reference only ever uses the default, "cosine" (sample_esmdiff.py:116-119)
+NOISE_SCHEDULES = {
+    "cosine": cosine_schedule,
+    "linear": lambda t: 1.0 - t,
+    "square_root_schedule": lambda t: 1.0 - math.sqrt(t),
+    "cubic": lambda t: 1.0 - t ** 3,
+    "square": lambda t: 1.0 - t ** 2,
+}
+
+
+def unmask_schedule(total_to_sample: int, num_steps: int, schedule: str = "cosine") -> List[int]:
+    if schedule not in NOISE_SCHEDULES:
+        raise ValueError(f"unknown schedule {schedule!r}; one of {sorted(NOISE_SCHEDULES)}")
+    fn = NOISE_SCHEDULES[schedule]
     T = min(num_steps, total_to_sample)
     out, still = [], total_to_sample
     for t in range(T):
-        after = int(cosine_schedule((t + 1) / T) * total_to_sample + 0.1)
+        after = int(fn((t + 1) / T) * total_to_sample + 0.1)
         k = max(still - after, 0)
         out.append(k)
         still -= k
@@ -64,8 +78,12 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
     for c in configs:
         if c.track != "structure":
             raise NotImplementedError("only the structure track is sampled by this engine")
-        if (c.num_steps, c.temperature, c.top_p) != (cfg0.num_steps, cfg0.temperature, cfg0.top_p):
-            raise NotImplementedError("one batch shares num_steps / temperature / top_p (the reference passes copies)")
+        if (c.num_steps, c.temperature, c.top_p, c.schedule) != (cfg0.num_steps, cfg0.temperature, cfg0.top_p, cfg0.schedule):
+            raise NotImplementedError("one batch shares num_steps / temperature / top_p / schedule (the reference passes copies)")
+        if c.strategy != "entropy":     # esm also has "random" (positions drawn uniformly); the device kernel orders by entropy
+            raise NotImplementedError(f"strategy {c.strategy!r}: only the default entropy-ordered unmasking is built")
+        if c.invalid_ids:
+            raise NotImplementedError("invalid_ids: the engine masks the structure track's special ids itself; extra ids are not built")
     seqs = [encode_sequence(p.sequence) for p in proteins]
     L = seqs[0].numel()
     if any(s.numel() != L for s in seqs):
@@ -93,7 +111,7 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
     else:
         table = torch.zeros(T, len(proteins), dtype=torch.int32)
         for b, tot in enumerate(totals):
-            sch = unmask_schedule(tot, cfg0.num_steps)
+            sch = unmask_schedule(tot, cfg0.num_steps, cfg0.schedule)
             table[: len(sch), b] = torch.tensor(sch, dtype=torch.int32)
         out_x = eng.gibbs_sample(seq, x0, table, cfg0.temperature, cfg0.top_p, seed=seed,
                                  sample_offset=sample_offset).cpu()

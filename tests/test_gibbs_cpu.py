@@ -27,6 +27,15 @@ def test_schedule_cosine_unmasking():
         assert s == unmask_schedule(total, steps)
         assert len(s) == min(steps, total) and sum(s) == total and all(k >= 0 for k in s)
     assert G.unmask_schedule(256, 4) == [20, 55, 83, 98]   # 256 - int(cos(pi/8)*256 + .1) = 20, ...
+    # the other registered schedules: every position unmasked exactly once, linear in equal shares
+    from esmdiff_amd.gibbs import NOISE_SCHEDULES
+    assert unmask_schedule(256, 4, "linear") == [64, 64, 64, 64]
+    for name in NOISE_SCHEDULES:
+        for total, steps in ((256, 16), (64, 50), (7, 3)):
+            s = unmask_schedule(total, steps, name)
+            assert len(s) == min(steps, total) and sum(s) == total and all(k >= 0 for k in s), (name, s)
+    with pytest.raises(ValueError, match="unknown schedule"):
+        unmask_schedule(10, 3, "sigmoid")
 
 
 @pytest.mark.parametrize("vocab", [4096, 4101])
@@ -87,3 +96,16 @@ def test_philox_step_is_shard_independent():
     part = c_oracle.gibbs_step(x[2:].numpy(), seq[2:].numpy(), logits[2:].numpy(), 1.4, 0.9, n_un[2:], seed=3,
                                sample_offset=12, step=1)
     assert np.array_equal(full[2:], part)
+
+
+def test_generation_config_options_are_honoured_or_refused():
+    """GenerationConfig fields the reference leaves at their defaults (sample_esmdiff.py:116-119) are never silently
+    ignored: the schedule is used, an unsupported strategy / invalid_ids / track is refused before any device work."""
+    from esmdiff_amd.gibbs import iterative_sampling_raw
+    from esmdiff_amd.sdk import ESMProtein, GenerationConfig
+    prot = [ESMProtein(sequence="RPDFCLE")]
+    for bad in (GenerationConfig(strategy="random"), GenerationConfig(invalid_ids=[5]), GenerationConfig(track="sequence")):
+        with pytest.raises(NotImplementedError):
+            iterative_sampling_raw(object(), prot, [bad])
+    with pytest.raises(ValueError, match="unknown schedule"):
+        iterative_sampling_raw(type("E", (), {"has_geom": False})(), prot, [GenerationConfig(schedule="sigmoid", num_steps=3)])
