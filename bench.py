@@ -7,7 +7,8 @@ the ESM3-open-sized (1.4 B parameter, random-init, bf16 MFMA) structure-token tr
 sampler launches (BASELINE.json configs[1]; reference loop: slm/models/model.py:543-581 driven by
 slm/sample_esmdiff.py:137-233).  Inputs (tokens, weights) are resident in HBM when the timed region starts.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]        (N > 1 without a launcher: re-executes itself under
+                                                            torch.distributed.run, one rank per GPU, still ONE JSON line)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  Extra objects:
@@ -175,6 +176,93 @@ class PowerSampler:
                 "source": "amdgpu hwmon power1_input / freq1_input every 50 ms over the timed region"}
 
 
+def roofline_report(args, cfg, B, L, n_fwd_sample, prof_dom, prof):
+    """The dominant kernel (FFN-up GEMM [M,1536] x [8192,1536]^T, SwiGLU epilogue) against the bf16 MFMA peak.
+
+    The engine runs a large batch as sub-batches on separate HIP streams, so an FFN-up launch covers M / streams rows and
+    shares the GPU with the other stream's kernels.  Three figures, all from HIP events on the launch streams:
+      roofline.achieved / frac   TIMED REGION, device level: FFN-up FLOP of ALL streams / the UNION of the launches' busy
+                                 intervals on the device timeline (no instant counted twice; still includes whatever
+                                 else the other stream ran beside it)
+      roofline.per_launch        TIMED REGION, the contract's figure: algorithmic FLOP of one launch / mean launch duration
+                                 (what rocprofv3 --kernel-trace --stats reports as the kernel's average; overlapped time)
+      roofline.exclusive         the same kernel ALONE on the GPU at the full M (single-stream breakdown pass, untimed)"""
+    M = B * L
+    timed = prof_dom["gemm_ffn_up"]["launches"] > 0
+    up = prof_dom["gemm_ffn_up"] if timed else prof["gemm_ffn_up"]
+    expect = (args.steps if timed else 1) * n_fwd_sample * cfg.n_layers
+    parts = max(1, round(up["launches"] / expect))
+    flop_up_full = 2.0 * M * cfg.d_model * 2 * cfg.ffn_hidden
+    flop_up = flop_up_full / parts
+    ms_up = up["ms"] / max(up["launches"], 1)
+    ach_launch = flop_up / (ms_up * 1e-3) / 1e12 if ms_up > 0 else 0.0
+    un = prof_dom.get("gemm_ffn_up_union", {"ms": 0.0, "launches": 0})
+    if timed and un["launches"] == up["launches"] and un["ms"] > 0:
+        union_ms = un["ms"]
+    else:                                                       # no timed events (--no-profile): single-stream sections
+        union_ms = up["ms"]
+    ach = flop_up * up["launches"] / (union_ms * 1e-3) / 1e12 if union_ms > 0 else 0.0
+    ex = prof["gemm_ffn_up"]
+    ms_ex = ex["ms"] / max(ex["launches"], 1)
+    ach_ex = flop_up_full / (ms_ex * 1e-3) / 1e12 if ms_ex > 0 else 0.0
+    sections = {k: v for k, v in prof.items() if k != "gemm_ffn_up_union"}
+    gemm_ms = sum(sections[s]["ms"] for s in ("gemm_qkv", "gemm_out", "gemm_ffn_up", "gemm_ffn_down", "head"))
+    tot_ms = sum(v["ms"] for v in sections.values())
+    lin_flop_fwd = M * (cfg.n_layers * (2 * cfg.d_model * (3 * cfg.d_model + cfg.d_model + 2 * cfg.ffn_hidden)
+                                        + 2 * cfg.ffn_hidden * cfg.d_model)
+                        + 2 * cfg.d_model * cfg.d_model + 2 * cfg.d_model * cfg.n_structure_heads)
+    n_fwd = n_fwd_sample                                        # the breakdown pass is one step
+    traffic, traffic_note = None, "no PMC pass on record"
+    for name in ("r03_gemm_traffic.json", "r02_gemm_traffic.json"):
+        tp = ROOT / "profiles" / name
+        if tp.exists() and not args.tiny:                       # separate rocprofv3 --pmc passes of this same kernel at this M
+            rec = json.loads(tp.read_text()).get("by_rows", {}).get(str(M // parts))
+            if rec:
+                traffic = rec["traffic_bytes_per_launch"]
+                traffic_note = f"profiles/{name}: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, fabric-level" + (
+                    "; " + rec["note"] if "note" in rec else "")
+                break
+    return {
+        "roofline": {"bound": "mfma", "kernel": "g4::gemm256w4_kernel<SWIGLU> (FFN-up, M=%d N=%d K=%d)" % (M // parts, 2 * cfg.ffn_hidden, cfg.d_model),
+                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                     "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
+                     "what": ("timed region, device level: FFN-up FLOP of all %d stream(s) / union of the launches' busy intervals "
+                              "(HIP events on the launch streams)" % parts),
+                     "algorithmic_flop_per_launch": flop_up, "launches": up["launches"], "streams": parts,
+                     "union_busy_ms": round(union_ms, 3),
+                     "per_launch": {"what": "timed region: algorithmic FLOP of one launch / mean launch duration (the figure rocprofv3 "
+                                            "--kernel-trace --stats shows as the kernel's average; the launch shares the GPU with the other "
+                                            "stream's kernels)" if parts > 1 else "timed region, single stream",
+                                    "launch_ms": round(ms_up, 4), "achieved": round(ach_launch, 1),
+                                    "frac": round(ach_launch / PEAK_BF16_TFLOPS, 4)},
+                     "exclusive": {"what": "same kernel alone on the GPU at M=%d (single-stream breakdown pass, HIP events)" % M,
+                                   "launch_ms": round(ms_ex, 4), "achieved": round(ach_ex, 1),
+                                   "frac": round(ach_ex / PEAK_BF16_TFLOPS, 4)},
+                     "all_gemm_tflops": round(lin_flop_fwd * n_fwd / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms else None},
+        "sections_ms_per_forward": {k: round(v["ms"] / n_fwd, 3) for k, v in sections.items()},
+        "sections_note": "per-launch HIP events of one extra untimed single-stream step; roofline.* is from the timed region",
+        "device_ms_per_forward": round(tot_ms / n_fwd, 3),
+    }
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run this same command line under torch.distributed.run, one rank per
+    GPU of this node (rendezvous on 127.0.0.1, a free port), and hand its exit code back.  Rank 0 of the child prints the ONE
+    JSON line on the inherited stdout; the launcher's own chatter goes to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,33 +281,51 @@ def main():
     ap.add_argument("--inpaint", type=str, default=None, metavar="A:B",
                     help="BASELINE configs[4]: residues A..B-1 start as MASK, all others carry fixed (synthetic) structure "
                          "tokens through input_prior (sample_esmdiff.py:196-209); use with --num-steps 50")
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="CI only: a CPU stand-in engine (tests/standin_engine.py) over the gloo backend — exercises the launch, "
+                         "process-group, gather and reporting path of this script without a GPU; prints data=debug-stub-engine")
     args = ap.parse_args()
 
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
+    if args.gpus > 1 and not launched:
+        raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): pass --nproc-per-node {args.gpus}")
     import torch.distributed as dist
-    use_dist = "RANK" in os.environ and "MASTER_PORT" in os.environ   # launched by torch.distributed.run
+    use_dist = launched
+    stub = args.stub_engine
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from esmdiff_amd.config import ESM3_OPEN, TINY
-    from esmdiff_amd.engine import Engine
     from esmdiff_amd.schedule import ddpm_schedule
     from esmdiff_amd.weights import random_init_state_dict
 
     cfg = TINY if args.tiny else ESM3_OPEN
     B, L, T = args.samples_per_gpu, args.residues + 2, args.num_steps
-    sd = random_init_state_dict(cfg, seed=args.seed, device=str(dev), with_geom=True)   # same weights on every rank (GPU generator)
-    eng = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank)
+    if stub:
+        from tests.standin_engine import StandinEngine
+        sd = {}
+        eng = StandinEngine(cfg, max_batch=B, max_len=L)
+    else:
+        from esmdiff_amd.engine import Engine
+        sd = random_init_state_dict(cfg, seed=args.seed, device=str(dev), with_geom=True)   # same weights on every rank (GPU generator)
+        eng = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank)
     g = torch.Generator().manual_seed(args.seed)
     seq1 = torch.cat([torch.tensor([0]), torch.randint(4, 24, (args.residues,), generator=g), torch.tensor([2])])
     seq = seq1[None].repeat(B, 1).to(dev)
@@ -258,10 +364,12 @@ def main():
         return ids
 
     def sync():
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
+        if not stub:
             torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier() if stub else dist.barrier(device_ids=[local_rank])
+            if not stub:
+                torch.cuda.synchronize(dev)
 
     for w in range(args.warmup):
         one_step(1000 + w)
@@ -269,7 +377,7 @@ def main():
     # HIP events on the launch stream around the dominant kernel only (96 per forward: <0.1 % overhead; bracketing
     # every launch costs 2.3 %), collected after the region
     eng.set_profiling(0 if args.no_profile else 2)
-    power = PowerSampler(local_rank)
+    power = PowerSampler(-1 if stub else local_rank)
     power.start()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -284,7 +392,8 @@ def main():
     prof_dom = eng.get_profile()
     eng.set_profiling(1)                                         # one extra, UNTIMED pass for the per-section breakdown
     one_step(2000)
-    torch.cuda.synchronize(dev)
+    sync_local = (lambda: None) if stub else (lambda: torch.cuda.synchronize(dev))
+    sync_local()
     prof = eng.get_profile()
     eng.set_profiling(0)
     assert int((ids == 4096).sum()) == 0
@@ -294,42 +403,13 @@ def main():
         value = total_samples / elapsed
         n_fwd_sample = T + 1 if args.mode == "ddpm" else int(table.shape[0])
         f_sample = flops_forward_per_sample(L, cfg) * n_fwd_sample
-        # dominant kernel: FFN-up GEMM  [M,1536] x [8192,1536]^T with the SwiGLU epilogue
-        M = B * L
-        # The engine runs a large batch as sub-batches on separate HIP streams, so a launch covers M / parts rows and
-        # overlaps with the other stream's kernels.  roofline.* is the spec'd live figure (events on the launch stream,
-        # timed region); "exclusive" is the same kernel alone on the GPU at full M (the single-stream breakdown pass).
-        up = prof_dom["gemm_ffn_up"] if prof_dom["gemm_ffn_up"]["launches"] else prof["gemm_ffn_up"]
-        expect = args.steps * n_fwd_sample * cfg.n_layers if prof_dom["gemm_ffn_up"]["launches"] else n_fwd_sample * cfg.n_layers
-        parts = max(1, round(up["launches"] / expect))
-        flop_up_full = 2.0 * M * cfg.d_model * 2 * cfg.ffn_hidden
-        flop_up = flop_up_full / parts
-        ms_up = up["ms"] / max(up["launches"], 1)
-        ach = flop_up / (ms_up * 1e-3) / 1e12 if ms_up > 0 else 0.0
-        ex = prof["gemm_ffn_up"]
-        ms_ex = ex["ms"] / max(ex["launches"], 1)
-        ach_ex = flop_up_full / (ms_ex * 1e-3) / 1e12 if ms_ex > 0 else 0.0
-        gemm_ms = sum(prof[s]["ms"] for s in ("gemm_qkv", "gemm_out", "gemm_ffn_up", "gemm_ffn_down", "head"))
-        tot_ms = sum(v["ms"] for v in prof.values())
-        lin_flop_fwd = M * (cfg.n_layers * (2 * cfg.d_model * (3 * cfg.d_model + cfg.d_model + 2 * cfg.ffn_hidden)
-                                            + 2 * cfg.ffn_hidden * cfg.d_model)
-                            + 2 * cfg.d_model * cfg.d_model + 2 * cfg.d_model * cfg.n_structure_heads)
-        n_fwd = n_fwd_sample                                     # the breakdown pass is one step
-        traffic, traffic_note = None, "no PMC pass on record"
-        tp = ROOT / "profiles" / "r02_gemm_traffic.json"
-        if tp.exists() and not args.tiny:   # separate rocprofv3 --pmc passes of this same kernel at this M
-            tj = json.loads(tp.read_text())
-            rec = tj.get("by_rows", {}).get(str(M // parts))
-            if rec:
-                traffic, traffic_note = rec["traffic_bytes_per_launch"], ("profiles/r02_gemm_traffic.json: FETCH_SIZE x2 "
-                                                                           "(gfx950 correction) + WRITE_SIZE, fabric-level")
         out = {
             "metric": ("conformation samples/sec (256-res, 25 steps)" if (args.mode, args.residues, T) == ("ddpm", 256, 25) and not args.inpaint
                        else f"conformation samples/sec ({args.residues}-res, {T} steps, {args.mode}{', inpaint' if args.inpaint else ''})"),
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic" if not args.tiny else "debug-tiny-model",
+            "data": "debug-stub-engine" if stub else ("synthetic" if not args.tiny else "debug-tiny-model"),
             "config": {"workload": workload_name(args, world),
                        "samples_per_gpu": B, "L_tok": L, "num_steps": T, "forwards_per_sample": n_fwd_sample, "mode": args.mode,
                        "layers": cfg.n_layers, "d_model": cfg.d_model, "noise": "philox4x32-10",
@@ -337,29 +417,19 @@ def main():
                                        "single process, one GPU, no process group (nothing crosses RCCL at N=1)")},
             "flop_per_sample": f_sample,
             "mfma_frac_whole_job": round(value / world * f_sample / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": {"bound": "mfma", "kernel": "g4::gemm256w4_kernel<SWIGLU> (FFN-up, M=%d N=%d K=%d)" % (M // parts, 2 * cfg.ffn_hidden, cfg.d_model),
-                         "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "bytes/launch", "traffic_source": traffic_note,
-                         "algorithmic_flop_per_launch": flop_up,
-                         "launch_ms": round(ms_up, 4), "launches": up["launches"], "streams": parts,
-                         "note": ("launches of the %d sub-batch streams overlap each other's kernels, so launch_ms is not "
-                                  "exclusive GPU time; see 'exclusive'" % parts) if parts > 1 else "single stream",
-                         "exclusive": {"what": "same kernel alone on the GPU at M=%d (single-stream breakdown pass, HIP events)" % M,
-                                       "launch_ms": round(ms_ex, 4), "achieved": round(ach_ex, 1),
-                                       "frac": round(ach_ex / PEAK_BF16_TFLOPS, 4)},
-                         "all_gemm_tflops": round(lin_flop_fwd * n_fwd / (gemm_ms * 1e-3) / 1e12, 1) if gemm_ms else None},
-            "sections_ms_per_forward": {k: round(v["ms"] / n_fwd, 3) for k, v in prof.items()},
-            "sections_note": "per-launch HIP events of one extra untimed step; roofline.launch_ms is from the timed region",
-            "device_ms_per_forward": round(tot_ms / n_fwd, 3),
-            "power": power_rec,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if stub:
+            out["roofline"] = None
+            out["note"] = "stand-in engine on CPU over gloo: launch / process-group / reporting path only, not a measurement"
+        else:
+            out.update(roofline_report(args, cfg, B, L, n_fwd_sample, prof_dom, prof))
+            out["power"] = power_rec
+        if world == 1 and not args.no_cpu_baseline and not stub:
             try:
                 out["cpu_baseline"], out["parity_spot"] = cpu_baseline(cfg, sd, L, T, eng)
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"error": repr(ex)}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     eng.close()
     if use_dist:
         dist.destroy_process_group()

@@ -16,6 +16,8 @@ c_i64p = ctypes.POINTER(ctypes.c_int64)
 
 EPI_BF16, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_F32 = range(5)
 DT_F32, DT_BF16 = 0, 1
+PRECISION = {"bf16": 0, "f32": 1}       # esmdiff_precision
+F32EPI_STORE, F32EPI_BIAS_GELU, F32EPI_RESID_DIV = range(3)
 SECTIONS = ["embed", "layernorm", "gemm_qkv", "qk_norm_rope", "attention", "gemm_out", "gemm_ffn_up",
             "gemm_ffn_down", "head", "sampler"]
 
@@ -24,7 +26,7 @@ class Config(ctypes.Structure):
     _fields_ = [("d_model", ctypes.c_int32), ("n_heads", ctypes.c_int32), ("n_layers", ctypes.c_int32),
                 ("ffn_hidden", ctypes.c_int32), ("vocab_out", ctypes.c_int32), ("freq_dim", ctypes.c_int32),
                 ("max_batch", ctypes.c_int32), ("max_len", ctypes.c_int32), ("residue_scale", ctypes.c_float),
-                ("time_conditioning", ctypes.c_int32)]
+                ("time_conditioning", ctypes.c_int32), ("precision", ctypes.c_int32)]
 
 
 class Weight(ctypes.Structure):
@@ -44,7 +46,7 @@ EXPORTS = [
     "esmdiff_get_profile", "esmdiff_set_frames", "esmdiff_gemm_bf16_ws", "esmdiff_decoder_create",
     "esmdiff_decoder_decode", "esmdiff_metrics_js_pwd", "esmdiff_metrics_js_rg", "esmdiff_metrics_validity",
     "esmdiff_metrics_bonding_validity", "esmdiff_metrics_pwd", "esmdiff_metrics_js_columns", "esmdiff_encoder_create", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error",
-    "esmdiff_encoder_encode",
+    "esmdiff_encoder_encode", "esmdiff_gemm_f32",
 ]
 
 
@@ -99,11 +101,12 @@ def lib():
     L.esmdiff_encoder_last_error.argtypes = [vp]
     L.esmdiff_encoder_last_error.restype = ctypes.c_char_p
     L.esmdiff_encoder_encode.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.esmdiff_gemm_f32.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     L.esmdiff_gemm_bf16_ws.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     for n in EXPORTS:
         if n not in ("esmdiff_engine_destroy", "esmdiff_last_error", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error"):
             getattr(L, n).restype = ctypes.c_int
-    if L.esmdiff_abi_version() != 3:
+    if L.esmdiff_abi_version() != 4:
         raise RuntimeError("libesmdiff_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -36,6 +36,8 @@ enum Section { S_EMBED = 0, S_LN, S_QKV, S_QKROPE, S_ATTN, S_OUT, S_FFN_UP, S_FF
 struct Layer {
   float *ln1_w, *ln1_b, *q_ln_w, *k_ln_w, *ln2_w, *ln2_b;
   bf16_t *w_qkv, *w_out, *w_up, *w_down;
+  // precision = F32 (csrc/strict.hip): the linears as float32 in the checkpoint's own row order (no SwiGLU interleave)
+  float *fw_qkv, *fw_out, *fw_up, *fw_down;
 };
 
 }  // namespace
@@ -94,6 +96,11 @@ struct esmdiff_engine {
   ed::GemmWorkspace gemm_ws[4] = {};  // split-K partials of the small-M GEMM path, one per launch queue
   ed::GemmWorkspace gemm_ws2[4] = {}; // ... a second set: the out-projection's K slices stay live next to the FFN-down's
   int small_fused = 1;                // ESMDIFF_SMALL_FUSED=0: branch linears write bf16 deltas at every size (A/B runs)
+  // precision = ESMDIFF_PRECISION_F32: float32 weights / activations (forward_strict); the bf16 members above stay null
+  bool strict = false;
+  float *fhead_w0 = nullptr, *fhead_w3 = nullptr, *fpl_w0 = nullptr, *fpl_w3 = nullptr, *fpw_down = nullptr;
+  float *fh = nullptr, *fh2 = nullptr, *fqkv = nullptr, *fq = nullptr, *fk = nullptr, *fctx = nullptr, *fgu = nullptr,
+        *fmid = nullptr, *fpair_qk = nullptr;
   // profiling
   int profiling = 0;  // 0 off, 1 every launch, 2 only the dominant kernel (FFN-up GEMM)
   std::vector<hipEvent_t> ev;
@@ -209,11 +216,36 @@ void prof_collect(esmdiff_engine* e) {
     return;
   }
   hipDeviceSynchronize();
+  // mode 2 (only the FFN-up launches are bracketed, possibly on two overlapping streams): besides the per-launch sum, the
+  // UNION of the launches' busy intervals on the device timeline (event timestamps share one clock across streams) —
+  // slot 15 — so that FFN-up FLOP of all streams / union is a device-level rate that never counts an instant twice.
+  std::vector<std::pair<float, float>> iv;
   for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
     float ms = 0;
     hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]);
     e->prof_ms[e->ev_section[i]] += ms;
     e->prof_launches[e->ev_section[i]] += 1;
+    if (e->profiling == 2) {
+      float t0 = 0;
+      if (i) hipEventElapsedTime(&t0, e->ev[0], e->ev[i]);   // may be negative across streams: fine, only order matters
+      iv.emplace_back(t0, t0 + ms);
+    }
+  }
+  if (!iv.empty()) {
+    std::sort(iv.begin(), iv.end());
+    float busy = 0, lo = iv[0].first, hi = iv[0].second;
+    for (size_t i = 1; i < iv.size(); ++i) {
+      if (iv[i].first > hi) {
+        busy += hi - lo;
+        lo = iv[i].first;
+        hi = iv[i].second;
+      } else if (iv[i].second > hi) {
+        hi = iv[i].second;
+      }
+    }
+    busy += hi - lo;
+    e->prof_ms[15] += busy;
+    e->prof_launches[15] += (int)iv.size();
   }
   e->ev_used = 0;
 }
@@ -254,6 +286,54 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
               e->gemm_ws2[queue].partial ? &e->gemm_ws2[queue] : nullptr};
 }
 
+// precision = F32: the same network in float32 end to end (csrc/strict.hip).  One stream, one launch per op, residual
+// adds in the branch GEMMs' epilogues as x + r / scaling_factor (esm's own expression).  Sections are timed like the
+// bf16 path's.  The geometric branch is not built here (esmdiff_set_frames refuses on a strict engine).
+int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const float* t_freq_dev, float* logits,
+                   int ld, int B, int L, hipStream_t st) {
+  const esmdiff_config& c = e->cfg;
+  const int D = c.d_model, H = c.n_heads, FH = c.ffn_hidden, M = B * L;
+  Prof p{e, st};
+#define RUN(section, call)   \
+  do {                       \
+    p.mark(section);         \
+    HIP_TRY(e, (call));      \
+    p.mark(section);         \
+  } while (0)
+  const float* cond = nullptr;
+  if (t_freq_dev && e->sig_w1) {
+    RUN(S_EMBED, launch_sigma_mlp(t_freq_dev, e->sig_w1, e->sig_b1, e->sig_w2, e->sig_b2, e->sig_hidden, e->cond, c.freq_dim, D, st));
+    cond = e->cond;
+  }
+  if (e->kind == 1) RUN(S_EMBED, launch_gather_rows(xtok, e->e_struct, e->x, M, D, ESMDIFF_VOCAB, st));
+  else RUN(S_EMBED, launch_embed(seq, xtok, e->e_seq, e->e_struct, e->cvec, cond, e->x, B, L, D, st));
+  for (int i = 0; i < c.n_layers; ++i) {
+    const Layer& ly = e->layers[i];
+    RUN(S_LN, launch_layernorm_f32(e->x, ly.ln1_w, ly.ln1_b, e->fh, M, D, st));
+    RUN(S_QKV, launch_gemm_f32(e->fh, D, ly.fw_qkv, e->fqkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_F32EPI_STORE, st));
+    RUN(S_QKROPE, launch_qk_norm_rope_f32(e->fqkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, e->fq, e->fk, B, L, H, st));
+    RUN(S_ATTN, launch_attention_f32(e->fq, e->fk, e->fqkv, e->fctx, B, L, H, st));
+    RUN(S_OUT, launch_gemm_f32(e->fctx, D, ly.fw_out, e->x, nullptr, M, D, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
+    RUN(S_LN, launch_layernorm_f32(e->x, ly.ln2_w, ly.ln2_b, e->fh, M, D, st));
+    RUN(S_FFN_UP, launch_gemm_f32(e->fh, D, ly.fw_up, e->fgu, nullptr, M, 2 * FH, D, 2 * FH, 2 * FH, 1.f, ESMDIFF_F32EPI_STORE, st));
+    RUN(S_FFN_UP, launch_swiglu_f32(e->fgu, e->fmid, M, FH, st));
+    RUN(S_FFN_DOWN, launch_gemm_f32(e->fmid, FH, ly.fw_down, e->x, nullptr, M, D, FH, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
+  }
+  RUN(S_LN, launch_layernorm_f32(e->x, e->final_ln_w, nullptr, e->fh, M, D, st));
+  RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fhead_w0, e->fh2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_F32EPI_BIAS_GELU, st));
+  if (e->has_plddt) RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fpl_w0, e->fctx, e->pl_b0, M, D, D, D, D, 1.f, ESMDIFF_F32EPI_BIAS_GELU, st));
+  if (e->has_pair) {   // the pairwise confidence head keeps its bf16 MFMA pipeline (pTM / PAE are not under the 1e-4 A bar)
+    RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fpw_down, e->fpair_qk, nullptr, M, 128, D, 128, 128, 1.f, ESMDIFF_F32EPI_STORE, st));
+    RUN(S_HEAD, launch_to_bf16(e->fpair_qk, ESMDIFF_F32, e->pair_qk, (int64_t)M * 128, st));
+  }
+  RUN(S_LN, launch_layernorm_f32(e->fh2, e->head_ln_w, e->head_ln_b, e->fh, M, D, st));
+  if (e->has_plddt) RUN(S_LN, launch_layernorm_f32(e->fctx, e->pl_ln_w, e->pl_ln_b, e->fq, M, D, st));
+  RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fhead_w3, logits, e->head_b3, M, c.vocab_out, D, ld, c.vocab_out, 1.f, ESMDIFF_F32EPI_STORE, st));
+  if (e->has_plddt) RUN(S_HEAD, launch_gemm_f32(e->fq, D, e->fpl_w3, e->pl_logits, e->pl_b3, M, e->plddt_bins, D, e->ld_plddt, e->plddt_bins, 1.f, ESMDIFF_F32EPI_STORE, st));
+#undef RUN
+  return 0;
+}
+
 // The whole network: tokens -> f32 logits [M, ld].
 //
 // Samples are independent, so a large batch is run as two sub-batches on two HIP streams (the caller's and one
@@ -275,6 +355,7 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
 //     matrix for half the rows and lose (B = 4 at L_tok = 60: 87.0 / 95.8 ms), and B = 3 at L_tok = 258 cuts into 1 + 2.
 int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const float* t_freq_dev, float* logits,
             int ld, int B, int L, hipStream_t st) {
+  if (e->strict) return forward_strict(e, seq, xtok, t_freq_dev, logits, ld, B, L, st);
   const esmdiff_config& c = e->cfg;
   const int D = c.d_model, H = c.n_heads, FH = c.ffn_hidden;
   const float inv_scale = 1.0f / c.residue_scale;
@@ -443,10 +524,14 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       (kind == 0 && (V < ESMDIFF_MASK_ID || V > 5120 || F <= 0)) || (kind == 1 && V != 23))
     return fail(nullptr, ESMDIFF_E_INVALID, "invalid configuration");
 
+  if (cfg->precision != ESMDIFF_PRECISION_BF16 && cfg->precision != ESMDIFF_PRECISION_F32)
+    return fail(nullptr, ESMDIFF_E_INVALID, "precision %d: expected ESMDIFF_PRECISION_BF16 (0) or ESMDIFF_PRECISION_F32 (1)", cfg->precision);
   esmdiff_engine* e = new esmdiff_engine;
   e->cfg = *cfg;
   e->kind = kind;
   e->device = device;
+  e->strict = cfg->precision == ESMDIFF_PRECISION_F32;
+  const bool strict = e->strict;
   auto bail = [&](int code) {
     g_create_error = e->err;
     esmdiff_engine_destroy(e);
@@ -475,28 +560,37 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     const std::string b = stack + "blocks." + std::to_string(i) + ".";
     TRY(load_f32(e, t, b + "attn.layernorm_qkv.0.weight", {D}, &ly.ln1_w));
     TRY(load_f32(e, t, b + "attn.layernorm_qkv.0.bias", {D}, &ly.ln1_b));
-    TRY(load_bf16(e, t, b + "attn.layernorm_qkv.1.weight", {3 * D, D}, &ly.w_qkv));
+    ly.w_qkv = ly.w_out = ly.w_up = ly.w_down = nullptr;
+    ly.fw_qkv = ly.fw_out = ly.fw_up = ly.fw_down = nullptr;
+    if (strict) TRY(load_f32(e, t, b + "attn.layernorm_qkv.1.weight", {3 * D, D}, &ly.fw_qkv));
+    else TRY(load_bf16(e, t, b + "attn.layernorm_qkv.1.weight", {3 * D, D}, &ly.w_qkv));
     TRY(load_f32(e, t, b + "attn.q_ln.weight", {D}, &ly.q_ln_w));
     TRY(load_f32(e, t, b + "attn.k_ln.weight", {D}, &ly.k_ln_w));
-    TRY(load_bf16(e, t, b + "attn.out_proj.weight", {D, D}, &ly.w_out));
+    if (strict) TRY(load_f32(e, t, b + "attn.out_proj.weight", {D, D}, &ly.fw_out));
+    else TRY(load_bf16(e, t, b + "attn.out_proj.weight", {D, D}, &ly.w_out));
     TRY(load_f32(e, t, b + "ffn.0.weight", {D}, &ly.ln2_w));
     TRY(load_f32(e, t, b + "ffn.0.bias", {D}, &ly.ln2_b));
-    {
+    if (strict) {
+      TRY(load_f32(e, t, b + "ffn.1.weight", {2 * FH, D}, &ly.fw_up));
+      TRY(load_f32(e, t, b + "ffn.3.weight", {D, FH}, &ly.fw_down));
+    } else {
       const esmdiff_weight* w;
       TRY(need(e, t, b + "ffn.1.weight", {2 * FH, D}, &w));
       TRY(dalloc(e, &ly.w_up, (size_t)2 * FH * D));
       if (launch_interleave_swiglu(w->data, w->dtype, ly.w_up, FH, D, 0) != hipSuccess)
         return bail(fail(e, ESMDIFF_E_HIP, "interleave_swiglu launch failed"));
+      TRY(load_bf16(e, t, b + "ffn.3.weight", {D, FH}, &ly.w_down));
     }
-    TRY(load_bf16(e, t, b + "ffn.3.weight", {D, FH}, &ly.w_down));
   }
   TRY(load_f32(e, t, stack + "norm.weight", {D}, &e->final_ln_w));
-  TRY(load_bf16(e, t, head0 + "weight", {D, D}, &e->head_w0));
+  if (strict) TRY(load_f32(e, t, head0 + "weight", {D, D}, &e->fhead_w0));
+  else TRY(load_bf16(e, t, head0 + "weight", {D, D}, &e->head_w0));
   TRY(load_f32(e, t, head0 + "bias", {D}, &e->head_b0));
   TRY(load_f32(e, t, head2 + "weight", {D}, &e->head_ln_w));
   TRY(load_f32(e, t, head2 + "bias", {D}, &e->head_ln_b));
   e->vocab_pad = round_up(V, 256);  // 4101 -> 4352: 17 column tiles of the 256x256 kernel (the 128x128 kernel took 0.40 ms at M = 25 800)
-  TRY(load_bf16(e, t, head3 + "weight", {V, D}, &e->head_w3, e->vocab_pad));
+  if (strict) TRY(load_f32(e, t, head3 + "weight", {V, D}, &e->fhead_w3));
+  else TRY(load_bf16(e, t, head3 + "weight", {V, D}, &e->head_w3, e->vocab_pad));
   {
     const esmdiff_weight* w;
     TRY(need(e, t, head3 + "bias", {V}, &w));
@@ -510,11 +604,13 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       if (nb <= 0 || nb > 128) return bail(fail(e, ESMDIFF_E_INVALID, "plddt_head.3.weight: %d bins unsupported (1..128)", nb));
       e->plddt_bins = nb;
       e->ld_plddt = round_up(nb, 4);
-      TRY(load_bf16(e, t, "plddt_head.0.weight", {D, D}, &e->pl_w0));
+      if (strict) TRY(load_f32(e, t, "plddt_head.0.weight", {D, D}, &e->fpl_w0));
+      else TRY(load_bf16(e, t, "plddt_head.0.weight", {D, D}, &e->pl_w0));
       TRY(load_f32(e, t, "plddt_head.0.bias", {D}, &e->pl_b0));
       TRY(load_f32(e, t, "plddt_head.2.weight", {D}, &e->pl_ln_w));
       TRY(load_f32(e, t, "plddt_head.2.bias", {D}, &e->pl_ln_b));
-      TRY(load_bf16(e, t, "plddt_head.3.weight", {nb, D}, &e->pl_w3, 128));
+      if (strict) TRY(load_f32(e, t, "plddt_head.3.weight", {nb, D}, &e->fpl_w3));
+      else TRY(load_bf16(e, t, "plddt_head.3.weight", {nb, D}, &e->pl_w3, 128));
       const esmdiff_weight* w;
       TRY(need(e, t, "plddt_head.3.bias", {nb}, &w));
       TRY(dalloc(e, &e->pl_b3, (size_t)128, true));
@@ -523,7 +619,8 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     }
     if (t.find("pairwise_classification_head.linear2.weight")) {
       const std::string ph = "pairwise_classification_head.";
-      TRY(load_bf16(e, t, ph + "downproject.weight", {128, D}, &e->pw_down));
+      if (strict) TRY(load_f32(e, t, ph + "downproject.weight", {128, D}, &e->fpw_down));
+      else TRY(load_bf16(e, t, ph + "downproject.weight", {128, D}, &e->pw_down));
       TRY(load_bf16(e, t, ph + "linear1.weight", {128, 128}, &e->pw_l1));
       TRY(load_f32(e, t, ph + "norm.weight", {128}, &e->pw_ln_w));
       TRY(load_f32(e, t, ph + "norm.bias", {128}, &e->pw_ln_b));
@@ -543,7 +640,8 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(load_f32(e, t, "sigma_embedder.mlp.2.bias", {D}, &e->sig_b2));
   }
   // block 0's geometric attention: optional (the DDPM path never needs it: coordinates are all-NaN there)
-  if (const esmdiff_weight* pw = kind == 0 ? t.find("transformer.blocks.0.geom_attn.proj.weight") : nullptr) {
+  // (a strict engine carries no geometric branch: esmdiff_set_frames refuses there)
+  if (const esmdiff_weight* pw = (kind == 0 && !strict) ? t.find("transformer.blocks.0.geom_attn.proj.weight") : nullptr) {
     const std::string ga = "transformer.blocks.0.geom_attn.";
     const int VH = pw->ndim == 2 ? (int)(pw->shape[0] / 15) : 0;  // proj: Linear(D, v_heads * 3 * 5)
     if (VH <= 0 || (15 * VH) % 128 || (3 * VH) % 64) return bail(fail(e, ESMDIFF_E_INVALID, "geom_attn v_heads=%d unsupported", VH));
@@ -621,14 +719,26 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     const size_t Mx = (size_t)cfg->max_batch * cfg->max_len;
     e->ld_logits = round_up(V, 4);
     TRY(dalloc(e, &e->x, Mx * D));
-    TRY(dalloc(e, &e->h, Mx * D));
-    TRY(dalloc(e, &e->h2, Mx * D));
-    TRY(dalloc(e, &e->qkv, Mx * 3 * D));
-    TRY(dalloc(e, &e->q, Mx * D));
-    TRY(dalloc(e, &e->k, Mx * D));
-    TRY(dalloc(e, &e->ctx, Mx * D));
-    TRY(dalloc(e, &e->dlt, Mx * D));
-    TRY(dalloc(e, &e->dlt2, Mx * D));
+    if (strict) {
+      TRY(dalloc(e, &e->fh, Mx * D));
+      TRY(dalloc(e, &e->fh2, Mx * D));
+      TRY(dalloc(e, &e->fqkv, Mx * 3 * D));
+      TRY(dalloc(e, &e->fq, Mx * D));
+      TRY(dalloc(e, &e->fk, Mx * D));
+      TRY(dalloc(e, &e->fctx, Mx * D));
+      TRY(dalloc(e, &e->fgu, Mx * 2 * FH));
+      TRY(dalloc(e, &e->fmid, Mx * FH));
+      if (e->has_pair) TRY(dalloc(e, &e->fpair_qk, Mx * 128));
+    } else {
+      TRY(dalloc(e, &e->h, Mx * D));
+      TRY(dalloc(e, &e->h2, Mx * D));
+      TRY(dalloc(e, &e->qkv, Mx * 3 * D));
+      TRY(dalloc(e, &e->q, Mx * D));
+      TRY(dalloc(e, &e->k, Mx * D));
+      TRY(dalloc(e, &e->ctx, Mx * D));
+      TRY(dalloc(e, &e->dlt, Mx * D));
+      TRY(dalloc(e, &e->dlt2, Mx * D));
+    }
     if (e->has_geom) {
       TRY(dalloc(e, &e->gp, Mx * 15 * e->v_heads));
       TRY(dalloc(e, &e->gctx, Mx * 3 * e->v_heads));
@@ -636,7 +746,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       TRY(dalloc(e, &e->f_trans, Mx * 3));
       TRY(dalloc(e, &e->f_mask, Mx));
     }
-    TRY(dalloc(e, &e->mid, Mx * FH));
+    if (!strict) TRY(dalloc(e, &e->mid, Mx * FH));
     TRY(dalloc(e, &e->logits, Mx * e->ld_logits));
     if (e->has_plddt) TRY(dalloc(e, &e->pl_logits, Mx * e->ld_plddt));
     if (e->has_pair) {
@@ -653,7 +763,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(dalloc(e, &e->g_nunmask, (size_t)e->tfreq_rows * cfg->max_batch));
     {  // split-K workspaces: S * N <= 12288 for every shape the launcher splits; rows up to the small-batch switch
       const char* sk = getenv("ESMDIFF_GEMM_SPLITK");
-      if (!(sk && sk[0] == '0')) {
+      if (!(sk && sk[0] == '0') && !strict) {
         const size_t rows = (size_t)round_up((int)std::min<size_t>(Mx, ed::small_max_rows()), 128);
         for (int q = 0; q < 4; ++q) {
           e->gemm_ws[q].partial_floats = rows * 12288;
@@ -900,6 +1010,14 @@ int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias
   return 0;
 }
 
+int esmdiff_gemm_f32(const float* A, int32_t lda, const float* W, float* out, const float* bias, int32_t M, int32_t N,
+                     int32_t K, int32_t ldc, int32_t n_valid, float div, int32_t epilogue, void* stream) {
+  if (!A || !W || !out) return ESMDIFF_E_INVALID;
+  hipError_t s = launch_gemm_f32(A, lda, W, out, bias, M, N, K, ldc, n_valid, div, epilogue, (hipStream_t)stream);
+  if (s != hipSuccess) return fail(nullptr, s == hipErrorInvalidValue ? ESMDIFF_E_INVALID : ESMDIFF_E_HIP, "gemm_f32: %s", hipGetErrorString(s));
+  return 0;
+}
+
 int esmdiff_gemm_bf16_ws(esmdiff_engine* e, const void* A, const void* W, void* out, const float* bias, int32_t M,
                          int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream) {
   if (!e || !A || !W || !out) return ESMDIFF_E_INVALID;
@@ -954,6 +1072,7 @@ int esmdiff_attention_bf16(esmdiff_engine* e, const void* qkv, const float* q_ln
                            int32_t B, int32_t L, void* stream) {
   if (!e) return ESMDIFF_E_INVALID;
   if (!qkv || !q_ln_w || !k_ln_w || !ctx) return fail(e, ESMDIFF_E_INVALID, "null pointer");
+  if (e->strict) return fail(e, ESMDIFF_E_INVALID, "esmdiff_attention_bf16 on a float32 (strict) engine: it has no bf16 workspace");
   if (int r = check_bl(e, B, L)) return r;
   HIP_TRY(e, launch_qk_norm_rope((const bf16_t*)qkv, q_ln_w, k_ln_w, e->rope_cos, e->rope_sin, e->q, e->k, B, L,
                                  e->cfg.n_heads, (hipStream_t)stream));
@@ -968,6 +1087,8 @@ int esmdiff_set_frames(esmdiff_engine* e, const float* rot, const float* trans, 
     e->frames_B = e->frames_L = 0;
     return 0;
   }
+  if (e->strict)
+    return fail(e, ESMDIFF_E_INVALID, "coordinate conditioning is not built for the float32 (strict) precision: create the engine with ESMDIFF_PRECISION_BF16");
   if (!e->has_geom)
     return fail(e, ESMDIFF_E_MISSING, "coordinates given but the weight table had no transformer.blocks.0.geom_attn.* tensors");
   if (!trans || !has_frame) return fail(e, ESMDIFF_E_INVALID, "null argument");

@@ -112,6 +112,16 @@ hipError_t launch_plddt_mean(const float* v, int ld, int n_bins, float* out, int
 hipError_t launch_sigma_mlp(const float* t_freq, const float* w1, const float* b1, const float* w2,
                             const float* b2, float* hidden, float* cond, int F, int D, hipStream_t stream);
 
+// ---- strict.hip: the float32 precision path (esmdiff_config.precision = ESMDIFF_PRECISION_F32) -----------------
+hipError_t launch_gemm_f32(const float* A, int lda, const float* W, float* out, const float* bias, int M, int n_rows, int K,
+                           int ldc, int n_valid, float div, int epi, hipStream_t stream);
+hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, float* y, int M, int D, hipStream_t stream);
+hipError_t launch_swiglu_f32(const float* gu, float* mid, int M, int FH, hipStream_t stream);
+hipError_t launch_qk_norm_rope_f32(const float* qkv, const float* q_ln_w, const float* k_ln_w, const float* rope_cos,
+                                   const float* rope_sin, float* q, float* k, int B, int L, int H, hipStream_t stream);
+hipError_t launch_attention_f32(const float* q, const float* k, const float* qkv, float* ctx, int B, int L, int H,
+                                hipStream_t stream);
+
 // ---- convert.hip (weight preparation at engine create) ---------------------------------------
 hipError_t launch_to_bf16(const void* src, int src_dtype, bf16_t* dst, int64_t n, hipStream_t stream);
 hipError_t launch_to_f32(const void* src, int src_dtype, float* dst, int64_t n, hipStream_t stream);

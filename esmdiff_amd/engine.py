@@ -37,15 +37,21 @@ class Engine:
     """One engine per (process, device).  Not thread-safe.  All work is enqueued on torch's current stream."""
 
     def __init__(self, cfg: ModelConfig, state_dict: Dict[str, torch.Tensor], max_batch: int, max_len: int,
-                 device: int = 0):
+                 device: int = 0, precision: str = "bf16"):
+        """precision: "bf16" (the throughput path: bf16 MFMA, f32 accumulate and residual stream) or "f32" (the strict
+        path, csrc/strict.hip: float32 weights and activations on the f32-input MFMA — the reference's own arithmetic,
+        checkpoint_utils.py:59-73; ~1/12 of the throughput; no coordinate conditioning)."""
         _require_gpu()
+        if precision not in N.PRECISION:
+            raise ValueError(f"precision must be one of {sorted(N.PRECISION)}, got {precision!r}")
+        self.precision = precision
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         self.max_batch, self.max_len = max_batch, max_len
         self._lib = N.lib()
         self._h = ctypes.c_void_p(0)
         c = N.Config(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden, cfg.n_structure_heads, cfg.freq_dim,
-                     max_batch, max_len, cfg.residue_scale, int(cfg.time_conditioning))
+                     max_batch, max_len, cfg.residue_scale, int(cfg.time_conditioning), N.PRECISION[precision])
         # upload the caller's tensors (any float dtype) as device containers; the engine makes its own
         # bf16 / re-laid-out copies, after which these are released.
         keep, table = [], (N.Weight * len(state_dict))()
@@ -66,7 +72,7 @@ class Engine:
                                f"{self._lib.esmdiff_last_error(None).decode()}")
         del keep
         self.ld_logits = (cfg.n_structure_heads + 3) // 4 * 4
-        self.has_geom = any(k.endswith("transformer.blocks.0.geom_attn.proj.weight") for k in state_dict)
+        self.has_geom = precision == "bf16" and any(k.endswith("transformer.blocks.0.geom_attn.proj.weight") for k in state_dict)
         self.has_sigma_embedder = any(k.startswith("sigma_embedder.mlp.0.") for k in state_dict)
         self._frames = None
 
@@ -265,7 +271,10 @@ class Engine:
         ms = (ctypes.c_float * 16)()
         n = (ctypes.c_int32 * 16)()
         self._chk(self._lib.esmdiff_get_profile(self._h, ms, n))
-        return {s: {"ms": float(ms[i]), "launches": int(n[i])} for i, s in enumerate(N.SECTIONS)}
+        out = {s: {"ms": float(ms[i]), "launches": int(n[i])} for i, s in enumerate(N.SECTIONS)}
+        # profiling mode 2: union of the FFN-up launches' busy intervals over all streams (slot 15 of the C ABI arrays)
+        out["gemm_ffn_up_union"] = {"ms": float(ms[15]), "launches": int(n[15])}
+        return out
 
     def attention(self, qkv: torch.Tensor, q_ln_w: torch.Tensor, k_ln_w: torch.Tensor, B: int, L: int) -> torch.Tensor:
         D = self.cfg.d_model
@@ -280,13 +289,21 @@ class StructureDecoder:
     """Structure tokens -> backbone coordinates on the device (esmdiff_decoder_create / esmdiff_decoder_decode): what the
     reference gets from `esm3.decode(ESMProteinTensor(structure=...))`, /root/reference/slm/sample_esmdiff.py:40-61."""
 
-    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], max_batch: int, max_len: int, device: int = 0):
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], max_batch: int, max_len: int, device: int = 0,
+                 precision: str = "f32"):
+        """precision defaults to "f32": the reference decodes in the model's float32 and north_star's bar for this output
+        is a backbone within 1e-4 A; decoding is 3e13 FLOP per 100 samples and sits outside the timed sampling metric.
+        "bf16" is the r01 / r02 MFMA path (0.05 A mean off the f32 result, ~10x faster)."""
         _require_gpu()
+        if precision not in N.PRECISION:
+            raise ValueError(f"precision must be one of {sorted(N.PRECISION)}, got {precision!r}")
+        self.precision = precision
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         self._lib = N.lib()
         self._h = ctypes.c_void_p(0)
-        c = N.Config(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden, 23, 1, max_batch, max_len, 1.0, 0)
+        c = N.Config(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden, 23, 1, max_batch, max_len, 1.0, 0,
+                     N.PRECISION[precision])
         keep, table = [], (N.Weight * len(state_dict))()
         with torch.cuda.device(self.device):
             for i, (name, t) in enumerate(state_dict.items()):
@@ -416,6 +433,24 @@ def gemm_bf16(A: torch.Tensor, W: torch.Tensor, epilogue: int, *, out: Optional[
     ldc = out.stride(0)
     N.check(N.lib().esmdiff_gemm_bf16(_ptr(A), _ptr(W), _ptr(out), _ptr(bias), M, Nn, K, ldc,
                                       Nn if n_valid is None else n_valid, float(alpha), epilogue, _stream()))
+    return out
+
+
+def gemm_f32(A: torch.Tensor, W: torch.Tensor, epilogue: int = 0, *, out: Optional[torch.Tensor] = None,
+             bias: Optional[torch.Tensor] = None, div: float = 1.0) -> torch.Tensor:
+    """The strict path's linear (esmdiff_gemm_f32): out f32 [M,N] = epi(A f32 [M,K] @ W f32 [N,K]^T); K % 32 == 0.
+    epilogue N.F32EPI_RESID_DIV updates `out` in place: out + acc / div."""
+    _require_gpu()
+    M, K = A.shape
+    Nn = W.shape[0]
+    assert A.dtype == W.dtype == torch.float32 and A.stride(1) == 1 and W.is_contiguous() and W.shape[1] == K
+    if out is None:
+        if epilogue == N.F32EPI_RESID_DIV:
+            raise ValueError("the residual epilogue updates `out` in place: pass it")
+        out = torch.empty(M, Nn, dtype=torch.float32, device=A.device)
+    assert out.dtype == torch.float32 and out.stride(1) == 1
+    N.check(N.lib().esmdiff_gemm_f32(_ptr(A), A.stride(0), _ptr(W), _ptr(out), _ptr(bias), M, Nn, K, out.stride(0), Nn,
+                                     float(div), epilogue, _stream()))
     return out
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESMDIFF_ABI_VERSION 3
+#define ESMDIFF_ABI_VERSION 4
 
 /* structure-track vocabulary: esm constants mirrored at model.py:380-381 */
 #define ESMDIFF_VOCAB 4101
@@ -53,6 +53,16 @@ typedef enum {
 
 typedef enum { ESMDIFF_F32 = 0, ESMDIFF_BF16 = 1 } esmdiff_dtype;
 
+/* Arithmetic of the network (esmdiff_config.precision).
+ *   BF16  the throughput path: bf16 weights and GEMM operands on the bf16 MFMA, f32 accumulation, f32 residual stream.
+ *   F32   the "strict" path (csrc/strict.hip): float32 weights and activations end to end, every linear on the f32-input
+ *         MFMA (bitwise an fmaf chain), correctly rounded divide / sqrt — the arithmetic the reference itself runs in
+ *         (checkpoint_utils.py:59-73 loads float32; decode at sample_esmdiff.py:40-61), ~1/12 of the bf16 throughput.
+ *         It is what north_star's floating-point bars are stated against (ids equal under a fixed seed, decoded backbone
+ *         within 1e-4 A) and the structure decoder's default on the Python side.  A row's result does not depend on the
+ *         batch it is computed in.  Not available with coordinate conditioning (esmdiff_set_frames -> ESMDIFF_E_INVALID). */
+typedef enum { ESMDIFF_PRECISION_BF16 = 0, ESMDIFF_PRECISION_F32 = 1 } esmdiff_precision;
+
 /* Hyper-parameters of CustomizedESM3 (net.py:322-332) + TimestepEmbedder (net.py:487) +
  * StructureOutputHeads (net.py:299); values for ESM3-open: 1536 / 24 / 48 / 4096 / 4101 / 256. */
 typedef struct {
@@ -66,6 +76,7 @@ typedef struct {
   int32_t max_len;      /* tokens incl. BOS/EOS */
   float residue_scale;  /* sqrt(n_layers/36) — esm TransformerStack */
   int32_t time_conditioning; /* mdlm.yaml:41 */
+  int32_t precision;    /* esmdiff_precision (ABI 4) */
 } esmdiff_config;
 
 /* One state-dict entry.  `name` uses the reference's key layout for the ESMDiff
@@ -167,6 +178,16 @@ typedef enum {
 
 int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N,
                       int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream);
+
+/* The strict path's linear (csrc/strict.hip): out f32 [M,ldc] = epi(A f32 [M,K] (row stride lda) . W f32 [N,K]^T), every
+ * product and sum in float32 on v_mfma_f32_32x32x2_f32; K % 32 == 0; columns >= n_valid are not written. */
+typedef enum {
+  ESMDIFF_F32EPI_STORE = 0,      /* out = acc (+ bias[N] when bias != NULL)                        */
+  ESMDIFF_F32EPI_BIAS_GELU = 1,  /* out = gelu(acc + bias), exact (erf) GELU                        */
+  ESMDIFF_F32EPI_RESID_DIV = 2   /* out = out + acc / div  (x + branch / scaling_factor, in place)  */
+} esmdiff_gemm_f32_epilogue;
+int esmdiff_gemm_f32(const float* A, int32_t lda, const float* W, float* out, const float* bias, int32_t M, int32_t N,
+                     int32_t K, int32_t ldc, int32_t n_valid, float div, int32_t epilogue, void* stream);
 
 /* The same GEMM as the engine issues it: with the engine's split-K workspace, so the small-M path (M < 1152 rows,
  * K >= 2048: FFN-down) runs as K slices + a fixed-order reduce kernel (csrc/gemm.hip).  Not re-entrant per engine. */

@@ -101,3 +101,37 @@ class GeometricAttentionRef(nn.Module):
         out = out.masked_fill(~mask[..., None], 0.0)                  # mask_and_zero_frameless
         y = self.out_proj(out)
         return (y, p, out) if return_parts else y
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# RMSD after rigid alignment — the quantity north_star states the decode bar in ("decoded backbone RMSD within 1e-4 A").
+# Restates /root/reference/slm/utils/geo_utils.py: _find_rigid_alignment :91-122 (Kabsch through the SVD of the
+# covariance, R = V U^T, no reflection fix — the reference has none) and squared_deviation :58-88.  PINNED: reproduces
+# tests/golden/g10_rmsd.npz, made by the reference's own functions (tests/golden/make_goldens_rmsd.py).
+def find_rigid_alignment(src: torch.Tensor, tgt: torch.Tensor):
+    """src, tgt (B, L, 3) -> R (B, 3, 3), t (B, 3) with R src + t ~ tgt."""
+    assert src.shape[-2] > 1
+    src_com, tgt_com = src.mean(dim=-2, keepdim=True), tgt.mean(dim=-2, keepdim=True)
+    H = (src - src_com).transpose(-2, -1).bmm(tgt - tgt_com)
+    U, _, Vh = torch.linalg.svd(H)
+    R = Vh.transpose(-2, -1).bmm(U.transpose(-2, -1))
+    t = tgt_com - R.bmm(src_com.transpose(-2, -1)).transpose(-2, -1)
+    return R, t.squeeze(-2)
+
+
+def squared_deviation(xyz1: torch.Tensor, xyz2: torch.Tensor, reduction: str = "none") -> torch.Tensor:
+    """Per-point squared deviation (B, L) of xyz1 aligned onto xyz2, or with reduction='rmsd' the RMSD (B,)."""
+    R, t = find_rigid_alignment(xyz1, xyz2)
+    aligned = R.bmm(xyz1.transpose(-2, -1)).transpose(-2, -1) + t.unsqueeze(1)
+    sd = ((aligned - xyz2) ** 2).sum(dim=-1)
+    if reduction == "none":
+        return sd
+    if reduction == "rmsd":
+        return torch.sqrt(sd.mean(dim=-1))
+    raise NotImplementedError(reduction)
+
+
+def backbone_rmsd(got: torch.Tensor, ref: torch.Tensor) -> torch.Tensor:
+    """(B, L, 3, 3) N/CA/C coordinates -> (B,) RMSD over all 3L backbone atoms after alignment, in float64."""
+    B = got.shape[0]
+    return squared_deviation(got.reshape(B, -1, 3).double(), ref.reshape(B, -1, 3).double(), reduction="rmsd")

@@ -1,0 +1,304 @@
+"""GPU parity tests of the float32 ("strict") precision path (csrc/strict.hip; run with -m gpu on an MI355X).
+
+north_star states two floating-point bars against the reference's own float32 arithmetic
+(/root/reference/slm/utils/checkpoint_utils.py:59-73 loads float32; /root/reference/slm/sample_esmdiff.py:40-61 decodes in it):
+  * "emitted structure-token ids match ... bit-exact under a fixed RNG seed" — /root/reference/slm/models/model.py:543-607
+  * "decoded backbone RMSD within 1e-4 A" — RMSD per /root/reference/slm/utils/geo_utils.py:58-122 (oracle.geom_ref, pinned to g10)
+The bf16 MFMA path cannot meet either literally (0.014 logit error flips near-ties; 0.05 A backbone error); this file checks that
+the strict path does, and measures how far the bf16 path's trajectory stays with the float32 chain.
+
+Every measured figure is written to gpurun_out/parity_strict.json (copied to profiles/ per round; DESIGN.md section 4 quotes it).
+"""
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+MASK, V = 4096, 4101
+_OUT = Path(__file__).resolve().parent.parent / "gpurun_out" / "parity_strict.json"
+
+
+def _record(key, val):
+    try:
+        _OUT.parent.mkdir(exist_ok=True)
+        cur = json.loads(_OUT.read_text()) if _OUT.exists() else {}
+        cur[key] = val
+        _OUT.write_text(json.dumps(cur, indent=1, sort_keys=True))
+    except OSError:
+        pass
+    print(key, json.dumps(val))
+
+
+def _seq(B, L, g):
+    return torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1)
+
+
+def _stats(got, ref):
+    err = (got - ref).abs()
+    return {"max_err": float(err.max()), "mean_err": float(err.mean()), "ref_std": float(ref.std()),
+            "argmax_agree": float((got.argmax(-1) == ref.argmax(-1)).float().mean())}
+
+
+# ---------------------------------------------------------------------------------------------------
+# the f32 GEMM alone
+@pytest.mark.parametrize("M,N,K", [(300, 4101, 1536), (130, 23, 1280), (517, 1536, 4096), (64, 50, 128), (1, 128, 32)])
+def test_gemm_f32_vs_float64(M, N, K):
+    """out = A W^T on v_mfma_f32_32x32x2_f32 against a float64 product: the error of an f32 fmaf chain is bounded by
+    ~K eps Sum|a w| in the worst case and grows like sqrt(K) eps in practice; ragged M and N (edge tiles, n_valid)."""
+    from esmdiff_amd import _native as N_
+    from esmdiff_amd.engine import gemm_f32
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = (torch.rand(N, K, generator=g) * 2 - 1) / K ** 0.5
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T
+    mag = A.double().abs() @ W.double().abs().T                     # Sum_k |a w| per output
+    got = gemm_f32(A.cuda(), W.cuda()).cpu()
+    rel = float(((got.double() - ref).abs() / mag).max())
+    assert rel < 2e-6, rel                                          # measured ~2e-7 (guide: 0.75-3.5e-7 up to K = 4096)
+    # bias + exact GELU
+    got = gemm_f32(A.cuda(), W.cuda(), N_.F32EPI_BIAS_GELU, bias=bias.cuda()).cpu()
+    want = torch.nn.functional.gelu(ref + bias.double())
+    assert bool(((got.double() - want).abs() <= 2e-6 * mag + 1e-6).all())     # gelu' <= 1.13
+    # residual: x + acc / div in place, only the valid columns touched
+    x0 = torch.randn(M, N + 3, generator=g)
+    x = x0.clone().cuda()
+    gemm_f32(A.cuda(), W.cuda(), N_.F32EPI_RESID_DIV, out=x[:, :N], div=1.1547005)
+    want = x0[:, :N].double() + ref / 1.1547005
+    assert bool(((x.cpu()[:, :N].double() - want).abs() <= 2e-6 * mag + 1e-6).all())
+    assert torch.equal(x.cpu()[:, N:], x0[:, N:])
+    # a row's result does not depend on the rows around it (fixed K order per output element)
+    if M > 4:
+        sub = gemm_f32(A[3:4].contiguous().cuda(), W.cuda()).cpu()
+        full = gemm_f32(A.cuda(), W.cuda()).cpu()
+        assert torch.equal(sub[0], full[3])
+
+
+# ---------------------------------------------------------------------------------------------------
+# forward: strict engine vs the f32 oracle network
+@pytest.mark.parametrize("layers,B,L", [(3, 2, 60), (3, 3, 258)])
+def test_strict_forward_production_width(layers, B, L):
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    from oracle.esm3_ref import build_from_state_dict
+    cfg = ModelConfig(n_layers=layers)
+    sd = random_init_state_dict(cfg, seed=5)
+    eng = Engine(cfg, sd, max_batch=B, max_len=L, precision="f32")
+    net, emb = build_from_state_dict(cfg, sd)
+    g = torch.Generator().manual_seed(L)
+    seq = _seq(B, L, g)
+    x = torch.full((B, L), MASK, dtype=torch.int64)
+    x[:, 5:20] = torch.randint(0, 4096, (B, 15), generator=g)
+    sch = ddpm_schedule(25)
+    i = 6
+    with torch.no_grad():
+        cond = torch.tile(emb(sch.sigma_t[i] * torch.ones(B))[:, None, :], (1, L, 1))
+        ref = net(structure_tokens=x, sequence_tokens=seq, auxiliary_embeddings=cond).structure_logits
+    got = eng.forward_logits(x.cuda(), seq.cuda(), sch.t_freq[i]).float().cpu()
+    # batch independence: sample 1 alone gives the very same bits
+    alone = eng.forward_logits(x[1:2].cuda(), seq[1:2].cuda(), sch.t_freq[i]).float().cpu()
+    eng.close()
+    s = _stats(got, ref)
+    _record(f"strict_wide{layers}_B{B}_L{L}", s)
+    assert s["max_err"] < 2e-5 and s["mean_err"] < 2e-6, s          # measured: see profiles/r03_parity_strict.json
+    assert s["argmax_agree"] == 1.0, s
+    assert torch.equal(alone[0], got[1])
+
+
+@pytest.fixture(scope="module")
+def full48():
+    """The full ESM3-open-sized model (48 blocks, random init) as a strict engine, a bf16 engine and the f32 oracle."""
+    from esmdiff_amd.config import ESM3_OPEN
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.weights import random_init_state_dict
+    from oracle.esm3_ref import build_from_state_dict
+    sd = random_init_state_dict(ESM3_OPEN, seed=11)
+    strict = Engine(ESM3_OPEN, sd, max_batch=4, max_len=258, precision="f32")
+    fast = Engine(ESM3_OPEN, sd, max_batch=4, max_len=258)
+    net, emb = build_from_state_dict(ESM3_OPEN, sd)
+    del sd
+    yield ESM3_OPEN, strict, fast, net, emb
+    strict.close()
+    fast.close()
+
+
+def _oracle_chain(net, emb, seq, sch, T, seed, offset=0, forced=None):
+    """The float32 reference chain: oracle forward (torch CPU f32) -> C-oracle sampler with Philox(seed, sample, step) noise
+    (model.py:543-581).  Returns the ids after every update [T + 1, B, L] and the logits of every step."""
+    from oracle import c_oracle
+    B, L = seq.shape
+    x = np.full((B, L), MASK, dtype=np.int64)
+    ids, logits = [], []
+    for i in range(T + 1):
+        fin = i == T
+        with torch.no_grad():
+            cond = torch.tile(emb(sch.sigma_t[i] * torch.ones(B))[:, None, :], (1, L, 1))
+            lg = net(structure_tokens=torch.from_numpy(x), sequence_tokens=seq, auxiliary_embeddings=cond).structure_logits.numpy()
+        x = c_oracle.ddpm_step(x, lg, 0.0 if fin else sch.mc_t[i].item(), 0.0 if fin else sch.mc_s[i].item(), final=fin,
+                               seed=seed, sample_offset=offset, step=i)
+        ids.append(x.copy())
+        logits.append(lg)
+    return np.stack(ids), logits
+
+
+def _engine_chain(eng, seq, sch, T, seed, offset=0, teacher=None):
+    """The engine's chain step by step through the C ABI (forward_logits + ddpm_step, Philox); with `teacher` (the oracle's
+    ids after every step) each step starts from the ORACLE's state instead of its own (per-step flip rate)."""
+    B, L = seq.shape
+    x = torch.full((B, L), MASK, dtype=torch.int64, device="cuda")
+    ids, errs = [], []
+    tf = eng.conditioning_rows(sch.t_freq)
+    for i in range(T + 1):
+        fin = i == T
+        if teacher is not None and i > 0:
+            x = torch.from_numpy(teacher[0][i - 1]).cuda()
+        lg = eng.forward_logits(x, seq.cuda(), tf[i])
+        if teacher is not None:
+            errs.append(float((lg.float().cpu() - torch.from_numpy(teacher[1][i])).abs().max()))
+        x = eng.ddpm_step(x.clone(), lg, 0.0 if fin else sch.mc_t[i].item(), 0.0 if fin else sch.mc_s[i].item(), final=fin,
+                          seed=seed, sample_offset=offset, step=i)
+        ids.append(x.cpu().numpy().copy())
+    return np.stack(ids), errs
+
+
+def test_strict_trajectory_configs0_ids_equal_oracle_chain(full48):
+    """BASELINE configs[0]'s shape (B = 4, L_tok = 60, 25 steps) on the full 48-block model: the strict engine's WHOLE
+    free-running trajectory — every id after every one of the 26 updates — equals the float32 oracle chain's under the
+    same Philox seed.  (A flip would need a near-tie of the exponential race closer than the f32 summation-order noise,
+    ~1e-6 relative; with 26 x 232 draws that is not expected, and the assertion says so.)"""
+    from esmdiff_amd.schedule import ddpm_schedule
+    cfg, strict, fast, net, emb = full48
+    B, L, T = 4, 60, 25
+    g = torch.Generator().manual_seed(60)
+    seq = _seq(B, L, g)
+    sch = ddpm_schedule(T, freq_dim=cfg.freq_dim)
+    ref_ids, ref_logits = _oracle_chain(net, emb, seq, sch, T, seed=17)
+    got_ids, _ = _engine_chain(strict, seq, sch, T, seed=17)
+    forced_ids, errs = _engine_chain(strict, seq, sch, T, seed=17, teacher=(ref_ids, ref_logits))
+    per_step = [float((got_ids[i] == ref_ids[i]).mean()) for i in range(T + 1)]
+    first_div = next((i for i, a in enumerate(per_step) if a < 1.0), None)
+    # the device loop (esmdiff_ddpm_sample) is the same chain
+    loop = strict.ddpm_sample(seq.cuda(), sch, seed=17).cpu().numpy()
+    rec = {"B": B, "L_tok": L, "steps": T, "layers": cfg.n_layers, "final_ids_equal": bool(np.array_equal(got_ids[-1], ref_ids[-1])),
+           "first_divergence_step": first_div, "min_per_step_agreement": min(per_step),
+           "max_abs_logit_err_teacher_forced": max(errs), "device_loop_equals_stepwise": bool(np.array_equal(loop, got_ids[-1]))}
+    _record("strict_full48_configs0_trajectory", rec)
+    assert rec["device_loop_equals_stepwise"], rec
+    assert rec["max_abs_logit_err_teacher_forced"] < 5e-5, rec
+    assert np.array_equal(forced_ids, ref_ids), rec                  # every single update, from the oracle's own states
+    assert rec["final_ids_equal"] and first_div is None, rec         # and the free-running chain never leaves it
+    # same chain on the bf16 engine, for the record: where does the throughput path leave the float32 chain?
+    fast_ids, _ = _engine_chain(fast, seq, sch, T, seed=17)
+    ff_ids, ferrs = _engine_chain(fast, seq, sch, T, seed=17, teacher=(ref_ids, ref_logits))
+    fper = [float((fast_ids[i] == ref_ids[i]).mean()) for i in range(T + 1)]
+    _record("bf16_full48_configs0_trajectory", {
+        "free_running_agreement_per_step": [round(a, 4) for a in fper],
+        "first_divergence_step": next((i for i, a in enumerate(fper) if a < 1.0), None),
+        "final_agreement": fper[-1],
+        "teacher_forced_flip_rate_per_step": [round(float((ff_ids[i] != ref_ids[i]).mean()), 5) for i in range(T + 1)],
+        "max_abs_logit_err_teacher_forced": max(ferrs)})
+
+
+def test_bf16_trajectory_agreement_configs1_shape(full48):
+    """The measurement VERDICT r02 asked for: the WHOLE 25-step ddpm trajectory at 48 blocks, B = 2, L_tok = 258 on the bf16
+    MFMA path against the float32 oracle chain — per-step id agreement free-running, first divergence, and the per-step
+    flip rate when every step starts from the oracle's state (teacher-forced).  The strict engine runs the same chain and
+    must stay ON the oracle chain in teacher-forced mode."""
+    from esmdiff_amd.schedule import ddpm_schedule
+    cfg, strict, fast, net, emb = full48
+    B, L, T = 2, 258, 25
+    g = torch.Generator().manual_seed(258)
+    seq = _seq(B, L, g)
+    sch = ddpm_schedule(T, freq_dim=cfg.freq_dim)
+    ref_ids, ref_logits = _oracle_chain(net, emb, seq, sch, T, seed=23)
+    rec = {"B": B, "L_tok": L, "steps": T, "layers": cfg.n_layers}
+    for name, eng in (("bf16", fast), ("f32", strict)):
+        free, _ = _engine_chain(eng, seq, sch, T, seed=23)
+        forced, errs = _engine_chain(eng, seq, sch, T, seed=23, teacher=(ref_ids, ref_logits))
+        per = [float((free[i] == ref_ids[i]).mean()) for i in range(T + 1)]
+        flips = [int((forced[i] != ref_ids[i]).sum()) for i in range(T + 1)]
+        rec[name] = {"free_running_agreement_per_step": [round(a, 4) for a in per],
+                     "first_divergence_step": next((i for i, a in enumerate(per) if a < 1.0), None),
+                     "final_agreement": per[-1],
+                     "teacher_forced_flips_per_step": flips, "teacher_forced_flips_total": int(sum(flips)),
+                     "draws_total": int(B * (L) * (T + 1)),
+                     "max_abs_logit_err_teacher_forced": max(errs)}
+    _record("full48_configs1_shape_trajectory", rec)
+    assert rec["f32"]["teacher_forced_flips_total"] == 0, rec["f32"]
+    assert rec["f32"]["final_agreement"] == 1.0, rec["f32"]
+    assert rec["f32"]["max_abs_logit_err_teacher_forced"] < 5e-5, rec["f32"]
+    # the throughput path: logits within the bf16 bar at every step of the trajectory, flips rare per step
+    assert rec["bf16"]["max_abs_logit_err_teacher_forced"] < 0.04, rec["bf16"]
+    assert rec["bf16"]["teacher_forced_flips_total"] <= 0.02 * rec["bf16"]["draws_total"], rec["bf16"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# decoder: RMSD <= 1e-4 A
+def test_structure_decoder_full_depth_rmsd_1e4():
+    """The shipped decoder shape (d 1280 / 20 heads / ALL 30 blocks) at its default precision (f32) against oracle/decoder_ref.py:
+    backbone RMSD after rigid alignment (geo_utils.py:58-122 restated in oracle.geom_ref, pinned to g10) <= 1e-4 A — the
+    tolerance north_star states for this output — and without alignment too; pLDDT to 1e-5."""
+    from esmdiff_amd.config import DecoderConfig
+    from esmdiff_amd.engine import StructureDecoder
+    from esmdiff_amd.weights import random_init_decoder_state_dict
+    from oracle.decoder_ref import build_decoder_from_state_dict
+    from oracle.geom_ref import backbone_rmsd
+    cfg = DecoderConfig()
+    assert (cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden) == (1280, 20, 30, 3584)
+    sd = random_init_decoder_state_dict(cfg, seed=6)
+    ref_net = build_decoder_from_state_dict(cfg, sd)
+    rec = {}
+    dec = StructureDecoder(cfg, sd, max_batch=3, max_len=258)
+    assert dec.precision == "f32"
+    for B, L in ((2, 130), (3, 258)):
+        g = torch.Generator().manual_seed(9 + L)
+        tok = torch.randint(0, 4096, (B, L), generator=g)
+        tok[:, 0], tok[:, -1] = 4098, 4097
+        with torch.no_grad():
+            ref, pl_ref = ref_net(tok, return_plddt=True)
+            ptm_ref, pae_ref = ref_net.confidence(tok)
+        got, pl, ptm, pae = dec.decode(tok.cuda(), return_plddt=True, return_ptm=True, return_pae=True)
+        got, pl = got.cpu(), pl.cpu()
+        dev = (got - ref).norm(dim=-1)
+        rmsd = backbone_rmsd(got, ref)
+        rec[f"B{B}_L{L}"] = {"rmsd_aligned_A": [float(v) for v in rmsd], "max_atom_dev_A": float(dev.max()),
+                             "rmsd_unaligned_A": float(torch.sqrt((dev.double() ** 2).mean())),
+                             "coord_abs_max_A": float(ref.abs().max()),
+                             "plddt_err": float((pl - pl_ref).abs().max()), "ptm_err": float((ptm.cpu() - ptm_ref).abs().max()),
+                             "pae_mean_A": float((pae.cpu() - pae_ref).abs().mean())}
+        assert float(rmsd.max()) <= 1e-4, rec
+        assert float(dev.max()) <= 5e-4, rec
+        assert rec[f"B{B}_L{L}"]["plddt_err"] < 1e-5, rec
+        assert rec[f"B{B}_L{L}"]["ptm_err"] < 5e-3 and rec[f"B{B}_L{L}"]["pae_mean_A"] < 0.12, rec   # bf16 pairwise pipeline
+    dec.close()
+    # the bf16 decoder for the record (r02's path): same tokens, RMSD
+    fast = StructureDecoder(cfg, sd, max_batch=3, max_len=258, precision="bf16")
+    got = fast.decode(tok.cuda()).cpu()
+    rec["bf16_B3_L258_rmsd_aligned_A"] = [float(v) for v in backbone_rmsd(got, ref)]
+    fast.close()
+    _record("decoder1280_30blocks_f32", rec)
+    assert max(rec["bf16_B3_L258_rmsd_aligned_A"]) < 0.3, rec
+
+
+def test_strict_engine_refuses_what_it_does_not_build():
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.geometry import build_affine3d_from_coordinates
+    from esmdiff_amd.weights import random_init_state_dict
+    sd = random_init_state_dict(TINY, seed=1, with_geom=True)
+    with pytest.raises(ValueError):
+        Engine(TINY, sd, max_batch=2, max_len=16, precision="fp8")
+    eng = Engine(TINY, sd, max_batch=2, max_len=16, precision="f32")
+    xyz = torch.randn(2, 16, 3, 3)
+    with pytest.raises(RuntimeError, match="strict"):
+        eng.set_frames(*build_affine3d_from_coordinates(xyz))
+    with pytest.raises(RuntimeError, match="strict"):
+        eng.attention(torch.zeros(32, 3 * TINY.d_model, dtype=torch.bfloat16, device="cuda"),
+                      torch.ones(TINY.d_model), torch.ones(TINY.d_model), 2, 16)
+    eng.close()

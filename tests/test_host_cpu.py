@@ -42,7 +42,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(str(lib_path))
     for name in declared:
         assert hasattr(L, name), name
-    assert L.esmdiff_abi_version() == 3
+    assert L.esmdiff_abi_version() == 4
 
 
 def test_config_dimensions():

@@ -189,3 +189,25 @@ def test_philox_known_answer():
         0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
     u = c_oracle.philox_uniforms(7, 3, 2, 5)
     assert u.min() >= 0.0 and u.max() < 1.0 and abs(u.mean() - 0.5) < 0.02
+
+
+def test_g10_rmsd_after_alignment(golden_dir):
+    """oracle.geom_ref.squared_deviation / find_rigid_alignment vs the reference's geo_utils.py:58-122 (the RMSD the decode
+    bar is stated in): fixture made by the reference's own functions."""
+    from oracle.geom_ref import backbone_rmsd, find_rigid_alignment, squared_deviation
+    g = np.load(golden_dir / "g10_rmsd.npz")
+    src, tgt = torch.as_tensor(g["src"]), torch.as_tensor(g["tgt"])
+    rmsd = squared_deviation(src, tgt, reduction="rmsd").numpy()
+    sd = squared_deviation(src, tgt).numpy()
+    # torch.svd (the reference) and torch.linalg.svd may differ in the last bits; the noise-free pair is ~1e-14 either way
+    np.testing.assert_allclose(rmsd[1:], g["rmsd"][1:], rtol=1e-9)
+    assert rmsd[0] < 1e-12 and g["rmsd"][0] < 1e-12
+    np.testing.assert_allclose(sd[1:], g["sd"][1:], rtol=1e-7, atol=1e-18)
+    np.testing.assert_allclose(g["rmsd_np_entry"], g["rmsd"], rtol=0, atol=0)
+    R, t = find_rigid_alignment(src, tgt)
+    np.testing.assert_allclose(R.numpy(), g["R"], atol=1e-12)
+    np.testing.assert_allclose(t.numpy(), g["t"], atol=1e-10)
+    # the backbone wrapper is the same function over the flattened atoms
+    bb = torch.as_tensor(g["src"]).reshape(5, 16, 3, 3)
+    bt = torch.as_tensor(g["tgt"]).reshape(5, 16, 3, 3)
+    np.testing.assert_allclose(backbone_rmsd(bb, bt).numpy()[1:], g["rmsd"][1:], rtol=1e-9)
