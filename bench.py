@@ -284,10 +284,13 @@ def main():
     ap.add_argument("--stub-engine", action="store_true",
                     help="CI only: a CPU stand-in engine (tests/standin_engine.py) over the gloo backend — exercises the launch, "
                          "process-group, gather and reporting path of this script without a GPU; prints data=debug-stub-engine")
+    ap.add_argument("--spawn", action="store_true",
+                    help="go through the launcher path (torch.distributed.run, process group, RCCL gather) even at --gpus 1: the "
+                         "multi-GPU code path on a one-GPU box")
     args = ap.parse_args()
 
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
-    if args.gpus > 1 and not launched:
+    if (args.gpus > 1 or args.spawn) and not launched:
         raise SystemExit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

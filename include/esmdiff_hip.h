@@ -76,7 +76,7 @@ typedef struct {
   int32_t max_len;      /* tokens incl. BOS/EOS */
   float residue_scale;  /* sqrt(n_layers/36) — esm TransformerStack */
   int32_t time_conditioning; /* mdlm.yaml:41 */
-  int32_t precision;    /* esmdiff_precision (ABI 4) */
+  int32_t precision;    /* one of the esmdiff_precision values; new in ABI 4 */
 } esmdiff_config;
 
 /* One state-dict entry.  `name` uses the reference's key layout for the ESMDiff

@@ -301,3 +301,40 @@ def test_cli_argparser_matches_reference_defaults():
     a = get_argparser([])
     assert (a.input, a.ckpt, a.output, a.mode, a.num_steps, a.num_samples, a.mask_ids) == (
         "data/targets/bpti", None, "output/inference_esmdiff", "gibbs", 25, 10, None)
+
+
+def _run_bench(extra, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py")] + extra, capture_output=True, text=True, timeout=timeout, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                  # ONE JSON line whatever the number of ranks
+    return json.loads(lines[0])
+
+
+def test_bench_self_spawns_ranks_world2_gloo_stub():
+    """`python bench.py --gpus 2` with NO launcher (the form the driver used for --gpus 1): the script re-executes itself under
+    torch.distributed.run, both ranks join a process group, shard by global sample index, all_gather the int16 ids, take the
+    max-over-ranks time, and rank 0 prints ONE JSON line.  CPU stand-in engine + gloo here; the GPU suite runs the same
+    branch with the real engine over RCCL (tests/test_gpu_dist.py)."""
+    out = _run_bench(["--gpus", "2", "--stub-engine", "--tiny", "--steps", "2", "--warmup", "1", "--samples-per-gpu", "3",
+                      "--residues", "10"])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["data"] == "debug-stub-engine" and out["roofline"] is None
+    assert "sample-sharded x2" in out["config"]["parallelism"]
+    # whole-job value: samples of BOTH ranks / max-over-ranks time
+    assert abs(out["value"] - 2 * 3 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-3
+
+
+def test_bench_refuses_mismatched_world(monkeypatch):
+    """Under a launcher the world size must equal --gpus (a silent mismatch would mis-report n_gpus)."""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--stub-engine", "--tiny"], capture_output=True,
+                       text=True, timeout=120, env=env, cwd=root)
+    assert r.returncode != 0 and "--nproc-per-node 2" in r.stderr
