@@ -114,7 +114,10 @@ def tica_fit(x: torch.Tensor, lagtime: int, dim: int = 2, epsilon: float = 1e-6)
     wh = u[:, keep] / torch.sqrt(s[keep])                        # whitening: wh^T c00 wh = I
     lam, v = torch.linalg.eigh(wh.T @ c0t @ wh)
     order = torch.argsort(lam.abs(), descending=True)[:dim]
-    return mean, wh @ v[:, order]
+    # deeptime's TICA defaults to scaling="kinetic_map": the projected coordinates are the whitened eigenfunctions TIMES
+    # their eigenvalues.  The JS value does not depend on it (the histogram range follows the reference
+    # projection), the returned TIC coordinates do.  The sign of each TIC is arbitrary (an eigenvector's sign).
+    return mean, (wh @ v[:, order]) * lam[order]
 
 
 def js_tica(ca_coords_dict, ref_key: str = "target", n_bins: int = 50, lagtime: int = 20, return_tic: bool = True,

@@ -26,7 +26,7 @@ from .weights import load_checkpoint_state_dict, random_init_state_dict
 class MaskedDiffusionLanguageModeling:
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: ModelConfig = ESM3_OPEN,
                  noise_schedule: Optional[Noise] = None, max_batch: int = 128, max_len: int = 1026,
-                 device: int = 0, noise_removal: bool = True):
+                 device: int = 0, noise_removal: bool = True, precision: str = "bf16"):
         if noise_schedule is None:
             print("Using default noise schedule: CosineNoise(eps=1e-3)")    # model.py:345-347
             noise_schedule = CosineNoise(eps=1e-3)
@@ -37,7 +37,7 @@ class MaskedDiffusionLanguageModeling:
         self.vocab_size = STRUCTURE_VOCAB
         self.mask_index = STRUCTURE_MASK_TOKEN
         self.neg_infinity = -1000000.0
-        self.net = Engine(cfg, state_dict, max_batch=max_batch, max_len=max_len, device=device)
+        self.net = Engine(cfg, state_dict, max_batch=max_batch, max_len=max_len, device=device, precision=precision)
         self.device = self.net.device
         self._parity_gen = None      # noise="torch-cpu": ONE generator stream per run, like the reference's global RNG
         self._parity_seed = None
@@ -47,6 +47,14 @@ class MaskedDiffusionLanguageModeling:
 
     def to(self, device):
         return self
+
+    def reset_parity_stream(self, seed: int) -> None:
+        """noise="torch-cpu": restart the replay of the reference's process-wide torch.rand stream at `seed` — what a
+        torch.manual_seed(seed) before the reference's first ddpm_sample does (the reference itself never re-seeds, so
+        every later batch and target runs on in the same stream).  Implicit at the first parity call of a model and when
+        the seed changes; tests that replay the reference's goldens call it where the golden script seeded."""
+        self._parity_gen = torch.Generator().manual_seed(seed)         # same mt19937 stream as torch.manual_seed(seed)
+        self._parity_seed = seed
 
     def _sample_prior(self, *batch_dims):
         return self.mask_index * torch.ones(*batch_dims, dtype=torch.int64)
@@ -74,12 +82,12 @@ class MaskedDiffusionLanguageModeling:
         tf = self.net.conditioning_rows(sch.t_freq)
         tf = [None] * (num_steps + 1) if tf is None else tf
         if noise == "torch-cpu":
-            # The reference never re-seeds between batches: torch.rand_like keeps consuming ONE process-wide CPU stream
-            # (model.py:27).  A private generator restarts that stream at the first batch of a run (global sample 0, or
-            # a new seed) and runs on through the later batches, so equally sized batches do not repeat each other.
-            if self._parity_gen is None or self._parity_seed != seed or sample_offset == 0:
-                self._parity_gen = torch.Generator().manual_seed(seed)     # same mt19937 stream as torch.manual_seed(seed)
-                self._parity_seed = seed
+            # The reference never seeds inside its sampling path: torch.rand_like keeps consuming the ONE process-wide CPU
+            # stream (model.py:27) across batches AND across targets, from wherever the caller's torch.manual_seed left it.  The
+            # private generator below is that stream: created at the first parity call of a run (or when the seed
+            # changes, or after reset_parity_stream()) and never restarted per target or per batch.
+            if self._parity_gen is None or self._parity_seed != seed:
+                self.reset_parity_stream(seed)
             gen = self._parity_gen
         elif noise != "philox":
             raise ValueError(f"unknown noise source {noise!r}")
@@ -117,7 +125,7 @@ def config_from_hydra_yaml(path, cfg: ModelConfig = ESM3_OPEN):
 
 
 def load_state_dict_from_lightning_ckpt(ckpt_path, device="cuda", max_batch: int = 128, max_len: int = 1026,
-                                        cfg: ModelConfig = ESM3_OPEN):
+                                        cfg: ModelConfig = ESM3_OPEN, precision: str = "bf16"):
     """/root/reference/slm/utils/checkpoint_utils.py:41-74: a `.pt` whose 'module' dict holds `net.*` and
     `sigma_embedder.*`; the model is what the run's `.hydra/config.yaml` says when that file sits where the reference
     looks for it (:45-50), else the mdlm.yaml configuration (LogLinearNoise, time conditioning, 4101-way head);
@@ -133,12 +141,12 @@ def load_state_dict_from_lightning_ckpt(ckpt_path, device="cuda", max_batch: int
     print(f"Loaded experiment config: {exp_cfg_path or 'mdlm.yaml defaults'}...")
     sd = load_checkpoint_state_dict(ckpt_path)
     dev = torch.device(device).index or 0
-    model = MaskedDiffusionLanguageModeling(sd, cfg, noise, max_batch, max_len, dev, noise_removal=True)
+    model = MaskedDiffusionLanguageModeling(sd, cfg, noise, max_batch, max_len, dev, noise_removal=True, precision=precision)
     print(f"Sucessfully loaded model from {ckpt_path}...")
     return model
 
 
-def load_stock_esm3(path, device="cuda", max_batch: int = 128, max_len: int = 1026):
+def load_stock_esm3(path, device="cuda", max_batch: int = 128, max_len: int = 1026, precision: str = "bf16"):
     """The pre-trained ESM3 the reference uses when --ckpt is absent (`ESM3.from_pretrained("esm3_sm_open_v1")`,
     /root/reference/slm/sample_esmdiff.py:37, :252-255; gibbs mode only): a plain esm state dict (keys without the
     `net.` prefix, 4096-way structure head, no sigma_embedder) saved with torch.save."""
@@ -146,11 +154,13 @@ def load_stock_esm3(path, device="cuda", max_batch: int = 128, max_len: int = 10
     sd = torch.load(path, map_location="cpu", weights_only=True)
     sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
     dev = torch.device(device).index or 0
-    return MaskedDiffusionLanguageModeling(sd, ESM3_OPEN_STOCK, None, max_batch, max_len, dev, noise_removal=True)
+    return MaskedDiffusionLanguageModeling(sd, ESM3_OPEN_STOCK, None, max_batch, max_len, dev, noise_removal=True,
+                                           precision=precision)
 
 
 def random_init_model(cfg: ModelConfig = ESM3_OPEN, seed: int = 0, max_batch: int = 128, max_len: int = 1026,
-                      device: int = 0):
+                      device: int = 0, precision: str = "bf16"):
     """ESM3-open-sized random weights (no checkpoint can be fetched offline): synthetic benchmarking / tests."""
     sd = random_init_state_dict(cfg, seed=seed, device=f"cuda:{device}", with_geom=True)   # real checkpoints carry geom_attn too
-    return MaskedDiffusionLanguageModeling(sd, cfg, LogLinearNoise(), max_batch, max_len, device, noise_removal=True)
+    return MaskedDiffusionLanguageModeling(sd, cfg, LogLinearNoise(), max_batch, max_len, device, noise_removal=True,
+                                           precision=precision)

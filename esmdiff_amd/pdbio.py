@@ -87,9 +87,13 @@ def write_backbone_pdb(path, sequence: str, coords: np.ndarray, bfactor: Optiona
     """N/CA/C backbone (+ the inferred carbonyl O, as the reference's decoded chains carry it) as ATOM records."""
     lines, serial = [], 1
     coords = np.asarray(coords)
-    if with_oxygen and coords.shape[0] == len(sequence) and coords.shape[0] > 0:
-        coords = np.concatenate([coords[:, :3], infer_oxygen(coords)[:, None]], axis=1)
-    atoms = (("N", "N"), ("CA", "C"), ("C", "C"), ("O", "O"))[:coords.shape[1] if coords.ndim == 3 else 3]
+    if coords.ndim == 3:
+        coords = coords[:, :3]       # N, CA, C only: a 4th / 5th input column (atom37: CB, O) is never written under another name
+    n_atoms = 3
+    if with_oxygen and coords.ndim == 3 and coords.shape[0] == len(sequence) and coords.shape[0] > 0:
+        coords = np.concatenate([coords, infer_oxygen(coords)[:, None]], axis=1)
+        n_atoms = 4                  # the O column exists only when it was inferred here
+    atoms = (("N", "N"), ("CA", "C"), ("C", "C"), ("O", "O"))[:n_atoms]
     for i, aa in enumerate(sequence):
         for j, (name, elem) in enumerate(atoms):
             x, y, z = (float(v) for v in coords[i, j])

@@ -38,11 +38,19 @@ from .sdk import ESMProtein, encode_sequence
 DEFAULT_NMAX = 1026 * 1026 * 32
 
 
+def mask_ids_given(args) -> bool:
+    return bool(getattr(args, "mask_ids", None))
+
+
 def batch_sizes(n_tokens: int, num_samples: int, n_max_residue_square: int = DEFAULT_NMAX, cap: int = 0):
     """sample_esmdiff.py:181-193 (the length is the TOKEN count in ddpm mode, the residue count in gibbs mode).  The
     reference's arithmetic can make the remainder batch larger than the regular ones; `cap` (the engine's max_batch)
-    additionally splits any batch the engine could not hold — samples are independent and the noise is keyed by the
-    global sample index, so the split does not change a single id."""
+    additionally splits any batch the engine could not hold — samples are independent and the Philox noise is keyed by the
+    global sample index, so the split draws the same noise for every sample.  The LOGITS may differ at bf16 rounding level
+    between two splits (the engine picks its GEMM kernel, stream count and small-batch path by row count, DESIGN 3.1b /
+    3.8), so a near-tie can resolve to another id; an engine created with precision="f32" is batch-independent bit for bit.
+    In --parity mode (the reference's torch.rand stream, drawn per batch) a cap split would reorder that stream: the CLI
+    refuses it there."""
     sq = n_tokens * n_tokens
     total = sq * num_samples
     bsz = [n_max_residue_square // sq] * (total // n_max_residue_square)
@@ -173,6 +181,10 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
     outs = []
     done = 0
     cap = getattr(getattr(model, "net", model), "max_batch", 0)
+    if noise == "torch-cpu" and count and batch_sizes(seq_tok.numel(), count, n_max_residue_square, cap) != \
+            batch_sizes(seq_tok.numel(), count, n_max_residue_square):
+        raise ValueError(f"--parity replays the reference's per-batch torch.rand stream, but the engine capacity ({cap}) would "
+                         "split the reference's batches and reorder it: build the engine with a larger max_batch")
     for bs in batch_sizes(seq_tok.numel(), count, n_max_residue_square, cap) if count else []:
         batch = seq_tok[None, :].repeat(bs, 1)
         prior = None
@@ -199,6 +211,8 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
         (output_dir / f"{sample_basename}.json").write_text(json.dumps(
             {"sequence": sequence, "num_steps": num_steps, "num_samples": num_samples, "eps": eps, "seed": seed,
              "noise": noise, "world_size": world, "sampling_seconds": round(sample_t, 3),
+             "precision": getattr(getattr(model, "net", model), "precision", None),
+             "decoder_precision": getattr(decoder, "precision", None),
              **({} if ptm is None else {"ptm": [round(float(v), 4) for v in ptm.cpu()]})}, indent=1))
         if coords is not None:
             write_models_pdb(coords, plddt, sequence, output_dir / f"{sample_basename}.pdb", sample_basename)
@@ -315,6 +329,12 @@ def get_argparser(argv=None):
     p.add_argument("--synthetic_len", type=int, default=0, help="sample a random sequence of this length")
     p.add_argument("--n_max_residue_square", type=int, default=DEFAULT_NMAX)
     p.add_argument("--parity", action="store_true", help="uniforms from torch's CPU generator, like the reference")
+    p.add_argument("--precision", choices=["bf16", "f32"], default="bf16",
+                   help="arithmetic of the sampling network: bf16 = the MFMA throughput path (default); f32 = the strict path, the "
+                        "reference's own float32 arithmetic (ids equal to a float32 run of the same seed; ~1/12 of the throughput; "
+                        "no coordinate conditioning)")
+    p.add_argument("--decoder_precision", choices=["f32", "bf16"], default="f32",
+                   help="arithmetic of the structure decoder: f32 (default, backbone within 1e-4 A of a float32 decode) or bf16")
     p.add_argument("--no_timestamp", action="store_true")
     return p.parse_args(argv)
 
@@ -338,6 +358,9 @@ def main(argv=None):
                          "--random_init (synthetic weights)")
     if args.esm3_ckpt and args.ckpt is None:
         assert args.mode == "gibbs", "Only Gibbs sampling is supported for the pre-trained ESM3 model."
+    if args.precision == "f32" and mask_ids_given(args) and args.mode == "gibbs":
+        raise SystemExit("--precision f32 has no coordinate conditioning (gibbs-mode inpainting hands the known backbone to block "
+                         "0's geometric attention): use --precision bf16, or --mode ddpm whose prior is token-space")
     if args.parity and world > 1:
         raise SystemExit("--parity replays the reference's single-process torch.rand stream; it cannot be sharded over "
                          "ranks (every rank would draw the same uniforms) — run it on one GPU")
@@ -369,13 +392,14 @@ def main(argv=None):
     if args.random_init:
         from .config import ESM3_OPEN, TINY
         model = random_init_model(TINY if args.tiny else ESM3_OPEN, seed=args.seed, max_batch=max_b, max_len=max_len,
-                                  device=local_rank)
+                                  device=local_rank, precision=args.precision)
     elif args.ckpt is None:
         from .model import load_stock_esm3
-        model = load_stock_esm3(args.esm3_ckpt, device=f"cuda:{local_rank}", max_batch=max_b, max_len=max_len)
+        model = load_stock_esm3(args.esm3_ckpt, device=f"cuda:{local_rank}", max_batch=max_b, max_len=max_len,
+                                precision=args.precision)
     else:
         model = load_state_dict_from_lightning_ckpt(args.ckpt, device=f"cuda:{local_rank}", max_batch=max_b,
-                                                    max_len=max_len)
+                                                    max_len=max_len, precision=args.precision)
     decoder = None
     if args.decoder_ckpt or args.random_init_decoder:          # one per rank: each rank decodes its own shard
         from .config import STRUCTURE_DECODER_V0, TINY_DECODER
@@ -386,7 +410,8 @@ def main(argv=None):
             dsd = torch.load(args.decoder_ckpt, map_location="cpu", weights_only=True)
         else:
             dsd = random_init_decoder_state_dict(dcfg, seed=args.seed, device=f"cuda:{local_rank}")
-        decoder = StructureDecoder(dcfg, dsd, max_batch=64, max_len=max_len, device=local_rank)
+        decoder = StructureDecoder(dcfg, dsd, max_batch=64, max_len=max_len, device=local_rank,
+                                   precision=args.decoder_precision)
     encoder = None
     if args.encoder_ckpt or args.random_init_encoder:
         from .config import STRUCTURE_ENCODER_V0, TINY_ENCODER

@@ -287,7 +287,7 @@ def test_structure_decoder_production_width():
     assert (cfg.d_model, cfg.n_heads, cfg.ffn_hidden) == (1280, 20, 3584)
     sd = random_init_decoder_state_dict(cfg, seed=4)
     ref_net = build_decoder_from_state_dict(cfg, sd)
-    dec = StructureDecoder(cfg, sd, max_batch=3, max_len=260)
+    dec = StructureDecoder(cfg, sd, max_batch=3, max_len=260, precision="bf16")   # the MFMA path (f32 default: test_gpu_strict.py)
     rec = {}
     for B, L in ((3, 60), (2, 258)):
         g = torch.Generator().manual_seed(L)
@@ -301,7 +301,7 @@ def test_structure_decoder_production_width():
         assert float(((got[:, :, 1] - got[:, :, 2]).norm(dim=-1) - 1.5251).abs().max()) < 2e-3
         err = (got - ref).norm(dim=-1)
         rec[f"B{B}_L{L}"] = {"mean_A": float(err.mean()), "max_A": float(err.max())}
-        assert float(err.mean()) < 0.08 and float(err.max()) < 0.3, rec       # measured 0.038 / 0.107 A
+        assert float(err.mean()) < 0.076 and float(err.max()) < 0.22, rec      # measured 0.038 / 0.107 A: bars at 2x
         with torch.no_grad():
             ptm_ref, pae_ref = ref_net.confidence(tok)
         _, ptm, pae = dec.decode(tok.cuda(), return_ptm=True, return_pae=True)
@@ -331,15 +331,15 @@ def test_structure_decoder_full_depth():
     with torch.no_grad():
         ref, pl_ref = ref_net(tok, return_plddt=True)
         ptm_ref, pae_ref = ref_net.confidence(tok)
-    dec = StructureDecoder(cfg, sd, max_batch=B, max_len=L)
+    dec = StructureDecoder(cfg, sd, max_batch=B, max_len=L, precision="bf16")      # the MFMA path (f32 default: test_gpu_strict.py)
     got, pl, ptm, pae = dec.decode(tok.cuda(), return_plddt=True, return_ptm=True, return_pae=True)
     err = (got.cpu() - ref).norm(dim=-1)
     e_pae = (pae.cpu() - pae_ref).abs()
     rec = {"mean_A": float(err.mean()), "max_A": float(err.max()), "plddt_err": float((pl.cpu() - pl_ref).abs().max()),
            "ptm_err": float((ptm.cpu() - ptm_ref).abs().max()), "pae_max_A": float(e_pae.max()), "pae_mean_A": float(e_pae.mean())}
     _record("decoder1280_30blocks_B2_L130", rec)
-    assert rec["mean_A"] < 0.15 and rec["max_A"] < 0.8, rec
-    assert rec["plddt_err"] < 1e-2 and rec["ptm_err"] < 5e-3 and rec["pae_mean_A"] < 0.12, rec
+    assert rec["mean_A"] < 0.1 and rec["max_A"] < 0.25, rec                        # measured 0.049 / 0.125 A: bars at 2x
+    assert rec["plddt_err"] < 2e-3 and rec["ptm_err"] < 3e-3 and rec["pae_mean_A"] < 0.07, rec   # measured 4e-4 / 7e-4 / 0.031
     dec.close()
 
 
@@ -388,10 +388,11 @@ def test_structure_encoder_full_size_margin(B, L):
 def test_full_model_configs_3_and_4_token_counts():
     """configs[3]: 32 x 1024 residues (L_tok 1026: tiled-key attention, 32 832 rows through the two-stream forward);
     configs[4]: 100 x 256 residues with an inpainting prior (64 residues masked, the rest carried through input_prior).
-    Full ESM3-open-sized engine, num_steps cut to 3 (the step count only repeats the same launches); what must hold at
-    any size: no MASK left, ids in range, known tokens untouched, determinism, and independence of the batch composition
-    (a sample drawn alone at its global index equals the same sample drawn inside the batch: Philox by global index and
-    row-independent kernels)."""
+    Full ESM3-open-sized engine; configs[3] with num_steps cut to 3 (the step count only repeats the same launches),
+    configs[4] at its REAL 50 steps (51 forwards of 100 x 258 tokens).  What must hold at any size: no MASK left, ids in
+    range, known tokens untouched, determinism, and independence of the batch composition — a half batch drawn at its
+    global offset equals the same samples drawn inside the whole batch EXACTLY (Philox by global index; both sizes run
+    the same kernels with the same K order per output element, tests/test_gpu_fullwidth.py::test_logits_across_dispatch_paths)."""
     from esmdiff_amd.config import ESM3_OPEN
     from esmdiff_amd.engine import Engine
     from esmdiff_amd.schedule import ddpm_schedule
@@ -409,16 +410,55 @@ def test_full_model_configs_3_and_4_token_counts():
     again = eng.ddpm_sample(seq, sch, seed=21, sample_offset=0).cpu()
     assert torch.equal(out, again)
     half = eng.ddpm_sample(seq[16:], sch, seed=21, sample_offset=16).cpu()       # 16 x 1026 = 16 416 tokens: still two streams
-    agree = float((half == out[16:]).float().mean())
-    assert agree > 0.999, agree                                                   # same kernels -> same ids (ties aside)
+    assert torch.equal(half, out[16:])                                            # same kernels, same K order -> same ids
     # configs[4]
     B, L = 100, 258
     seq = _seq(B, L, g).cuda()
     prior = torch.randint(0, 4096, (1, L), generator=g).repeat(B, 1)
     prior[:, 0], prior[:, -1] = 4098, 4097
     prior[:, 96:160] = MASK
-    out = eng.ddpm_sample(seq, sch, seed=5, input_prior=prior.cuda()).cpu()
+    out = eng.ddpm_sample(seq, ddpm_schedule(50), seed=5, input_prior=prior.cuda()).cpu()   # configs[4]: num_steps = 50
     keep = prior != MASK
     assert torch.equal(out[keep], prior[keep]) and int((out == MASK).sum()) == 0
     assert len({tuple(r) for r in out[:, 96:160].tolist()}) > 90                  # the masked stretch really is sampled per sample
     eng.close()
+
+
+def test_logits_across_dispatch_paths():
+    """Which engine-internal switches can change a sample's logits (and so, at a near-tie, an id)?  The same sample is run
+    inside batches that take every dispatch path at L_tok = 258 (production width, 3 blocks):
+      B = 2 / 4   small-batch path (< 1 152 rows: f32 K-slice planes summed in the LayerNorm, 128-column kernel)
+      B = 6       regular path, one stream, 128-column GEMM kernel (1 548 rows)
+      B = 12      two streams of 1 548 rows
+      B = 40      two streams; N = 1536 linears on the 256x256 kernel, the rest mixed
+      B = 100     two streams of 12 900 rows, 256x256 four-wave kernel everywhere (the benchmark's shape)
+    Asserted: every REGULAR path gives the very same bits (the K order per output element does not depend on the tile
+    shape, the stream count or the batch), so ids cannot depend on how a large batch is cut; the small-batch path differs
+    from it only at bf16-rounding level of the branch outputs (documented: DESIGN 3.8), within the forward-vs-oracle bar."""
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ModelConfig(n_layers=3)
+    sd = random_init_state_dict(cfg, seed=5)
+    L = 258
+    eng = Engine(cfg, sd, max_batch=100, max_len=L)
+    g = torch.Generator().manual_seed(3)
+    seq1 = _seq(1, L, g)
+    x1 = torch.full((1, L), MASK, dtype=torch.int64)
+    x1[:, 40:90] = torch.randint(0, 4096, (1, 50), generator=g)
+    tf = ddpm_schedule(25).t_freq[4]
+    rows = {}
+    for B in (2, 4, 6, 12, 40, 100):
+        # the probed sample sits LAST (second stream, last tile) among random other samples
+        xs = torch.randint(0, 4096, (B, L), generator=g)
+        xs[:, ::3] = MASK
+        xs[-1] = x1[0]
+        rows[B] = eng.forward_logits(xs.cuda(), seq1.repeat(B, 1).cuda(), tf)[-1].float().cpu()
+    eng.close()
+    rec = {f"B{B}_vs_B100_max_abs": float((rows[B] - rows[100]).abs().max()) for B in rows}
+    _record("dispatch_paths_wide3_L258", rec)
+    for B in (6, 12, 40):
+        assert torch.equal(rows[B], rows[100]), rec                 # regular paths: bitwise identical
+    assert torch.equal(rows[2], rows[4]), rec                       # the small-batch path is batch-independent too
+    assert 0 < rec["B2_vs_B100_max_abs"] < 0.02, rec                # ... and differs from the regular one at bf16-rounding level

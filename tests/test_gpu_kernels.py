@@ -674,8 +674,8 @@ def test_model_wrapper_reference_rng_parity(tmp_path):
 
 def test_parity_stream_runs_across_batches_and_sigma0_conditioning():
     """(1) noise="torch-cpu" keeps ONE generator stream per run, like the reference's process-wide RNG: the second batch
-    of a run continues the stream (its samples differ from the first batch's), and a new run (sample_offset 0) restarts
-    it.  (2) A model built with time_conditioning = false still adds sigma_embedder(0) (model.py:466-471, 535-541)."""
+    AND the next target (sample_offset 0 again) continue the stream — the reference never re-seeds — and only
+    reset_parity_stream / a new seed restarts it.  (2) A model built with time_conditioning = false still adds sigma_embedder(0) (model.py:466-471, 535-541)."""
     import dataclasses
     from esmdiff_amd.config import TINY
     from esmdiff_amd.model import MaskedDiffusionLanguageModeling
@@ -689,8 +689,15 @@ def test_parity_stream_runs_across_batches_and_sigma0_conditioning():
     seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1)
     a0 = model.ddpm_sample(seq, num_steps=T, seed=9, sample_offset=0, noise="torch-cpu").cpu()
     a1 = model.ddpm_sample(seq, num_steps=T, seed=9, sample_offset=B, noise="torch-cpu").cpu()
+    c0 = model.ddpm_sample(seq, num_steps=T, seed=9, sample_offset=0, noise="torch-cpu").cpu()   # "second target": runs on
+    assert not torch.equal(a0, a1) and not torch.equal(c0, a0) and not torch.equal(c0, a1)
+    model.reset_parity_stream(9)
     b0 = model.ddpm_sample(seq, num_steps=T, seed=9, sample_offset=0, noise="torch-cpu").cpu()
-    assert torch.equal(a0, b0) and not torch.equal(a0, a1)
+    b1 = model.ddpm_sample(seq, num_steps=T, seed=9, sample_offset=B, noise="torch-cpu").cpu()
+    assert torch.equal(a0, b0) and torch.equal(a1, b1)
+    d0 = model.ddpm_sample(seq, num_steps=T, seed=10, sample_offset=0, noise="torch-cpu").cpu()    # a new seed restarts too
+    model.reset_parity_stream(10)
+    assert torch.equal(d0, model.ddpm_sample(seq, num_steps=T, seed=10, noise="torch-cpu").cpu())
     model.net.close()
     # (2)
     cfg0 = dataclasses.replace(TINY, time_conditioning=False)

@@ -302,3 +302,27 @@ def test_strict_engine_refuses_what_it_does_not_build():
         eng.attention(torch.zeros(32, 3 * TINY.d_model, dtype=torch.bfloat16, device="cuda"),
                       torch.ones(TINY.d_model), torch.ones(TINY.d_model), 2, 16)
     eng.close()
+
+
+def test_cli_precision_flags(tmp_path):
+    """`--precision f32` end to end through the reference-shaped CLI (both drivers), decoder at its f32 default: the run's
+    json records the arithmetic that produced it, the files are the reference's artefacts; gibbs-mode inpainting (needs
+    block 0's geometric attention) is refused up front on the strict engine."""
+    from esmdiff_amd.sample_esmdiff import main
+    common = ["--random_init", "--tiny", "--random_init_decoder", "--synthetic_len", "30", "--num_samples", "3", "--num_steps", "4",
+              "--output", str(tmp_path), "--no_timestamp", "--precision", "f32"]
+    main(common + ["--mode", "ddpm"])
+    d = tmp_path / "step4_eps1e-05_N3"
+    meta = json.loads((d / "synthetic30.json").read_text())
+    assert meta["precision"] == "f32" and meta["decoder_precision"] == "f32"
+    ids_f32 = np.load(d / "synthetic30.tokens.npy")
+    assert ids_f32.shape == (3, 30) and (d / "synthetic30.pdb").exists()
+    main(common)                                                         # default mode: gibbs
+    assert (tmp_path / "T1.4_step4_topp0.9_N3" / "synthetic30.tokens.npy").exists()
+    with pytest.raises(SystemExit, match="coordinate conditioning"):
+        main(common + ["--mask_ids", "3,4"])
+    # the bf16 engine on the same seed: same ids on this tiny case or not, but its json says bf16 / f32 decoder
+    out2 = tmp_path / "bf16"
+    main([a if a != str(tmp_path) else str(out2) for a in common[:-2]] + ["--mode", "ddpm"])
+    meta2 = json.loads((out2 / "step4_eps1e-05_N3" / "synthetic30.json").read_text())
+    assert meta2["precision"] == "bf16" and meta2["decoder_precision"] == "f32"
