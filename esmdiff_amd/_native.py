@@ -46,7 +46,7 @@ EXPORTS = [
     "esmdiff_get_profile", "esmdiff_set_frames", "esmdiff_gemm_bf16_ws", "esmdiff_decoder_create",
     "esmdiff_decoder_decode", "esmdiff_metrics_js_pwd", "esmdiff_metrics_js_rg", "esmdiff_metrics_validity",
     "esmdiff_metrics_bonding_validity", "esmdiff_metrics_pwd", "esmdiff_metrics_js_columns", "esmdiff_encoder_create", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error",
-    "esmdiff_encoder_encode", "esmdiff_gemm_f32",
+    "esmdiff_encoder_encode", "esmdiff_gemm_f32", "esmdiff_set_step0_sharing", "esmdiff_get_counters",
 ]
 
 
@@ -101,6 +101,8 @@ def lib():
     L.esmdiff_encoder_last_error.argtypes = [vp]
     L.esmdiff_encoder_last_error.restype = ctypes.c_char_p
     L.esmdiff_encoder_encode.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.esmdiff_set_step0_sharing.argtypes = [vp, i32]
+    L.esmdiff_get_counters.argtypes = [vp, c_i64p, c_i64p, i32]
     L.esmdiff_gemm_f32.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     L.esmdiff_gemm_bf16_ws.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     for n in EXPORTS:

@@ -101,6 +101,11 @@ struct esmdiff_engine {
   float *fhead_w0 = nullptr, *fhead_w3 = nullptr, *fpl_w0 = nullptr, *fpl_w3 = nullptr, *fpw_down = nullptr;
   float *fh = nullptr, *fh2 = nullptr, *fqkv = nullptr, *fq = nullptr, *fk = nullptr, *fctx = nullptr, *fgu = nullptr,
         *fmid = nullptr, *fpair_qk = nullptr;
+  // step-0 sharing (esmdiff_set_step0_sharing): when every sample of a sampling call starts from identical inputs, the first
+  // forward runs on a sub-batch and all samples draw from its logits; counters of the work really executed
+  int step0_share = 0;
+  int32_t* flag_dev = nullptr;
+  int64_t stat_forwards = 0, stat_rows = 0;
   // profiling
   int profiling = 0;  // 0 off, 1 every launch, 2 only the dominant kernel (FFN-up GEMM)
   std::vector<hipEvent_t> ev;
@@ -286,6 +291,32 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
               e->gemm_ws2[queue].partial ? &e->gemm_ws2[queue] : nullptr};
 }
 
+// How forward() will cut a batch: number of sub-batch streams, and whether the sub-batches take the small-batch path.
+int plan_parts(const esmdiff_engine* e, int B, int L) {
+  const int64_t tokens = (int64_t)B * L;
+  if (!e->side.empty() && e->profiling != 1 && B >= 2 &&
+      (tokens >= e->dual_min_tokens || (B >= 8 && tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(768, e->dual_min_tokens))))
+    return std::min<int>({(int)e->side.size() + 1, B, 4});
+  return 1;
+}
+bool plan_small(const esmdiff_engine* e, int B, int L) {
+  if (e->strict) return false;
+  const int np = plan_parts(e, B, L);
+  const int b_first = (int)((int64_t)B * 1 / np), b_last = B - (int)((int64_t)B * (np - 1) / np);
+  return e->small_fused && e->gemm_ws[0].partial && e->gemm_ws2[0].partial && (int64_t)b_last * L < ed::small_max_rows() &&
+         (int64_t)b_first * L < ed::small_max_rows();
+}
+// Step-0 sharing: the number of leading samples whose forward gives, bit for bit, the logits every sample of an
+// all-identical batch of B would get — a sub-batch that takes the same (regular) dispatch path as the whole batch
+// (tests: test_logits_across_dispatch_paths) — or B when nothing can be saved.
+int shared_forward_batch(const esmdiff_engine* e, int B, int L) {
+  if (e->strict) return 1;                       // every row's result is independent of the batch (fixed K order, one path)
+  if (plan_small(e, B, L)) return B;             // small-batch path: the plane count is fixed, but keep it simple: no sharing
+  for (int b = 1; b < B; ++b)
+    if (!plan_small(e, b, L) && (int64_t)b * L >= ed::small_max_rows()) return b;
+  return B;
+}
+
 // precision = F32: the same network in float32 end to end (csrc/strict.hip).  One stream, one launch per op, residual
 // adds in the branch GEMMs' epilogues as x + r / scaling_factor (esm's own expression).  Sections are timed like the
 // bf16 path's.  The geometric branch is not built here (esmdiff_set_frames refuses on a strict engine).
@@ -355,7 +386,11 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
 //     matrix for half the rows and lose (B = 4 at L_tok = 60: 87.0 / 95.8 ms), and B = 3 at L_tok = 258 cuts into 1 + 2.
 int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const float* t_freq_dev, float* logits,
             int ld, int B, int L, hipStream_t st) {
-  if (e->strict) return forward_strict(e, seq, xtok, t_freq_dev, logits, ld, B, L, st);
+  if (e->strict) {
+    e->stat_forwards += 1;
+    e->stat_rows += (int64_t)B * L;
+    return forward_strict(e, seq, xtok, t_freq_dev, logits, ld, B, L, st);
+  }
   const esmdiff_config& c = e->cfg;
   const int D = c.d_model, H = c.n_heads, FH = c.ffn_hidden;
   const float inv_scale = 1.0f / c.residue_scale;
@@ -378,11 +413,9 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   }
   // profiling == 1 (per-section breakdown) keeps one stream so that the sections do not overlap
   Part parts[4];
-  int np = 1;
-  const int64_t tokens = (int64_t)B * L;
-  if (!e->side.empty() && e->profiling != 1 && B >= 2 &&
-      (tokens >= e->dual_min_tokens || (B >= 8 && tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(768, e->dual_min_tokens))))
-    np = std::min<int>({(int)e->side.size() + 1, B, 4});
+  const int np = plan_parts(e, B, L);
+  e->stat_forwards += 1;
+  e->stat_rows += (int64_t)B * L;
   for (int pi = 0; pi < np; ++pi) {
     const int b0 = (int)((int64_t)B * pi / np), b1 = (int)((int64_t)B * (pi + 1) / np);
     parts[pi] = make_part(e, seq, xtok, logits, ld, b0, b1 - b0, L, pi == 0 ? st : e->side[pi - 1], pi);
@@ -425,8 +458,7 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   // attention-side LayerNorm, x += dA before the FFN-side one: the same two additions in the same order — so neither a
   // split-K reduce pass nor a bf16 delta round trip runs.  Sub-batches of one forward are all on the same side of the
   // switch or results would depend on how the batch was cut; parts differ by at most one sample, so test part 0's rows.
-  const bool small = e->small_fused && parts[0].gws && parts[0].gws2 && (int64_t)parts[np - 1].B * L < ed::small_max_rows() &&
-                     (int64_t)parts[0].B * L < ed::small_max_rows();
+  const bool small = plan_small(e, B, L);
   ed::GemmPartials PF[4] = {}, PA[4] = {};
   for (int i = 0; i < c.n_layers; ++i) {
     const Layer& ly = e->layers[i];
@@ -484,9 +516,39 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
   return 0;
 }
 
+// Step-0 sharing (esmdiff_set_step0_sharing).  Returns in *shared the number of leading samples whose forward serves the
+// whole batch at step 0, or 0 when the batch is run in full: the option is off, nothing would be saved, or — checked ON THE
+// DEVICE, not taken from the caller — the rows of seq / x are not all identical.  One 4-byte read-back per sampling call.
+int step0_shared_batch(esmdiff_engine* e, const int64_t* seq, const int64_t* x, int B, int L, hipStream_t st, int* shared) {
+  *shared = 0;
+  if (!e->step0_share || B < 2) return 0;
+  const int bs = shared_forward_batch(e, B, L);
+  if (bs >= B) return 0;
+  HIP_TRY(e, launch_rows_identical(seq, x, B, L, e->flag_dev, st));
+  int32_t h = 0;
+  HIP_TRY(e, hipMemcpyAsync(&h, e->flag_dev, sizeof h, hipMemcpyDeviceToHost, st));
+  HIP_TRY(e, hipStreamSynchronize(st));
+  if (h != 0) *shared = bs;
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+int esmdiff_set_step0_sharing(esmdiff_engine* e, int32_t on) {
+  if (!e) return ESMDIFF_E_INVALID;
+  e->step0_share = on ? 1 : 0;
+  return 0;
+}
+
+int esmdiff_get_counters(esmdiff_engine* e, int64_t* forwards, int64_t* token_rows, int32_t reset) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (forwards) *forwards = e->stat_forwards;
+  if (token_rows) *token_rows = e->stat_rows;
+  if (reset) e->stat_forwards = e->stat_rows = 0;
+  return 0;
+}
 
 int esmdiff_abi_version(void) { return ESMDIFF_ABI_VERSION; }
 
@@ -759,6 +821,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     e->tfreq_rows = 1026;
     TRY(dalloc(e, &e->tfreq, (size_t)e->tfreq_rows * F));
     TRY(dalloc(e, &e->g_entropy, Mx));
+    TRY(dalloc(e, &e->flag_dev, (size_t)4));
     TRY(dalloc(e, &e->g_sampled, Mx));
     TRY(dalloc(e, &e->g_nunmask, (size_t)e->tfreq_rows * cfg->max_batch));
     {  // split-K workspaces: S * N <= 12288 for every shape the launcher splits; rows up to the small-batch switch
@@ -905,12 +968,15 @@ int esmdiff_ddpm_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout,
   const int F = e->cfg.freq_dim;
   if (t_freq) HIP_TRY(e, hipMemcpyAsync(e->tfreq, t_freq, (size_t)(T + 1) * F * sizeof(float), hipMemcpyHostToDevice, st));
   Prof p{e, st};
+  int shared = 0;
+  if (int r = step0_shared_batch(e, seq, x_inout, B, L, st, &shared)) return r;
   for (int i = 0; i <= T; ++i) {
-    if (int r = forward(e, seq, x_inout, t_freq ? e->tfreq + (size_t)i * F : nullptr, e->logits, e->ld_logits, B, L, st)) return r;
+    const int Bf = (i == 0 && shared) ? shared : B;   // step 0 of an all-identical batch: one sub-batch forward serves all
+    if (int r = forward(e, seq, x_inout, t_freq ? e->tfreq + (size_t)i * F : nullptr, e->logits, e->ld_logits, Bf, L, st)) return r;
     const int fin = i == T;
     p.mark(S_SAMPLER);
     HIP_TRY(e, launch_ddpm_step(x_inout, e->logits, e->ld_logits, e->cfg.vocab_out, fin ? 0.f : mc_t[i], fin ? 0.f : mc_s[i],
-                                fin, nullptr, 1, rng->seed, rng->sample_offset, i, B, L, st));
+                                fin, nullptr, 1, rng->seed, rng->sample_offset, i, B, L, st, Bf < B ? Bf : 0));
     p.mark(S_SAMPLER);
   }
   return 0;
@@ -944,11 +1010,20 @@ int esmdiff_gibbs_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout
   if (int r = check_bl(e, B, L)) return r;
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(e, hipMemcpyAsync(e->g_nunmask, n_unmask_table, (size_t)T * B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  if (!(temperature > 0.f)) return fail(e, ESMDIFF_E_INVALID, "temperature must be > 0 (argmax decoding is not built)");
+  if (!(top_p > 0.f)) return fail(e, ESMDIFF_E_INVALID, "top_p must be in (0, 1]");
+  int shared = 0;
+  if (e->frames_B == 0)              // (with coordinate conditioning the frames may differ per prompt: no sharing)
+    if (int r = step0_shared_batch(e, seq, x_inout, B, L, st, &shared)) return r;
   for (int i = 0; i < T; ++i) {
-    if (int r = forward(e, seq, x_inout, nullptr, e->logits, e->ld_logits, B, L, st)) return r;
-    if (int r = esmdiff_gibbs_step(e, x_inout, seq, e->logits, e->ld_logits, temperature, top_p, e->g_nunmask + (size_t)i * B,
-                                   nullptr, rng, i, B, L, stream))
-      return r;
+    const int Bf = (i == 0 && shared) ? shared : B;
+    if (int r = forward(e, seq, x_inout, nullptr, e->logits, e->ld_logits, Bf, L, st)) return r;
+    Prof p{e, st};
+    p.mark(S_SAMPLER);
+    HIP_TRY(e, launch_gibbs_step(x_inout, seq, e->logits, e->ld_logits, e->cfg.vocab_out, temperature, top_p,
+                                 e->g_nunmask + (size_t)i * B, nullptr, 1, rng->seed, rng->sample_offset, i, e->g_sampled,
+                                 e->g_entropy, B, L, st, Bf < B ? Bf : 0));
+    p.mark(S_SAMPLER);
   }
   return 0;
 }

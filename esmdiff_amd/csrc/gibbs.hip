@@ -55,13 +55,16 @@ __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restric
                                                         int ld, int W, float inv_temperature, float top_p,
                                                         const float* __restrict__ u, int use_philox, uint64_t seed,
                                                         uint64_t sample_offset, int step, int L,
-                                                        int32_t* __restrict__ sampled, float* __restrict__ entropy) {
+                                                        int32_t* __restrict__ sampled, float* __restrict__ entropy,
+                                                        int logits_period) {
   const int row = blockIdx.x;
   if (x[row] != G_MASK) return;  // only masked positions are candidates
   __shared__ float red[4];
   __shared__ int s_idx[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const float* z = logits + (int64_t)row * ld;
+  // logits_period > 0: prompt b reads the logits of prompt b % logits_period (step-0 sharing, see sampler.hip)
+  const int lrow = logits_period > 0 ? ((row / L) % logits_period) * L + (row % L) : row;
+  const float* z = logits + (int64_t)lrow * ld;
 
   float zz[G_PER];
   float m = -3.402823466e38f;
@@ -208,11 +211,11 @@ __global__ __launch_bounds__(GNT) void gibbs_select_kernel(int64_t* __restrict__
 hipError_t launch_gibbs_step(int64_t* x, const int64_t* seq, const float* logits, int ld, int vocab, float temperature,
                              float top_p, const int32_t* n_unmask, const float* u, int use_philox, uint64_t seed,
                              uint64_t sample_offset, int step, int32_t* sampled, float* entropy, int B, int L,
-                             hipStream_t stream) {
+                             hipStream_t stream, int logits_period) {
   if (B <= 0 || L <= 0) return hipSuccess;
   if (L > 1280 || vocab < G_NVALID || vocab > G_PER * GNT || ld < vocab || !(temperature > 0.f)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gibbs_row_kernel, dim3(B * L), dim3(GNT), 0, stream, x, logits, ld, vocab, 1.0f / temperature, top_p, u,
-                     use_philox, seed, sample_offset, step, L, sampled, entropy);
+                     use_philox, seed, sample_offset, step, L, sampled, entropy, logits_period);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(gibbs_select_kernel, dim3(B), dim3(GNT), 0, stream, x, seq, sampled, entropy, n_unmask, L);

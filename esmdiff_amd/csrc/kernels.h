@@ -14,7 +14,9 @@ namespace ed {
 // ---- sampler.hip -----------------------------------------------------------------------------
 hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, float mc_t, float mc_s, int final_,
                             const float* u, int use_philox, uint64_t seed, uint64_t sample_offset, int step,
-                            int B, int L, hipStream_t stream);
+                            int B, int L, hipStream_t stream, int logits_period = 0);
+// flag[0] (device int32) = -1 if every row of seq and x [B, L] equals row 0, else 0
+hipError_t launch_rows_identical(const int64_t* seq, const int64_t* x, int B, int L, int32_t* flag, hipStream_t stream);
 
 // ---- gibbs.hip ---------------------------------------------------------------------------------
 // one entropy-ordered unmasking step: per masked row nucleus(top_p) + temperature draw + entropy, then per prompt
@@ -22,7 +24,7 @@ hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, floa
 hipError_t launch_gibbs_step(int64_t* x, const int64_t* seq, const float* logits, int ld, int vocab, float temperature,
                              float top_p, const int32_t* n_unmask, const float* u, int use_philox, uint64_t seed,
                              uint64_t sample_offset, int step, int32_t* sampled, float* entropy, int B, int L,
-                             hipStream_t stream);
+                             hipStream_t stream, int logits_period = 0);
 
 // ---- gemm.hip --------------------------------------------------------------------------------
 // out = epilogue(A[M,K] · W[N,K]^T); K % 64 == 0, N % 128 == 0 (weights are padded at load time).

@@ -42,7 +42,8 @@ template <int PER>
 __global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, const float* __restrict__ logits,
                                                        int ld, int V, float mc_t, float mc_s, int final_,
                                                        const float* __restrict__ u, int use_philox,
-                                                       uint64_t seed, uint64_t sample_offset, int step, int L) {
+                                                       uint64_t seed, uint64_t sample_offset, int step, int L,
+                                                       int logits_period) {
   const int row = blockIdx.x;
   if (x[row] != MASK_ID) return;  // carry-over: copy_flag * x  (model.py:606-607)
 
@@ -50,7 +51,10 @@ __global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, 
   __shared__ int s_idx[4];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
-  const float* z = logits + (int64_t)row * ld;
+  // logits_period > 0: sample b reads the logits of sample b % logits_period (step-0 sharing: every sample of the batch
+  // had identical inputs, engine.hip::esmdiff_ddpm_sample); the noise stays keyed by the sample's own index
+  const int lrow = logits_period > 0 ? ((row / L) % logits_period) * L + (row % L) : row;
+  const float* z = logits + (int64_t)lrow * ld;
 
   float zz[PER];
   float m = -3.402823466e38f;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, 
 
 hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, float mc_t, float mc_s, int final_,
                             const float* u, int use_philox, uint64_t seed, uint64_t sample_offset, int step,
-                            int B, int L, hipStream_t stream) {
+                            int B, int L, hipStream_t stream, int logits_period) {
   const int rows = B * L;
   if (rows <= 0) return hipSuccess;
   const int per = (V + NT - 1) / NT;
@@ -151,12 +155,29 @@ hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, floa
   dim3 grid(rows), block(NT);
 #define ED_LAUNCH(P)                                                                                       \
   hipLaunchKernelGGL(ddpm_step_kernel<P>, grid, block, 0, stream, x, logits, ld, V, mc_t, mc_s, final_, u, \
-                     use_philox, seed, sample_offset, step, L)
+                     use_philox, seed, sample_offset, step, L, logits_period)
   if (per <= 1) ED_LAUNCH(1);
   else if (per <= 4) ED_LAUNCH(4);
   else if (per <= 17) ED_LAUNCH(17);
   else ED_LAUNCH(MAX_PER_THREAD);
 #undef ED_LAUNCH
+  return hipGetLastError();
+}
+
+// flag[0] &= (every row of seq and of x equals row 0): one thread per element of rows 1..B-1.
+__global__ void rows_identical_kernel(const int64_t* __restrict__ seq, const int64_t* __restrict__ x, int64_t n, int L,
+                                      int32_t* __restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int l = (int)(i % L);
+  if (seq[L + i] != seq[l] || x[L + i] != x[l]) flag[0] = 0;
+}
+
+hipError_t launch_rows_identical(const int64_t* seq, const int64_t* x, int B, int L, int32_t* flag, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(flag, 0xff, sizeof(int32_t), stream);   // all ones = true
+  if (e != hipSuccess || B <= 1) return e;
+  const int64_t n = (int64_t)(B - 1) * L;
+  hipLaunchKernelGGL(rows_identical_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, seq, x, n, L, flag);
   return hipGetLastError();
 }
 

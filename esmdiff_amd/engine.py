@@ -262,6 +262,18 @@ class Engine:
                                                  Nn, float(alpha), epilogue, _stream()))
         return out
 
+    def set_step0_sharing(self, on: bool) -> None:
+        """Exact step-0 sharing (esmdiff_set_step0_sharing): when every sample of a ddpm_sample / gibbs_sample call starts
+        from identical tokens (checked on the device), the first forward runs on a sub-batch and serves all samples; ids are
+        bit-identical to the unshared run.  Off by default."""
+        self._chk(self._lib.esmdiff_set_step0_sharing(self._h, int(bool(on))))
+
+    def counters(self, reset: bool = False) -> Dict[str, int]:
+        """Network forwards issued and token rows pushed through them since create / the last reset (executed work)."""
+        f, r = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._chk(self._lib.esmdiff_get_counters(self._h, ctypes.byref(f), ctypes.byref(r), int(reset)))
+        return {"forwards": int(f.value), "token_rows": int(r.value)}
+
     # ---- per-kernel entry points (parity tests / roofline bench) ---------------------------------
     def set_profiling(self, mode):
         """0/False off; 1/True HIP events around every launch; 2 only around the dominant kernel (FFN-up GEMM)."""

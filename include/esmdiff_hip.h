@@ -144,6 +144,19 @@ int esmdiff_ddpm_sample(esmdiff_engine* eng, const int64_t* seq, int64_t* x_inou
                         int32_t T, const float* mc_t, const float* mc_s, const float* t_freq,
                         const esmdiff_rng* rng, void* stream);
 
+/* Step-0 sharing (off by default; exact).  The reference's loop (model.py:570-573) runs the network on the whole batch at
+ * every step; at step 0 of a run whose samples all start from the same tokens (the CLI repeats ONE sequence and an all-MASK
+ * or identical prior, sample_esmdiff.py:196-209) every sample's inputs — and so its logits — are identical.  With the
+ * option on, esmdiff_ddpm_sample / esmdiff_gibbs_sample verify ON THE DEVICE that all rows of seq and x_inout are equal,
+ * run the first forward on the smallest sub-batch that takes the same dispatch path as the whole batch (bit-identical
+ * logits: tests/test_gpu_fullwidth.py::test_logits_across_dispatch_paths) and let every sample draw from those logits with
+ * its own noise: the ids are bit-identical to the unshared run (test_step0_sharing_is_exact) and 1 of the T + 1 forwards
+ * shrinks to a fraction.  Costs one 4-byte read-back per sampling call.  Not used with coordinate conditioning.
+ * esmdiff_get_counters: network forwards issued and token rows pushed through them since create / the last reset — the
+ * work actually executed, for FLOP accounting (bench.py reports the shared run as a separate, labelled figure). */
+int esmdiff_set_step0_sharing(esmdiff_engine* eng, int32_t on);
+int esmdiff_get_counters(esmdiff_engine* eng, int64_t* forwards, int64_t* token_rows, int32_t reset);
+
 /* Replaces, for ONE step, the per-prompt half of esm.utils.generation.iterative_sampling_raw as the reference calls
  * it in "gibbs" mode (sample_esmdiff.py:114-122; [ESM-RECALL]): for every still-masked position
  * entropy of softmax(logits over the 4096 codebook ids), nucleus filter (top_p), temperature, categorical draw; then

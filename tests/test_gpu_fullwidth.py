@@ -462,3 +462,64 @@ def test_logits_across_dispatch_paths():
         assert torch.equal(rows[B], rows[100]), rec                 # regular paths: bitwise identical
     assert torch.equal(rows[2], rows[4]), rec                       # the small-batch path is batch-independent too
     assert 0 < rec["B2_vs_B100_max_abs"] < 0.02, rec                # ... and differs from the regular one at bf16-rounding level
+
+
+def test_step0_sharing_is_exact():
+    """Step-0 sharing (esmdiff_set_step0_sharing): when all samples of a call start from identical tokens, the first forward
+    runs on a sub-batch — the ids must be BIT-IDENTICAL to the unshared run, the counters must show the saved rows, and a
+    batch whose rows differ (per-sample priors) must silently run in full.  Production width (3 blocks), B = 24 x L_tok 258
+    (two streams, regular path) and the small-batch shape B = 4 x 60 (nothing to share: runs in full); gibbs loop too."""
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.gibbs import unmask_schedule
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ModelConfig(n_layers=3)
+    eng = Engine(cfg, random_init_state_dict(cfg, seed=8), max_batch=24, max_len=258)
+    g = torch.Generator().manual_seed(4)
+    sch = ddpm_schedule(6)
+    rec = {}
+    for B, L in ((24, 258), (4, 60)):
+        seq = _seq(B, L, g).cuda()
+        eng.set_step0_sharing(False)
+        eng.counters(reset=True)
+        want = eng.ddpm_sample(seq, sch, seed=3, sample_offset=5).cpu()
+        full = eng.counters(reset=True)
+        eng.set_step0_sharing(True)
+        got = eng.ddpm_sample(seq, sch, seed=3, sample_offset=5).cpu()
+        part = eng.counters(reset=True)
+        assert torch.equal(got, want)
+        assert full == {"forwards": 7, "token_rows": 7 * B * L} and part["forwards"] == 7
+        rec[f"B{B}_L{L}"] = {"rows_full": full["token_rows"], "rows_shared": part["token_rows"]}
+        if B * L >= 2 * 1152:
+            assert part["token_rows"] < full["token_rows"] and (full["token_rows"] - part["token_rows"]) % L == 0
+            assert (full["token_rows"] - part["token_rows"]) // L >= B // 2      # at least half of step 0 saved
+        else:
+            assert part == full
+        # rows that differ: an inpainting prior that is NOT the same for every sample -> the engine must run in full
+        prior = torch.full((B, L), MASK, dtype=torch.int64)
+        prior[:, 5:15] = torch.randint(0, 4096, (B, 10), generator=g)
+        eng.counters(reset=True)
+        a = eng.ddpm_sample(seq, sch, seed=3, input_prior=prior.cuda()).cpu()
+        assert eng.counters(reset=True)["token_rows"] == 7 * B * L
+        eng.set_step0_sharing(False)
+        assert torch.equal(a, eng.ddpm_sample(seq, sch, seed=3, input_prior=prior.cuda()).cpu())
+        # ... and one that IS the same for every sample shares
+        same = prior[:1].repeat(B, 1).cuda()
+        b0 = eng.ddpm_sample(seq, sch, seed=3, input_prior=same).cpu()
+        eng.set_step0_sharing(True)
+        assert torch.equal(b0, eng.ddpm_sample(seq, sch, seed=3, input_prior=same).cpu())
+    # the gibbs loop
+    B, L = 24, 258
+    seq = _seq(B, L, g).cuda()
+    x0 = torch.full((B, L), MASK, dtype=torch.int64)
+    x0[:, 0], x0[:, -1] = 4098, 4097
+    table = torch.tensor(unmask_schedule(L - 2, 5), dtype=torch.int32)[:, None].repeat(1, B)
+    eng.set_step0_sharing(False)
+    want = eng.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=2).cpu()
+    eng.counters(reset=True)
+    eng.set_step0_sharing(True)
+    got = eng.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=2).cpu()
+    assert torch.equal(got, want) and eng.counters()["token_rows"] < 5 * B * L
+    eng.close()
+    _record("step0_sharing_rows", rec)
