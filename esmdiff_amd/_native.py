@@ -47,6 +47,7 @@ EXPORTS = [
     "esmdiff_decoder_decode", "esmdiff_metrics_js_pwd", "esmdiff_metrics_js_rg", "esmdiff_metrics_validity",
     "esmdiff_metrics_bonding_validity", "esmdiff_metrics_pwd", "esmdiff_metrics_js_columns", "esmdiff_encoder_create", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error",
     "esmdiff_encoder_encode", "esmdiff_gemm_f32", "esmdiff_set_step0_sharing", "esmdiff_get_counters",
+    "esmdiff_set_gibbs_options",
 ]
 
 
@@ -101,6 +102,7 @@ def lib():
     L.esmdiff_encoder_last_error.argtypes = [vp]
     L.esmdiff_encoder_last_error.restype = ctypes.c_char_p
     L.esmdiff_encoder_encode.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    L.esmdiff_set_gibbs_options.argtypes = [vp, i32, ctypes.POINTER(i32), i32]
     L.esmdiff_set_step0_sharing.argtypes = [vp, i32]
     L.esmdiff_get_counters.argtypes = [vp, c_i64p, c_i64p, i32]
     L.esmdiff_gemm_f32.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]

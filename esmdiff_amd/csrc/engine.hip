@@ -105,6 +105,10 @@ struct esmdiff_engine {
   // forward runs on a sub-batch and all samples draw from its logits; counters of the work really executed
   int step0_share = 0;
   int32_t* flag_dev = nullptr;
+  // gibbs options (esmdiff_set_gibbs_options): 0 entropy-ordered / 1 random positions; bit v of inv_mask = id v is never drawn
+  int g_strategy = 0;
+  uint32_t* g_inv_mask = nullptr;
+  bool g_inv_on = false;
   int64_t stat_forwards = 0, stat_rows = 0;
   // profiling
   int profiling = 0;  // 0 off, 1 every launch, 2 only the dominant kernel (FFN-up GEMM)
@@ -536,6 +540,28 @@ int step0_shared_batch(esmdiff_engine* e, const int64_t* seq, const int64_t* x, 
 
 extern "C" {
 
+int esmdiff_set_gibbs_options(esmdiff_engine* e, int32_t strategy, const int32_t* invalid_ids, int32_t n_invalid) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (strategy != 0 && strategy != 1) return fail(e, ESMDIFF_E_INVALID, "strategy %d: 0 (entropy) or 1 (random)", strategy);
+  if (n_invalid < 0 || (n_invalid > 0 && !invalid_ids)) return fail(e, ESMDIFF_E_INVALID, "invalid_ids: null with n = %d", n_invalid);
+  uint32_t mask[128] = {0};
+  int n_set = 0;
+  for (int i = 0; i < n_invalid; ++i) {
+    const int v = invalid_ids[i];
+    if (v < 0 || v >= ESMDIFF_VOCAB) return fail(e, ESMDIFF_E_INVALID, "invalid_ids[%d] = %d is not a structure-track id (0..%d)", i, v, ESMDIFF_VOCAB - 1);
+    if (v < 4096 && !((mask[v >> 5] >> (v & 31)) & 1u)) {   // the special ids >= 4096 are never drawn anyway
+      mask[v >> 5] |= 1u << (v & 31);
+      ++n_set;
+    }
+  }
+  if (n_set >= 4096) return fail(e, ESMDIFF_E_INVALID, "invalid_ids leaves no id to draw");
+  HIP_TRY(e, hipSetDevice(e->device));
+  HIP_TRY(e, hipMemcpy(e->g_inv_mask, mask, sizeof mask, hipMemcpyHostToDevice));   // synchronous: ordered against earlier launches
+  e->g_inv_on = n_set > 0;
+  e->g_strategy = strategy;
+  return 0;
+}
+
 int esmdiff_set_step0_sharing(esmdiff_engine* e, int32_t on) {
   if (!e) return ESMDIFF_E_INVALID;
   e->step0_share = on ? 1 : 0;
@@ -822,6 +848,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(dalloc(e, &e->tfreq, (size_t)e->tfreq_rows * F));
     TRY(dalloc(e, &e->g_entropy, Mx));
     TRY(dalloc(e, &e->flag_dev, (size_t)4));
+    TRY(dalloc(e, &e->g_inv_mask, (size_t)128, true));
     TRY(dalloc(e, &e->g_sampled, Mx));
     TRY(dalloc(e, &e->g_nunmask, (size_t)e->tfreq_rows * cfg->max_batch));
     {  // split-K workspaces: S * N <= 12288 for every shape the launcher splits; rows up to the small-batch switch
@@ -994,8 +1021,10 @@ int esmdiff_gibbs_step(esmdiff_engine* e, int64_t* x_inout, const int64_t* seq, 
   if (int r = check_bl(e, B, L)) return r;
   Prof p{e, (hipStream_t)stream};
   p.mark(S_SAMPLER);
+  if (e->g_strategy == 1 && u) return fail(e, ESMDIFF_E_INVALID, "strategy \"random\" draws its positions from the Philox source: pass rng, not explicit uniforms");
   HIP_TRY(e, launch_gibbs_step(x_inout, seq, logits, ld_logits, e->cfg.vocab_out, temperature, top_p, n_unmask, u, u ? 0 : 1, rng ? rng->seed : 0,
-                               rng ? rng->sample_offset : 0, step, e->g_sampled, e->g_entropy, B, L, (hipStream_t)stream));
+                               rng ? rng->sample_offset : 0, step, e->g_sampled, e->g_entropy, B, L, (hipStream_t)stream, 0,
+                               e->g_strategy, e->g_inv_on ? e->g_inv_mask : nullptr));
   p.mark(S_SAMPLER);
   return 0;
 }
@@ -1022,7 +1051,7 @@ int esmdiff_gibbs_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout
     p.mark(S_SAMPLER);
     HIP_TRY(e, launch_gibbs_step(x_inout, seq, e->logits, e->ld_logits, e->cfg.vocab_out, temperature, top_p,
                                  e->g_nunmask + (size_t)i * B, nullptr, 1, rng->seed, rng->sample_offset, i, e->g_sampled,
-                                 e->g_entropy, B, L, st, Bf < B ? Bf : 0));
+                                 e->g_entropy, B, L, st, Bf < B ? Bf : 0, e->g_strategy, e->g_inv_on ? e->g_inv_mask : nullptr));
     p.mark(S_SAMPLER);
   }
   return 0;

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restric
                                                         const float* __restrict__ u, int use_philox, uint64_t seed,
                                                         uint64_t sample_offset, int step, int L,
                                                         int32_t* __restrict__ sampled, float* __restrict__ entropy,
-                                                        int logits_period) {
+                                                        int logits_period, int strategy,
+                                                        const uint32_t* __restrict__ inv_mask) {
   const int row = blockIdx.x;
   if (x[row] != G_MASK) return;  // only masked positions are candidates
   __shared__ float red[4];
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restric
   for (int j = 0; j < G_PER; ++j) {
     const int v = t + j * GNT;
     if (v >= G_NVALID) continue;   // special ids are removed after the nucleus cut
+    if (inv_mask && ((inv_mask[v >> 5] >> (v & 31)) & 1u)) continue;   // ... and so are the caller's invalid_ids
     if (zz[j] > fb) {
       fb = zz[j];
       fb_i = v;
@@ -177,7 +179,9 @@ __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restric
       }
     }
     sampled[row] = bi != 0x7fffffff ? bi : fi;
-    entropy[row] = H;
+    // the ordering key of gibbs_select_kernel: the entropy (strategy "entropy"), or a uniform per position drawn from a
+    // Philox column no token draw uses (strategy "random": the k smallest keys are a uniformly random k-subset)
+    entropy[row] = strategy == 1 ? ed_philox_uniform(seed, sample_offset + (uint64_t)b, (uint32_t)step, (uint32_t)l, 4352u) : H;
   }
 }
 
@@ -211,11 +215,12 @@ __global__ __launch_bounds__(GNT) void gibbs_select_kernel(int64_t* __restrict__
 hipError_t launch_gibbs_step(int64_t* x, const int64_t* seq, const float* logits, int ld, int vocab, float temperature,
                              float top_p, const int32_t* n_unmask, const float* u, int use_philox, uint64_t seed,
                              uint64_t sample_offset, int step, int32_t* sampled, float* entropy, int B, int L,
-                             hipStream_t stream, int logits_period) {
+                             hipStream_t stream, int logits_period, int strategy, const uint32_t* inv_mask) {
   if (B <= 0 || L <= 0) return hipSuccess;
   if (L > 1280 || vocab < G_NVALID || vocab > G_PER * GNT || ld < vocab || !(temperature > 0.f)) return hipErrorInvalidValue;
+  if (strategy != 0 && (strategy != 1 || !use_philox)) return hipErrorInvalidValue;   // random positions need the Philox source
   hipLaunchKernelGGL(gibbs_row_kernel, dim3(B * L), dim3(GNT), 0, stream, x, logits, ld, vocab, 1.0f / temperature, top_p, u,
-                     use_philox, seed, sample_offset, step, L, sampled, entropy, logits_period);
+                     use_philox, seed, sample_offset, step, L, sampled, entropy, logits_period, strategy, inv_mask);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(gibbs_select_kernel, dim3(B), dim3(GNT), 0, stream, x, seq, sampled, entropy, n_unmask, L);

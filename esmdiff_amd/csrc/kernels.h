@@ -24,7 +24,7 @@ hipError_t launch_rows_identical(const int64_t* seq, const int64_t* x, int B, in
 hipError_t launch_gibbs_step(int64_t* x, const int64_t* seq, const float* logits, int ld, int vocab, float temperature,
                              float top_p, const int32_t* n_unmask, const float* u, int use_philox, uint64_t seed,
                              uint64_t sample_offset, int step, int32_t* sampled, float* entropy, int B, int L,
-                             hipStream_t stream, int logits_period = 0);
+                             hipStream_t stream, int logits_period = 0, int strategy = 0, const uint32_t* inv_mask = nullptr);
 
 // ---- gemm.hip --------------------------------------------------------------------------------
 // out = epilogue(A[M,K] · W[N,K]^T); K % 64 == 0, N % 128 == 0 (weights are padded at load time).

@@ -262,6 +262,15 @@ class Engine:
                                                  Nn, float(alpha), epilogue, _stream()))
         return out
 
+    def set_gibbs_options(self, strategy: str = "entropy", invalid_ids=()) -> None:
+        """GenerationConfig.strategy ("entropy" | "random") and .invalid_ids for the following gibbs steps
+        (esmdiff_set_gibbs_options); the defaults restore esm's default behaviour."""
+        if strategy not in ("entropy", "random"):
+            raise ValueError(f"strategy must be 'entropy' or 'random', got {strategy!r}")
+        ids = [int(v) for v in invalid_ids]
+        arr = (ctypes.c_int32 * max(1, len(ids)))(*ids)
+        self._chk(self._lib.esmdiff_set_gibbs_options(self._h, 1 if strategy == "random" else 0, arr if ids else None, len(ids)))
+
     def set_step0_sharing(self, on: bool) -> None:
         """Exact step-0 sharing (esmdiff_set_step0_sharing): when every sample of a ddpm_sample / gibbs_sample call starts
         from identical tokens (checked on the device), the first forward runs on a sub-batch and serves all samples; ids are

@@ -78,12 +78,12 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
     for c in configs:
         if c.track != "structure":
             raise NotImplementedError("only the structure track is sampled by this engine")
-        if (c.num_steps, c.temperature, c.top_p, c.schedule) != (cfg0.num_steps, cfg0.temperature, cfg0.top_p, cfg0.schedule):
-            raise NotImplementedError("one batch shares num_steps / temperature / top_p / schedule (the reference passes copies)")
-        if c.strategy != "entropy":     # esm also has "random" (positions drawn uniformly); the device kernel orders by entropy
-            raise NotImplementedError(f"strategy {c.strategy!r}: only the default entropy-ordered unmasking is built")
-        if c.invalid_ids:
-            raise NotImplementedError("invalid_ids: the engine masks the structure track's special ids itself; extra ids are not built")
+        if (c.num_steps, c.temperature, c.top_p, c.schedule, c.strategy, list(c.invalid_ids or [])) != \
+                (cfg0.num_steps, cfg0.temperature, cfg0.top_p, cfg0.schedule, cfg0.strategy, list(cfg0.invalid_ids or [])):
+            raise NotImplementedError("one batch shares num_steps / temperature / top_p / schedule / strategy / invalid_ids "
+                                      "(the reference passes copies)")
+        if c.strategy not in ("entropy", "random"):
+            raise ValueError(f"strategy {c.strategy!r}: 'entropy' or 'random'")
     seqs = [encode_sequence(p.sequence) for p in proteins]
     L = seqs[0].numel()
     if any(s.numel() != L for s in seqs):
@@ -113,8 +113,15 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
         for b, tot in enumerate(totals):
             sch = unmask_schedule(tot, cfg0.num_steps, cfg0.schedule)
             table[: len(sch), b] = torch.tensor(sch, dtype=torch.int32)
-        out_x = eng.gibbs_sample(seq, x0, table, cfg0.temperature, cfg0.top_p, seed=seed,
-                                 sample_offset=sample_offset).cpu()
+        custom = cfg0.strategy != "entropy" or bool(cfg0.invalid_ids)
+        if custom:
+            eng.set_gibbs_options(cfg0.strategy, cfg0.invalid_ids or ())
+        try:
+            out_x = eng.gibbs_sample(seq, x0, table, cfg0.temperature, cfg0.top_p, seed=seed,
+                                     sample_offset=sample_offset).cpu()
+        finally:
+            if custom:
+                eng.set_gibbs_options()
     if any(has_xyz):
         eng.set_frames(None)
     coords = plddt = ptm = None

@@ -166,6 +166,14 @@ int esmdiff_gibbs_step(esmdiff_engine* eng, int64_t* x_inout, const int64_t* seq
                        int32_t ld_logits, float temperature, float top_p, const int32_t* n_unmask, const float* u,
                        const esmdiff_rng* rng, int32_t step, int32_t B, int32_t L, void* stream);
 
+/* GenerationConfig fields the reference leaves at their defaults (sample_esmdiff.py:116-119 sets only track / num_steps /
+ * temperature / top_p) [ESM-RECALL]: strategy 0 = "entropy" (the k lowest-entropy masked positions are unmasked), 1 =
+ * "random" (a uniformly random k-subset of the masked positions: the k smallest of one Philox uniform per position; needs the
+ * rng noise source); invalid_ids [host, n_invalid]: codebook ids that are never drawn — masked after the nucleus cut exactly
+ * like the special ids >= 4096.  Applies to every following esmdiff_gibbs_step / esmdiff_gibbs_sample of this engine;
+ * (0, NULL, 0) restores the defaults.  Synchronous (a 512-byte upload). */
+int esmdiff_set_gibbs_options(esmdiff_engine* eng, int32_t strategy, const int32_t* invalid_ids, int32_t n_invalid);
+
 /* The whole loop of iterative_sampling_raw for one batch on the device (Philox noise, no time conditioning):
  * T x (forward, gibbs step).  n_unmask_table: [T,B] int32 [host] = positions to unmask per step and prompt
  * (cosine schedule, computed by the host: esmdiff_amd/gibbs.py). */

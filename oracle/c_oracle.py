@@ -53,7 +53,7 @@ def lib():
         _lib.oracle_gibbs_step.argtypes = [_i64p, _i64p, _f32p, ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                            ctypes.POINTER(ctypes.c_int32), _f32p, ctypes.c_uint64, ctypes.c_uint64,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, _f32p,
-                                           ctypes.POINTER(ctypes.c_int32)]
+                                           ctypes.POINTER(ctypes.c_int32), ctypes.c_int, ctypes.POINTER(ctypes.c_uint32)]
         _lib.oracle_gibbs_step.restype = None
     return _lib
 
@@ -116,7 +116,7 @@ def philox_uniforms(seed, sample, step, l, vocab=4101):
 
 
 def gibbs_step(x, seq, logits, temperature, top_p, n_unmask, u=None, seed=0, sample_offset=0, step=0,
-               return_aux=False, vocab=4096):
+               return_aux=False, vocab=4096, strategy="entropy", invalid_ids=()):
     """One entropy-ordered unmasking step (oracle_gibbs_step).  x, seq [B,L]; logits [B,L,ld>=vocab]; `vocab` = width of
     the structure head's row (4096 stock ESM3, 4101 ESMDiff): entropy and nucleus run over all of it, draws over the
     4096 codebook ids; n_unmask [B]; u [B,L,4096] or None (Philox)."""
@@ -133,8 +133,14 @@ def gibbs_step(x, seq, logits, temperature, top_p, n_unmask, u=None, seed=0, sam
     ent = np.full((B, L), np.inf, dtype=np.float32)
     smp = np.full((B, L), -1, dtype=np.int32)
     assert lg.shape[2] >= vocab
+    assert strategy in ("entropy", "random") and (strategy == "entropy" or u is None)
+    mask = np.zeros(128, dtype=np.uint32)
+    for v in invalid_ids:
+        if 0 <= int(v) < 4096:
+            mask[int(v) >> 5] |= np.uint32(1 << (int(v) & 31))
     lib().oracle_gibbs_step(x.ctypes.data_as(_i64p), seq.ctypes.data_as(_i64p), lgp, lg.shape[2], int(vocab),
                             np.float32(temperature), np.float32(top_p), nu.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                             up, int(seed), int(sample_offset), int(step), B, L, ent.ctypes.data_as(_f32p),
-                            smp.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+                            smp.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), 1 if strategy == "random" else 0,
+                            mask.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)) if len(invalid_ids) else None)
     return (x, ent, smp) if return_aux else x

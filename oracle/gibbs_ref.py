@@ -41,7 +41,7 @@ def top_p_logits(logits: torch.Tensor, top_p: float) -> torch.Tensor:
     return out.scatter(-1, idx, torch.where(keep, srt, torch.full_like(srt, float("-inf"))))
 
 
-def gibbs_step_ref(x, seq, logits, temperature, top_p, n_unmask, u, vocab: int = NVALID):
+def gibbs_step_ref(x, seq, logits, temperature, top_p, n_unmask, u, vocab: int = NVALID, invalid_ids=(), pos_key=None):
     """x, seq (B,L) int64; logits (B,L,>=vocab); u (B,L,4096) uniforms.  Returns new x, entropy, sampled.
     esm's order of operations: entropy and top-p on the WHOLE structure-logit row (`vocab` = 4096
     for the stock head, 4101 for the ESMDiff head), the special ids >= 4096 are masked AFTER top-p, then temperature.
@@ -49,9 +49,13 @@ def gibbs_step_ref(x, seq, logits, temperature, top_p, n_unmask, u, vocab: int =
     z = logits[..., :vocab].float()
     logp = torch.log_softmax(z, -1)
     ent = -(logp.exp() * logp).sum(-1)
-    zp = top_p_logits(z, top_p)[..., :NVALID]            # mask invalid ids after top-p
+    zp = top_p_logits(z, top_p)[..., :NVALID].clone()    # mask invalid ids after top-p: the specials ...
+    zv = z[..., :NVALID].clone()
+    for v in invalid_ids:                                # ... and GenerationConfig.invalid_ids, the same way
+        zp[..., int(v)] = float("-inf")
+        zv[..., int(v)] = float("-inf")
     dead = torch.isinf(zp).all(-1, keepdim=True)
-    best_valid = torch.nn.functional.one_hot(z[..., :NVALID].argmax(-1), NVALID).bool()
+    best_valid = torch.nn.functional.one_hot(zv.argmax(-1), NVALID).bool()
     zp = torch.where(dead & best_valid, torch.zeros_like(zp), zp)
     w = torch.softmax(zp / temperature, -1)
     g = 1e-10 - (u + 1e-10).log()
@@ -62,7 +66,9 @@ def gibbs_step_ref(x, seq, logits, temperature, top_p, n_unmask, u, vocab: int =
         k = int(n_unmask[b])
         if k <= 0 or not bool(elig.any()):
             continue
-        e = torch.where(elig, ent[b], torch.full_like(ent[b], float("inf")))
+        # strategy "entropy": lowest entropy first; "random" (pos_key given): lowest random key first = a uniform k-subset
+        key = ent[b] if pos_key is None else torch.as_tensor(pos_key[b], dtype=torch.float32)
+        e = torch.where(elig, key, torch.full_like(key, float("inf")))
         order = sorted(range(x.shape[1]), key=lambda i: (float(e[i]), i))[:k]
         for i in order:
             if bool(elig[i]):

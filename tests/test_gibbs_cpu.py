@@ -98,14 +98,60 @@ def test_philox_step_is_shard_independent():
     assert np.array_equal(full[2:], part)
 
 
+def test_strategy_random_and_invalid_ids_oracle_semantics():
+    """GenerationConfig.strategy = "random" and .invalid_ids (r03): the C oracle (what the HIP kernel is bit-compared with)
+    against the torch statement.  invalid ids are masked after top-p exactly like the special ids (never drawn, also not as
+    the fall-back id); "random" unmasks the k positions with the smallest per-position Philox key — a uniform k-subset —
+    and the drawn tokens themselves are unchanged by the strategy."""
+    logits, u, seq, x = _case(3, 14, 11, 2.0)
+    n_un = np.array([4, 3, 5], np.int32)
+    # invalid_ids with explicit uniforms: C oracle == torch semantics, and no invalid id is ever drawn
+    masked = (x == 4096).numpy()
+    base = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 1.4, 0.9, n_un, u=u.numpy(), return_aux=True, vocab=4101)
+    inv = sorted({int(v) for v in base[2][masked].tolist()})[:20] + [4097]         # forbid ids the free draw picks (+ a special: no-op)
+    xc, ent_c, smp_c = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 1.4, 0.9, n_un, u=u.numpy(), return_aux=True,
+                                           vocab=4101, invalid_ids=inv)
+    xr, ent_r, smp_r = G.gibbs_step_ref(x, seq, logits, 1.4, 0.9, torch.tensor(n_un), u, vocab=4101, invalid_ids=[v for v in inv if v < 4096])
+    assert np.array_equal(smp_c[masked], smp_r.numpy()[masked]) and np.array_equal(xc, xr.numpy())
+    assert not np.isin(smp_c[masked], inv).any() and np.isin(base[2][masked], inv).sum() >= 20
+    untouched = ~np.isin(base[2], inv) & masked                                    # rows whose free draw was legal keep it
+    assert np.array_equal(smp_c[untouched], base[2][untouched])
+    # strategy "random" (Philox): same tokens as "entropy", other positions; the keys reproduce from the Philox column 4352
+    e_x, e_ent, e_smp = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 1.4, 0.9, n_un, seed=5, sample_offset=2, step=1,
+                                            return_aux=True, vocab=4101)
+    r_x, r_key, r_smp = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 1.4, 0.9, n_un, seed=5, sample_offset=2, step=1,
+                                            return_aux=True, vocab=4101, strategy="random")
+    assert np.array_equal(e_smp[masked], r_smp[masked])
+    changed = r_x != x.numpy()
+    assert changed.sum(1).tolist() == n_un.tolist() and not changed[:, 0].any() and not changed[:, -1].any()
+    assert not np.array_equal(changed, e_x != x.numpy())
+    assert ((r_key[masked] >= 0) & (r_key[masked] < 1)).all()
+    # the torch statement fed with the same keys picks the same positions
+    uu = np.stack([[c_oracle.philox_uniforms(5, 2 + b, 1, l, 4096) for l in range(14)] for b in range(3)])
+    t_x, _, _ = G.gibbs_step_ref(x, seq, logits, 1.4, 0.9, torch.tensor(n_un), torch.from_numpy(uu), vocab=4101, pos_key=r_key)
+    assert np.array_equal(t_x.numpy(), r_x)
+    # over many steps every eligible position is chosen about equally often (uniform subset)
+    hits = np.zeros(14)
+    for st in range(400):
+        rx = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 1.4, 0.9, np.array([3, 3, 3], np.int32), seed=9, step=st,
+                                 vocab=4101, strategy="random")
+        hits += (rx != x.numpy()).sum(0)
+    elig = hits[1:-1][np.arange(1, 13) != 3]                                       # position 3 of sample 0 is known: skip it
+    assert hits[0] == hits[-1] == 0 and elig.min() > 0.7 * elig.mean() and elig.max() < 1.3 * elig.mean()
+
+
 def test_generation_config_options_are_honoured_or_refused():
     """GenerationConfig fields the reference leaves at their defaults (sample_esmdiff.py:116-119) are never silently
-    ignored: the schedule is used, an unsupported strategy / invalid_ids / track is refused before any device work."""
+    ignored: the schedule, strategy and invalid_ids are used (r03), an unknown strategy / another track is refused before
+    any device work."""
     from esmdiff_amd.gibbs import iterative_sampling_raw
     from esmdiff_amd.sdk import ESMProtein, GenerationConfig
     prot = [ESMProtein(sequence="RPDFCLE")]
-    for bad in (GenerationConfig(strategy="random"), GenerationConfig(invalid_ids=[5]), GenerationConfig(track="sequence")):
-        with pytest.raises(NotImplementedError):
-            iterative_sampling_raw(object(), prot, [bad])
+    with pytest.raises(NotImplementedError):
+        iterative_sampling_raw(object(), prot, [GenerationConfig(track="sequence")])
+    with pytest.raises(ValueError, match="strategy"):
+        iterative_sampling_raw(object(), prot, [GenerationConfig(strategy="greedy")])
+    with pytest.raises(NotImplementedError, match="shares"):
+        iterative_sampling_raw(object(), prot * 2, [GenerationConfig(), GenerationConfig(strategy="random")])
     with pytest.raises(ValueError, match="unknown schedule"):
         iterative_sampling_raw(type("E", (), {"has_geom": False})(), prot, [GenerationConfig(schedule="sigmoid", num_steps=3)])

@@ -883,6 +883,60 @@ def test_gibbs_iterative_sampling_raw_and_cli(tiny, tmp_path):
     dec.close()
 
 
+def test_gibbs_strategy_random_and_invalid_ids(tiny):
+    """GenerationConfig.strategy = "random" / .invalid_ids (r03) on the device: the step is bit-exact vs the C oracle with the
+    same options (both noise sources for invalid_ids; Philox for the random position keys), explicit uniforms + random is
+    refused, and iterative_sampling_raw honours both fields end to end and restores the defaults afterwards."""
+    from esmdiff_amd.gibbs import iterative_sampling_raw
+    from esmdiff_amd.sdk import ESMProtein, GenerationConfig
+    from oracle import c_oracle
+    eng = tiny[2]
+    B, L = 3, 60
+    g = torch.Generator().manual_seed(77)
+    logits = torch.randn(B, L, 4104, generator=g) * 3
+    u = torch.rand(B, L, 4096, generator=g)
+    seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1)
+    x = torch.full((B, L), MASK, dtype=torch.int64)
+    x[:, 0], x[:, -1] = 4098, 4097
+    n_un = torch.tensor([7, 1, 12], dtype=torch.int32)
+    inv = sorted({int(v) for v in logits[..., :4096].argmax(-1).flatten().tolist()}) + [4100]   # every row's arg-max is forbidden
+    try:
+        eng.set_gibbs_options("entropy", inv)
+        want = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 0.3, 0.9, n_un.numpy(), u=u.numpy(), vocab=4101, invalid_ids=inv)
+        got = eng.gibbs_step(x.clone().cuda(), seq.cuda(), logits.cuda(), 0.3, 0.9, n_un, u=u.cuda()).cpu().numpy()
+        assert np.array_equal(got, want) and not np.isin(got[got != x.numpy()], inv).any()
+        eng.set_gibbs_options("random", inv)
+        want = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 1.4, 0.9, n_un.numpy(), seed=4, sample_offset=9, step=2,
+                                   vocab=4101, invalid_ids=inv, strategy="random")
+        got = eng.gibbs_step(x.clone().cuda(), seq.cuda(), logits.cuda(), 1.4, 0.9, n_un, seed=4, sample_offset=9, step=2).cpu().numpy()
+        assert np.array_equal(got, want) and ((got != x.numpy()).sum(1) == n_un.numpy()).all()
+        ent = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 1.4, 0.9, n_un.numpy(), seed=4, sample_offset=9, step=2,
+                                  vocab=4101, invalid_ids=inv)
+        assert not np.array_equal(got != x.numpy(), ent != x.numpy())           # other positions than the entropy order picks
+        with pytest.raises(RuntimeError, match="Philox"):
+            eng.gibbs_step(x.clone().cuda(), seq.cuda(), logits.cuda(), 1.4, 0.9, n_un, u=u.cuda())
+        with pytest.raises(RuntimeError, match="not a structure-track id"):
+            eng.set_gibbs_options("entropy", [5000])
+        with pytest.raises(ValueError):
+            eng.set_gibbs_options("greedy")
+    finally:
+        eng.set_gibbs_options()
+    base = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 1.4, 0.9, n_un.numpy(), seed=4, vocab=4101)
+    assert np.array_equal(eng.gibbs_step(x.clone().cuda(), seq.cuda(), logits.cuda(), 1.4, 0.9, n_un, seed=4).cpu().numpy(), base)
+    # end to end through the reference's call shape
+    prots = [ESMProtein(sequence="RPDFCLEPPYTGPCKARIIRYFYNAKAGLCQTFVYGGCRAKRNNFKSAEDCMRTCGGA")] * 2
+    mk = lambda **kw: [GenerationConfig(track="structure", num_steps=6, temperature=1.4, top_p=0.9, **kw)] * 2   # noqa: E731
+    a = iterative_sampling_raw(eng, prots, mk(), seed=3)
+    r = iterative_sampling_raw(eng, prots, mk(strategy="random"), seed=3)
+    banned = sorted({int(v) for p in a for v in p.structure_tokens.tolist()})[:40]
+    v = iterative_sampling_raw(eng, prots, mk(invalid_ids=banned), seed=3)
+    assert all(int((p.structure_tokens == MASK).sum()) == 0 and int(p.structure_tokens.max()) < 4096 for p in a + r + v)
+    assert not torch.equal(a[0].structure_tokens, r[0].structure_tokens)
+    assert not any(np.isin(p.structure_tokens.numpy(), banned).any() for p in v)
+    again = iterative_sampling_raw(eng, prots, mk(), seed=3)                      # the options did not leak into the next call
+    assert all(torch.equal(p.structure_tokens, q.structure_tokens) for p, q in zip(a, again))
+
+
 def test_cli_gibbs_default_mode(tmp_path):
     from esmdiff_amd.sample_esmdiff import main
     main(["--random_init", "--synthetic_len", "40", "--num_samples", "3", "--num_steps", "8", "--output", str(tmp_path),
