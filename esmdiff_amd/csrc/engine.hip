@@ -99,6 +99,7 @@ struct esmdiff_engine {
   // precision = ESMDIFF_PRECISION_F32: float32 weights / activations (forward_strict); the bf16 members above stay null
   bool strict = false;
   float *fhead_w0 = nullptr, *fhead_w3 = nullptr, *fpl_w0 = nullptr, *fpl_w3 = nullptr, *fpw_down = nullptr;
+  float *fg_proj = nullptr, *fg_out = nullptr, *fgp = nullptr, *fgctx = nullptr;
   float *fh = nullptr, *fh2 = nullptr, *fqkv = nullptr, *fq = nullptr, *fk = nullptr, *fctx = nullptr, *fgu = nullptr,
         *fmid = nullptr, *fpair_qk = nullptr;
   // step-0 sharing (esmdiff_set_step0_sharing): when every sample of a sampling call starts from identical inputs, the first
@@ -323,7 +324,7 @@ int shared_forward_batch(const esmdiff_engine* e, int B, int L) {
 
 // precision = F32: the same network in float32 end to end (csrc/strict.hip).  One stream, one launch per op, residual
 // adds in the branch GEMMs' epilogues as x + r / scaling_factor (esm's own expression).  Sections are timed like the
-// bf16 path's.  The geometric branch is not built here (esmdiff_set_frames refuses on a strict engine).
+// bf16 path's.  Block 0's geometric branch runs between the attention and the FFN branch while frames are set.
 int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const float* t_freq_dev, float* logits,
                    int ld, int B, int L, hipStream_t st) {
   const esmdiff_config& c = e->cfg;
@@ -342,6 +343,10 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
   }
   if (e->kind == 1) RUN(S_EMBED, launch_gather_rows(xtok, e->e_struct, e->x, M, D, ESMDIFF_VOCAB, st));
   else RUN(S_EMBED, launch_embed(seq, xtok, e->e_seq, e->e_struct, e->cvec, cond, e->x, B, L, D, st));
+  const bool geom = e->has_geom && e->frames_B > 0;
+  if (geom && (e->frames_B != B || e->frames_L != L))
+    return fail(e, ESMDIFF_E_INVALID, "frames were set for B=%d L=%d, forward called with B=%d L=%d", e->frames_B, e->frames_L, B, L);
+  const int VH = e->v_heads;
   for (int i = 0; i < c.n_layers; ++i) {
     const Layer& ly = e->layers[i];
     RUN(S_LN, launch_layernorm_f32(e->x, ly.ln1_w, ly.ln1_b, e->fh, M, D, st));
@@ -349,6 +354,12 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
     RUN(S_QKROPE, launch_qk_norm_rope_f32(e->fqkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, e->fq, e->fk, B, L, H, st));
     RUN(S_ATTN, launch_attention_f32(e->fq, e->fk, e->fqkv, e->fctx, B, L, H, st));
     RUN(S_OUT, launch_gemm_f32(e->fctx, D, ly.fw_out, e->x, nullptr, M, D, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
+    if (i == 0 && geom) {   // x = x + geom_attn(s_norm(x), frames) / scaling_factor
+      RUN(S_LN, launch_layernorm_f32(e->x, e->g_snorm_w, nullptr, e->fh, M, D, st));
+      RUN(S_ATTN, launch_gemm_f32(e->fh, D, e->fg_proj, e->fgp, nullptr, M, 15 * VH, D, 15 * VH, 15 * VH, 1.f, ESMDIFF_F32EPI_STORE, st));
+      RUN(S_ATTN, launch_geom_attention_f32(e->fgp, e->f_rot, e->f_trans, e->f_mask, e->g_wrot, e->g_wdist, e->fgctx, B, L, VH, st));
+      RUN(S_ATTN, launch_gemm_f32(e->fgctx, 3 * VH, e->fg_out, e->x, nullptr, M, D, 3 * VH, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
+    }
     RUN(S_LN, launch_layernorm_f32(e->x, ly.ln2_w, ly.ln2_b, e->fh, M, D, st));
     RUN(S_FFN_UP, launch_gemm_f32(e->fh, D, ly.fw_up, e->fgu, nullptr, M, 2 * FH, D, 2 * FH, 2 * FH, 1.f, ESMDIFF_F32EPI_STORE, st));
     RUN(S_FFN_UP, launch_swiglu_f32(e->fgu, e->fmid, M, FH, st));
@@ -728,15 +739,19 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(load_f32(e, t, "sigma_embedder.mlp.2.bias", {D}, &e->sig_b2));
   }
   // block 0's geometric attention: optional (the DDPM path never needs it: coordinates are all-NaN there)
-  // (a strict engine carries no geometric branch: esmdiff_set_frames refuses there)
-  if (const esmdiff_weight* pw = (kind == 0 && !strict) ? t.find("transformer.blocks.0.geom_attn.proj.weight") : nullptr) {
+  if (const esmdiff_weight* pw = kind == 0 ? t.find("transformer.blocks.0.geom_attn.proj.weight") : nullptr) {
     const std::string ga = "transformer.blocks.0.geom_attn.";
     const int VH = pw->ndim == 2 ? (int)(pw->shape[0] / 15) : 0;  // proj: Linear(D, v_heads * 3 * 5)
     if (VH <= 0 || (15 * VH) % 128 || (3 * VH) % 64) return bail(fail(e, ESMDIFF_E_INVALID, "geom_attn v_heads=%d unsupported", VH));
     e->v_heads = VH;
     TRY(load_f32(e, t, ga + "s_norm.weight", {D}, &e->g_snorm_w));
-    TRY(load_bf16(e, t, ga + "proj.weight", {15 * VH, D}, &e->g_proj));
-    TRY(load_bf16(e, t, ga + "out_proj.weight", {D, 3 * VH}, &e->g_out));
+    if (strict) {
+      TRY(load_f32(e, t, ga + "proj.weight", {15 * VH, D}, &e->fg_proj));
+      TRY(load_f32(e, t, ga + "out_proj.weight", {D, 3 * VH}, &e->fg_out));
+    } else {
+      TRY(load_bf16(e, t, ga + "proj.weight", {15 * VH, D}, &e->g_proj));
+      TRY(load_bf16(e, t, ga + "out_proj.weight", {D, 3 * VH}, &e->g_out));
+    }
     TRY(load_f32(e, t, ga + "rotation_scale_per_head", {VH}, &e->g_wrot));
     TRY(load_f32(e, t, ga + "distance_scale_per_head", {VH}, &e->g_wdist));
     if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "geom weight conversion failed"));
@@ -828,8 +843,13 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       TRY(dalloc(e, &e->dlt2, Mx * D));
     }
     if (e->has_geom) {
-      TRY(dalloc(e, &e->gp, Mx * 15 * e->v_heads));
-      TRY(dalloc(e, &e->gctx, Mx * 3 * e->v_heads));
+      if (strict) {
+        TRY(dalloc(e, &e->fgp, Mx * 15 * e->v_heads));
+        TRY(dalloc(e, &e->fgctx, Mx * 3 * e->v_heads));
+      } else {
+        TRY(dalloc(e, &e->gp, Mx * 15 * e->v_heads));
+        TRY(dalloc(e, &e->gctx, Mx * 3 * e->v_heads));
+      }
       TRY(dalloc(e, &e->f_rot, Mx * 9));
       TRY(dalloc(e, &e->f_trans, Mx * 3));
       TRY(dalloc(e, &e->f_mask, Mx));
@@ -1191,8 +1211,6 @@ int esmdiff_set_frames(esmdiff_engine* e, const float* rot, const float* trans, 
     e->frames_B = e->frames_L = 0;
     return 0;
   }
-  if (e->strict)
-    return fail(e, ESMDIFF_E_INVALID, "coordinate conditioning is not built for the float32 (strict) precision: create the engine with ESMDIFF_PRECISION_BF16");
   if (!e->has_geom)
     return fail(e, ESMDIFF_E_MISSING, "coordinates given but the weight table had no transformer.blocks.0.geom_attn.* tensors");
   if (!trans || !has_frame) return fail(e, ESMDIFF_E_INVALID, "null argument");

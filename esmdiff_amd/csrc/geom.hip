@@ -21,24 +21,31 @@
 namespace ed {
 
 __device__ __forceinline__ float gbf(const bf16_t* p) { return __uint_as_float((uint32_t)(*p) << 16); }
+__device__ __forceinline__ float gbf(const float* p) { return *p; }
 
-__global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __restrict__ P, const float* __restrict__ rot,
+// T = bf16_t: the throughput path (bare v_sqrt_f32 / v_exp_f32, softmax in base 2).  T = float: the strict path
+// (esmdiff_config.precision = F32): float32 in and out, correctly rounded sqrt, libm-grade expf, natural-base softmax.
+template <typename T>
+__global__ __launch_bounds__(64) void geom_attention_kernel(const T* __restrict__ P, const float* __restrict__ rot,
                                                            const float* __restrict__ trans,
                                                            const uint8_t* __restrict__ fmask,
                                                            const float* __restrict__ w_rot,
-                                                           const float* __restrict__ w_dist, bf16_t* __restrict__ out,
+                                                           const float* __restrict__ w_dist, T* __restrict__ out,
                                                            int L, int VH) {
+  constexpr bool STRICT = sizeof(T) == 4;
   extern __shared__ __attribute__((aligned(16))) float kl[];  // [Lk][12]: k_rot 3 | k_dist 3 | value 3 | has-frame | pad 2  (three 16-byte reads per key)
   const int b = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
   const int ldp = 15 * VH;
   const int64_t row0 = (int64_t)b * L;
   const float c = 0.57735026918962576f;  // 1/sqrt(3)
-  const float LOG2E = 1.44269504088896341f;  // softmax in base 2 (v_exp_f32 is exp2)
+  const float LOG2E = STRICT ? 1.0f : 1.44269504088896341f;  // throughput path: softmax in base 2 (v_exp_f32 is exp2)
   const float wr = w_rot[h] * c * LOG2E, wd = w_dist[h] * c * LOG2E;
+  auto gsqrt = [](float v) { return STRICT ? sqrtf(v) : __builtin_amdgcn_sqrtf(v); };
+  auto gexp = [](float v) { return STRICT ? expf(v) : __builtin_amdgcn_exp2f(v); };
   const int Lk = (L + 3) & ~3;               // key count padded to the 4-key trip; pad keys carry has-frame = 0
 
   auto load3 = [&](int64_t row, int col, float* v) {
-    const bf16_t* p = P + row * ldp + col;
+    const T* p = P + row * ldp + col;
     v[0] = gbf(p); v[1] = gbf(p + 1); v[2] = gbf(p + 2);
   };
   auto rotate = [&](const float* R, const float* v, float* o) {  // o = R v, R row-major
@@ -95,19 +102,19 @@ __global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __rest
         for (int u = 0; u < 4; ++u) {
           const float* kk = kl + (k + u) * 12;
           const float dx = qd[0] - kk[3], dy = qd[1] - kk[4], dz = qd[2] - kk[5];
-          const float v = wr * (qr[0] * kk[0] + qr[1] * kk[1] + qr[2] * kk[2]) - wd * __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);  // bare v_sqrt_f32 (1 ulp)
+          const float v = wr * (qr[0] * kk[0] + qr[1] * kk[1] + qr[2] * kk[2]) - wd * gsqrt(dx * dx + dy * dy + dz * dz);  // bare v_sqrt_f32 (1 ulp) on the bf16 path
           sc[u] = kk[9] != 0.0f ? v : -__builtin_inff();
         }
         const float mx = fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]));
         if (mx > m) {  // lazy rescale: rare after the first few trips
-          const float a = __builtin_amdgcn_exp2f(m - mx);
+          const float a = gexp(m - mx);
           den *= a; o0 *= a; o1 *= a; o2 *= a;
           m = mx;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const float* kk = kl + (k + u) * 12;
-          const float p = __builtin_amdgcn_exp2f(sc[u] - m);  // bare v_exp_f32; exp2(-inf) = 0 for keys without a frame
+          const float p = gexp(sc[u] - m);  // bare v_exp_f32 on the bf16 path; exp(-inf) = 0 for keys without a frame
           den += p;
           o0 += p * kk[6]; o1 += p * kk[7]; o2 += p * kk[8];
         }
@@ -121,29 +128,44 @@ __global__ __launch_bounds__(64) void geom_attention_kernel(const bf16_t* __rest
       r1 = R[1] * o0 + R[4] * o1 + R[7] * o2;
       r2 = R[2] * o0 + R[5] * o1 + R[8] * o2;
     }
-    bf16_t* dst = out + row * (3 * VH) + 3 * h;
-    auto f2b = [](float f) {
-      uint32_t u = __float_as_uint(f);
-      return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-    };
-    dst[0] = f2b(r0); dst[1] = f2b(r1); dst[2] = f2b(r2);
+    T* dst = out + row * (3 * VH) + 3 * h;
+    if constexpr (STRICT) {
+      dst[0] = r0; dst[1] = r1; dst[2] = r2;
+    } else {
+      auto f2b = [](float f) {
+        uint32_t u = __float_as_uint(f);
+        return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+      };
+      dst[0] = f2b(r0); dst[1] = f2b(r1); dst[2] = f2b(r2);
+    }
   }
 }
 
-hipError_t launch_geom_attention(const bf16_t* P, const float* rot, const float* trans, const uint8_t* fmask,
-                                 const float* w_rot, const float* w_dist, bf16_t* out, int B, int L, int VH,
-                                 hipStream_t stream) {
+template <typename T>
+static hipError_t launch_geom_t(const T* P, const float* rot, const float* trans, const uint8_t* fmask, const float* w_rot,
+                                const float* w_dist, T* out, int B, int L, int VH, hipStream_t stream) {
   if (B <= 0 || L <= 0) return hipSuccess;
   const size_t lds = (size_t)((L + 3) & ~3) * 12 * sizeof(float);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void*)geom_attention_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    hipFuncSetAttribute((const void*)geom_attention_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     attr_done = true;
   }
-  hipLaunchKernelGGL(geom_attention_kernel, dim3(VH, B), dim3(64), lds, stream, P, rot, trans, fmask, w_rot, w_dist, out,
+  hipLaunchKernelGGL(geom_attention_kernel<T>, dim3(VH, B), dim3(64), lds, stream, P, rot, trans, fmask, w_rot, w_dist, out,
                      L, VH);
   return hipGetLastError();
+}
+
+hipError_t launch_geom_attention(const bf16_t* P, const float* rot, const float* trans, const uint8_t* fmask,
+                                 const float* w_rot, const float* w_dist, bf16_t* out, int B, int L, int VH,
+                                 hipStream_t stream) {
+  return launch_geom_t<bf16_t>(P, rot, trans, fmask, w_rot, w_dist, out, B, L, VH, stream);
+}
+hipError_t launch_geom_attention_f32(const float* P, const float* rot, const float* trans, const uint8_t* fmask,
+                                     const float* w_rot, const float* w_dist, float* out, int B, int L, int VH,
+                                     hipStream_t stream) {
+  return launch_geom_t<float>(P, rot, trans, fmask, w_rot, w_dist, out, B, L, VH, stream);
 }
 
 }  // namespace ed

@@ -95,6 +95,10 @@ hipError_t launch_geom_attention(const bf16_t* P, const float* rot, const float*
                                  const float* w_rot, const float* w_dist, bf16_t* out, int B, int L, int VH,
                                  hipStream_t stream);
 
+hipError_t launch_geom_attention_f32(const float* P, const float* rot, const float* trans, const uint8_t* fmask,
+                                     const float* w_rot, const float* w_dist, float* out, int B, int L, int VH,
+                                     hipStream_t stream);
+
 // ---- embed.hip -------------------------------------------------------------------------------
 // x[b,l,:] = E_seq[seq] + E_struct[struct'] + c + cond   (net.py:445-466)
 hipError_t launch_embed(const int64_t* seq, const int64_t* xtok, const float* e_seq, const float* e_struct,

@@ -40,7 +40,7 @@ class Engine:
                  device: int = 0, precision: str = "bf16"):
         """precision: "bf16" (the throughput path: bf16 MFMA, f32 accumulate and residual stream) or "f32" (the strict
         path, csrc/strict.hip: float32 weights and activations on the f32-input MFMA — the reference's own arithmetic,
-        checkpoint_utils.py:59-73; ~1/12 of the throughput; no coordinate conditioning)."""
+        checkpoint_utils.py:59-73; ~1/12 of the throughput)."""
         _require_gpu()
         if precision not in N.PRECISION:
             raise ValueError(f"precision must be one of {sorted(N.PRECISION)}, got {precision!r}")
@@ -72,7 +72,7 @@ class Engine:
                                f"{self._lib.esmdiff_last_error(None).decode()}")
         del keep
         self.ld_logits = (cfg.n_structure_heads + 3) // 4 * 4
-        self.has_geom = precision == "bf16" and any(k.endswith("transformer.blocks.0.geom_attn.proj.weight") for k in state_dict)
+        self.has_geom = any(k.endswith("transformer.blocks.0.geom_attn.proj.weight") for k in state_dict)
         self.has_sigma_embedder = any(k.startswith("sigma_embedder.mlp.0.") for k in state_dict)
         self._frames = None
 

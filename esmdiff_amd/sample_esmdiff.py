@@ -38,10 +38,6 @@ from .sdk import ESMProtein, encode_sequence
 DEFAULT_NMAX = 1026 * 1026 * 32
 
 
-def mask_ids_given(args) -> bool:
-    return bool(getattr(args, "mask_ids", None))
-
-
 def batch_sizes(n_tokens: int, num_samples: int, n_max_residue_square: int = DEFAULT_NMAX, cap: int = 0):
     """sample_esmdiff.py:181-193 (the length is the TOKEN count in ddpm mode, the residue count in gibbs mode).  The
     reference's arithmetic can make the remainder batch larger than the regular ones; `cap` (the engine's max_batch)
@@ -331,8 +327,7 @@ def get_argparser(argv=None):
     p.add_argument("--parity", action="store_true", help="uniforms from torch's CPU generator, like the reference")
     p.add_argument("--precision", choices=["bf16", "f32"], default="bf16",
                    help="arithmetic of the sampling network: bf16 = the MFMA throughput path (default); f32 = the strict path, the "
-                        "reference's own float32 arithmetic (ids equal to a float32 run of the same seed; ~1/12 of the throughput; "
-                        "no coordinate conditioning)")
+                        "reference's own float32 arithmetic (ids equal to a float32 run of the same seed; ~1/12 of the throughput)")
     p.add_argument("--decoder_precision", choices=["f32", "bf16"], default="f32",
                    help="arithmetic of the structure decoder: f32 (default, backbone within 1e-4 A of a float32 decode) or bf16")
     p.add_argument("--no_timestamp", action="store_true")
@@ -358,9 +353,6 @@ def main(argv=None):
                          "--random_init (synthetic weights)")
     if args.esm3_ckpt and args.ckpt is None:
         assert args.mode == "gibbs", "Only Gibbs sampling is supported for the pre-trained ESM3 model."
-    if args.precision == "f32" and mask_ids_given(args) and args.mode == "gibbs":
-        raise SystemExit("--precision f32 has no coordinate conditioning (gibbs-mode inpainting hands the known backbone to block "
-                         "0's geometric attention): use --precision bf16, or --mode ddpm whose prior is token-space")
     if args.parity and world > 1:
         raise SystemExit("--parity replays the reference's single-process torch.rand stream; it cannot be sharded over "
                          "ranks (every rank would draw the same uniforms) — run it on one GPU")

@@ -60,7 +60,7 @@ typedef enum { ESMDIFF_F32 = 0, ESMDIFF_BF16 = 1 } esmdiff_dtype;
  *         (checkpoint_utils.py:59-73 loads float32; decode at sample_esmdiff.py:40-61), ~1/12 of the bf16 throughput.
  *         It is what north_star's floating-point bars are stated against (ids equal under a fixed seed, decoded backbone
  *         within 1e-4 A) and the structure decoder's default on the Python side.  A row's result does not depend on the
- *         batch it is computed in.  Not available with coordinate conditioning (esmdiff_set_frames -> ESMDIFF_E_INVALID). */
+ *         batch it is computed in.  Coordinate conditioning (esmdiff_set_frames) runs in float32 too. */
 typedef enum { ESMDIFF_PRECISION_BF16 = 0, ESMDIFF_PRECISION_F32 = 1 } esmdiff_precision;
 
 /* Hyper-parameters of CustomizedESM3 (net.py:322-332) + TimestepEmbedder (net.py:487) +

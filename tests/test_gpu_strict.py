@@ -289,15 +289,11 @@ def test_structure_decoder_full_depth_rmsd_1e4():
 def test_strict_engine_refuses_what_it_does_not_build():
     from esmdiff_amd.config import TINY
     from esmdiff_amd.engine import Engine
-    from esmdiff_amd.geometry import build_affine3d_from_coordinates
     from esmdiff_amd.weights import random_init_state_dict
     sd = random_init_state_dict(TINY, seed=1, with_geom=True)
     with pytest.raises(ValueError):
         Engine(TINY, sd, max_batch=2, max_len=16, precision="fp8")
     eng = Engine(TINY, sd, max_batch=2, max_len=16, precision="f32")
-    xyz = torch.randn(2, 16, 3, 3)
-    with pytest.raises(RuntimeError, match="strict"):
-        eng.set_frames(*build_affine3d_from_coordinates(xyz))
     with pytest.raises(RuntimeError, match="strict"):
         eng.attention(torch.zeros(32, 3 * TINY.d_model, dtype=torch.bfloat16, device="cuda"),
                       torch.ones(TINY.d_model), torch.ones(TINY.d_model), 2, 16)
@@ -306,8 +302,7 @@ def test_strict_engine_refuses_what_it_does_not_build():
 
 def test_cli_precision_flags(tmp_path):
     """`--precision f32` end to end through the reference-shaped CLI (both drivers), decoder at its f32 default: the run's
-    json records the arithmetic that produced it, the files are the reference's artefacts; gibbs-mode inpainting (needs
-    block 0's geometric attention) is refused up front on the strict engine."""
+    json records the arithmetic that produced it, the files are the reference's artefacts."""
     from esmdiff_amd.sample_esmdiff import main
     common = ["--random_init", "--tiny", "--random_init_decoder", "--synthetic_len", "30", "--num_samples", "3", "--num_steps", "4",
               "--output", str(tmp_path), "--no_timestamp", "--precision", "f32"]
@@ -319,10 +314,48 @@ def test_cli_precision_flags(tmp_path):
     assert ids_f32.shape == (3, 30) and (d / "synthetic30.pdb").exists()
     main(common)                                                         # default mode: gibbs
     assert (tmp_path / "T1.4_step4_topp0.9_N3" / "synthetic30.tokens.npy").exists()
-    with pytest.raises(SystemExit, match="coordinate conditioning"):
-        main(common + ["--mask_ids", "3,4"])
     # the bf16 engine on the same seed: same ids on this tiny case or not, but its json says bf16 / f32 decoder
     out2 = tmp_path / "bf16"
     main([a if a != str(tmp_path) else str(out2) for a in common[:-2]] + ["--mode", "ddpm"])
     meta2 = json.loads((out2 / "step4_eps1e-05_N3" / "synthetic30.json").read_text())
     assert meta2["precision"] == "bf16" and meta2["decoder_precision"] == "f32"
+
+
+@pytest.mark.parametrize("B,L", [(2, 60), (2, 258)])
+def test_strict_forward_with_coordinates(B, L):
+    """Coordinate conditioning (block 0's geometric attention, the gibbs-mode inpainting path: sample_esmdiff.py:88-96) on the
+    strict engine at the shipped geometry (256 vector heads, d 1536, 3 blocks): float32 projection / geometric attention /
+    output projection against oracle/geom_ref.py inside the whole network — partly masked (Inf) coordinates, NaN at BOS / EOS."""
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.geometry import build_affine3d_from_coordinates
+    from esmdiff_amd.weights import random_init_state_dict
+    from oracle.esm3_ref import build_from_state_dict
+    cfg = ModelConfig(n_layers=3)
+    sd = random_init_state_dict(cfg, seed=8, with_geom=True)
+    net, _ = build_from_state_dict(cfg, sd)
+    g = torch.Generator().manual_seed(L + 1)
+    ca = torch.cumsum(torch.randn(B, L, 3, generator=g) * 2.2, 1)
+    xyz = torch.stack([ca + torch.randn(B, L, 3, generator=g) * 0.8, ca, ca + torch.randn(B, L, 3, generator=g) * 0.8], 2)
+    xyz[:, 0], xyz[:, -1] = float("nan"), float("nan")
+    xyz[:, L // 3:L // 3 + 12] = float("inf")
+    seq = _seq(B, L, g)
+    x = torch.full((B, L), MASK, dtype=torch.int64)
+    x[:, 5:20] = torch.randint(0, 4096, (B, 15), generator=g)
+    with torch.no_grad():
+        ref = net(structure_tokens=x, sequence_tokens=seq, structure_coords=xyz).structure_logits
+        ref0 = net(structure_tokens=x, sequence_tokens=seq).structure_logits
+    eng = Engine(cfg, sd, max_batch=B, max_len=L, precision="f32")
+    off = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu().clone()
+    eng.set_frames(*build_affine3d_from_coordinates(xyz))
+    got = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu().clone()
+    eng.set_frames(*build_affine3d_from_coordinates(torch.full((B, L, 3, 3), float("nan"))))
+    nan = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu().clone()
+    eng.close()
+    s = _stats(got, ref)
+    s["conditioning_effect_max"] = float((ref - ref0).abs().max())
+    s["unconditioned_max_err"] = float((off - ref0).abs().max())
+    _record(f"strict_wide3_coords_B{B}_L{L}", s)
+    assert s["conditioning_effect_max"] > 5e-2
+    assert s["max_err"] < 5e-5 and s["unconditioned_max_err"] < 2e-5, s
+    assert torch.equal(nan, off)                         # all-unknown coordinates: the branch contributes exactly zero
