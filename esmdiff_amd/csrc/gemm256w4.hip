@@ -152,13 +152,24 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16_t* __restr
 #ifndef ED_W4_M0SPLIT
 #define ED_W4_M0SPLIT 1
 #endif
-  auto glds = [&](const char* sbase, uint32_t voff, uint32_t lds_dst, int phase) {
-    if (phase == 0)
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
-    else if (phase == 1)
+  // cache policy of the operand streams (-DED_W4_POL_A / -DED_W4_POL_W = "" | " nt" | " sc1" ...; A/B builds only: the
+  // default policy measured best, profiles/r03_gemm_cache_policy.txt)
+#ifndef ED_W4_POL_A
+#define ED_W4_POL_A ""
+#endif
+#ifndef ED_W4_POL_W
+#define ED_W4_POL_W ""
+#endif
+  auto glds = [&](const char* sbase, uint32_t voff, uint32_t lds_dst, int phase, bool is_w) {
+    if (phase == 0) {
+      if (is_w) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ED_W4_POL_W : : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+      else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ED_W4_POL_A : : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+    } else if (phase == 1) {
       asm volatile("s_mov_b32 m0, %0" : : "s"(lds_dst) : "memory");
-    else
-      asm volatile("global_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase) : "memory");
+    } else {
+      if (is_w) asm volatile("global_load_lds_dwordx4 %0, %1" ED_W4_POL_W : : "v"(voff), "s"(sbase) : "memory");
+      else asm volatile("global_load_lds_dwordx4 %0, %1" ED_W4_POL_A : : "v"(voff), "s"(sbase) : "memory");
+    }
   };
   int xnext = 0;  // wave-uniform: this workgroup has another tile after the current one
   const int nk = K / BK;
@@ -170,9 +181,9 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16_t* __restr
     const uint32_t dst = lds_base + (p * 2 + buf) * HALF_BYTES + (i * 4 + wave) * 1024;
     const char* sb = (p < 2 ? Ab : Wb) + (size_t)v * kstride;  // one scalar base per operand and K-tile
     if constexpr (!decltype(NEXT)::value) {
-      glds(sb, p < 2 ? a_off[p][i] : w_off[p - 2][i], dst, phase);
+      glds(sb, p < 2 ? a_off[p][i] : w_off[p - 2][i], dst, phase, p >= 2);
     } else {
-      if (xnext) glds(sb, p < 2 ? a_offn[p][i] : w_offn[p - 2][i], dst, phase);
+      if (xnext) glds(sb, p < 2 ? a_offn[p][i] : w_offn[p - 2][i], dst, phase, p >= 2);
     }
   };
 
