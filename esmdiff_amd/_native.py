@@ -60,6 +60,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch FIRST: PyTorch-ROCm ships its own libamdhip64 / HSA runtime, and the tensors handed to this library live in that
+    # runtime's context.  libesmdiff_hip.so only names "libamdhip64.so.7"; loaded after torch it binds to the copy torch
+    # already mapped (one runtime per process), loaded before torch it would pull in /opt/rocm's and the process would hold
+    # two runtimes — the second one then reports no devices (seen with `python __graft_entry__.py --smoke`, where build()
+    # loaded this library before smoke() imported torch).
+    import torch  # noqa: F401
     if not _LIB_PATH.exists():
         raise RuntimeError(
             f"{_LIB_PATH} not found: build it with `python -m esmdiff_amd.build` (needs hipcc). "
