@@ -76,6 +76,12 @@ __device__ __forceinline__ bf16x4 lds_read_tr16(const char* p) {  // ds_read_b64
 #ifndef ED_ATTN_ABL
 #define ED_ATTN_ABL 0
 #endif
+#ifdef ED_ATTN_TRACE
+__device__ unsigned long long g_attn_trace[512 * 4 * 32];
+extern "C" int esmdiff_debug_attn_trace(unsigned long long* out_host) {   // debug builds only (scratch/attn_trace.py)
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_attn_trace), sizeof(g_attn_trace));
+}
+#endif
 #define ED_ATTN_NAME attention_kernel_occ3
 #define ED_ATTN_WPE 3
 #include "attention_kernel.inc"
