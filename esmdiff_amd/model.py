@@ -26,7 +26,7 @@ from .weights import load_checkpoint_state_dict, random_init_state_dict
 class MaskedDiffusionLanguageModeling:
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: ModelConfig = ESM3_OPEN,
                  noise_schedule: Optional[Noise] = None, max_batch: int = 128, max_len: int = 1026,
-                 device: int = 0, noise_removal: bool = True, precision: str = "bf16"):
+                 device: int = 0, noise_removal: bool = True, precision: str = "bf16", step0_sharing: bool = True):
         if noise_schedule is None:
             print("Using default noise schedule: CosineNoise(eps=1e-3)")    # model.py:345-347
             noise_schedule = CosineNoise(eps=1e-3)
@@ -38,6 +38,11 @@ class MaskedDiffusionLanguageModeling:
         self.mask_index = STRUCTURE_MASK_TOKEN
         self.neg_infinity = -1000000.0
         self.net = Engine(cfg, state_dict, max_batch=max_batch, max_len=max_len, device=device, precision=precision)
+        # exact step-0 sharing (include/esmdiff_hip.h): the CLI repeats ONE sequence per batch, so the first forward of a run has
+        # identical rows; the engine checks that on the device and then serves all samples from a sub-batch forward — ids are
+        # bit-identical to the unshared loop (tests/test_gpu_fullwidth.py::test_step0_sharing_is_exact).  bench.py's headline
+        # run builds its Engine directly and leaves it off.
+        self.net.set_step0_sharing(step0_sharing)
         self.device = self.net.device
         self._parity_gen = None      # noise="torch-cpu": ONE generator stream per run, like the reference's global RNG
         self._parity_seed = None
