@@ -100,6 +100,7 @@ struct esmdiff_engine {
   bool strict = false;
   float *fhead_w0 = nullptr, *fhead_w3 = nullptr, *fpl_w0 = nullptr, *fpl_w3 = nullptr, *fpw_down = nullptr;
   float *fg_proj = nullptr, *fg_out = nullptr, *fgp = nullptr, *fgctx = nullptr;
+  float *fpw_l1 = nullptr, *fpw_l2 = nullptr, *fpair_x = nullptr, *fpair_h = nullptr;   // pairwise head in float32
   float *fh = nullptr, *fh2 = nullptr, *fqkv = nullptr, *fq = nullptr, *fk = nullptr, *fctx = nullptr, *fgu = nullptr,
         *fmid = nullptr, *fpair_qk = nullptr;
   // step-0 sharing (esmdiff_set_step0_sharing): when every sample of a sampling call starts from identical inputs, the first
@@ -368,10 +369,8 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
   RUN(S_LN, launch_layernorm_f32(e->x, e->final_ln_w, nullptr, e->fh, M, D, st));
   RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fhead_w0, e->fh2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_F32EPI_BIAS_GELU, st));
   if (e->has_plddt) RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fpl_w0, e->fctx, e->pl_b0, M, D, D, D, D, 1.f, ESMDIFF_F32EPI_BIAS_GELU, st));
-  if (e->has_pair) {   // the pairwise confidence head keeps its bf16 MFMA pipeline (pTM / PAE are not under the 1e-4 A bar)
+  if (e->has_pair)     // the pairwise confidence head's down-projection (q | k, 64 + 64 columns per token), float32 like the rest
     RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fpw_down, e->fpair_qk, nullptr, M, 128, D, 128, 128, 1.f, ESMDIFF_F32EPI_STORE, st));
-    RUN(S_HEAD, launch_to_bf16(e->fpair_qk, ESMDIFF_F32, e->pair_qk, (int64_t)M * 128, st));
-  }
   RUN(S_LN, launch_layernorm_f32(e->fh2, e->head_ln_w, e->head_ln_b, e->fh, M, D, st));
   if (e->has_plddt) RUN(S_LN, launch_layernorm_f32(e->fctx, e->pl_ln_w, e->pl_ln_b, e->fq, M, D, st));
   RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fhead_w3, logits, e->head_b3, M, c.vocab_out, D, ld, c.vocab_out, 1.f, ESMDIFF_F32EPI_STORE, st));
@@ -720,11 +719,13 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       const std::string ph = "pairwise_classification_head.";
       if (strict) TRY(load_f32(e, t, ph + "downproject.weight", {128, D}, &e->fpw_down));
       else TRY(load_bf16(e, t, ph + "downproject.weight", {128, D}, &e->pw_down));
-      TRY(load_bf16(e, t, ph + "linear1.weight", {128, 128}, &e->pw_l1));
+      if (strict) TRY(load_f32(e, t, ph + "linear1.weight", {128, 128}, &e->fpw_l1));
+      else TRY(load_bf16(e, t, ph + "linear1.weight", {128, 128}, &e->pw_l1));
       TRY(load_f32(e, t, ph + "norm.weight", {128}, &e->pw_ln_w));
       TRY(load_f32(e, t, ph + "norm.bias", {128}, &e->pw_ln_b));
       // rows [distogram 64 | direction 96 | PAE 64]; padded so that the 128-row GEMM tile starting at row 160 stays inside
-      TRY(load_bf16(e, t, ph + "linear2.weight", {224, 128}, &e->pw_l2, 384));
+      if (strict) TRY(load_f32(e, t, ph + "linear2.weight", {224, 128}, &e->fpw_l2));
+      else TRY(load_bf16(e, t, ph + "linear2.weight", {224, 128}, &e->pw_l2, 384));
       TRY(dalloc(e, &e->zeros128, (size_t)128, true));
       e->has_pair = true;
     }
@@ -930,8 +931,9 @@ int esmdiff_decoder_create(const esmdiff_config* cfg, const esmdiff_weight* tabl
 // linear1 -> GELU -> LayerNorm -> linear2[PAE bins] on the MFMA GEMM, then the bin reduction (csrc/pairwise.hip).
 static int pairwise_confidence(esmdiff_engine* e, const int64_t* tokens, float* ptm, float* pae, int B, int L, hipStream_t st) {
   const int64_t LL = (int64_t)L * L;
-  // chunk of whole samples: ~1.5 GB of pair rows at most (768 B per row: features, hidden, 64 f32 logits)
-  int cb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(1536ll << 20) / (LL * 768)));
+  // chunk of whole samples: ~1.5 GB of pair rows at most (768 B per row: features, hidden, 64 f32 logits; 1280 B in float32)
+  const size_t esz = e->strict ? 4 : 2;
+  int cb = (int)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(1536ll << 20) / (LL * (int64_t)(256 * esz + 256))));
   if (e->pair_rows_cap < (int64_t)cb * LL) {
     HIP_TRY(e, hipStreamSynchronize(st));
     for (void* p : {(void*)e->pair_x, (void*)e->pair_h, (void*)e->pair_logits})
@@ -940,15 +942,26 @@ static int pairwise_confidence(esmdiff_engine* e, const int64_t* tokens, float* 
     e->pair_logits = nullptr;
     e->pair_rows_cap = 0;
     const size_t rows = (size_t)cb * LL;
-    if (hipMalloc(&e->pair_x, rows * 128 * 2) != hipSuccess || hipMalloc(&e->pair_h, rows * 128 * 2) != hipSuccess ||
+    if (hipMalloc(&e->pair_x, rows * 128 * esz) != hipSuccess || hipMalloc(&e->pair_h, rows * 128 * esz) != hipSuccess ||
         hipMalloc(&e->pair_logits, rows * 64 * 4) != hipSuccess)
       return fail(e, ESMDIFF_E_HIP, "pairwise head workspace for %d x %d^2 pair rows: out of memory", cb, L);
     e->pair_rows_cap = (int64_t)rows;
+    e->fpair_x = reinterpret_cast<float*>(e->pair_x);   // the same allocations, viewed as float32 on a strict engine
+    e->fpair_h = reinterpret_cast<float*>(e->pair_h);
   }
   for (int b0 = 0; b0 < B; b0 += cb) {
     const int nb = std::min(cb, B - b0);
     const int64_t rows = (int64_t)nb * LL;
     if (rows > 0x7fffffffll) return fail(e, ESMDIFF_E_INVALID, "pairwise head: too many pair rows in one chunk");
+    if (e->strict) {   // linear1 -> GELU -> LayerNorm -> linear2[PAE rows 160..223], all float32 (no biases in this head)
+      HIP_TRY(e, launch_pair_features_f32(e->fpair_qk + (int64_t)b0 * L * 128, e->fpair_x, nb, L, st));
+      HIP_TRY(e, launch_gemm_f32(e->fpair_x, 128, e->fpw_l1, e->fpair_h, nullptr, (int)rows, 128, 128, 128, 128, 1.f, ESMDIFF_F32EPI_BIAS_GELU, st));
+      HIP_TRY(e, launch_layernorm_f32(e->fpair_h, e->pw_ln_w, e->pw_ln_b, e->fpair_x, (int)rows, 128, st));
+      HIP_TRY(e, launch_gemm_f32(e->fpair_x, 128, e->fpw_l2 + 160 * 128, e->pair_logits, nullptr, (int)rows, 64, 128, 64, 64, 1.f, ESMDIFF_F32EPI_STORE, st));
+      HIP_TRY(e, launch_pae_tm(e->pair_logits, tokens + (int64_t)b0 * L, e->tm_rows + (int64_t)b0 * L, pae ? pae + (int64_t)b0 * LL : nullptr,
+                               ptm + b0, nb, L, 31.0f, st));
+      continue;
+    }
     HIP_TRY(e, launch_pair_features(e->pair_qk + (int64_t)b0 * L * 128, e->pair_x, nb, L, st));
     HIP_TRY(e, launch_gemm_bf16(e->pair_x, e->pw_l1, e->pair_h, e->zeros128, (int)rows, 128, 128, 128, 128, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, st));
     HIP_TRY(e, launch_layernorm_bf16_in(e->pair_h, e->pw_ln_w, e->pw_ln_b, e->pair_x, (int)rows, 128, st));

@@ -112,6 +112,7 @@ hipError_t launch_dim6_to_backbone(const float* v, int ld, float* out, int M, fl
 hipError_t launch_delay_us(int us, hipStream_t stream);
 // pairwise.hip: the decoder's pairwise confidence head (pair features; PAE / pTM from the 64 PAE bin logits)
 hipError_t launch_pair_features(const bf16_t* qk, bf16_t* X, int nb, int L, hipStream_t stream);
+hipError_t launch_pair_features_f32(const float* qk, float* X, int nb, int L, hipStream_t stream);
 hipError_t launch_pae_tm(const float* logits, const int64_t* tokens, float* tm_rows, float* pae, float* ptm, int nb, int L,
                          float max_bin, hipStream_t stream);
 hipError_t launch_plddt_mean(const float* v, int ld, int n_bins, float* out, int M, hipStream_t stream);

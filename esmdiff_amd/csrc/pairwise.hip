@@ -50,6 +50,32 @@ __global__ __launch_bounds__(256) void pair_features_kernel(const bf16_t* __rest
   *reinterpret_cast<uint4*>(X + row * 128 + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
+// float32 form (precision = F32): one thread = 4 feature columns of one pair row
+__global__ __launch_bounds__(256) void pair_features_f32_kernel(const float* __restrict__ qk, float* __restrict__ X, int L,
+                                                                int64_t n_rows) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_rows * 32) return;
+  const int64_t row = idx >> 5;
+  const int c = (int)(idx & 31);               // chunk of 4 columns: 0..15 product, 16..31 difference
+  const int64_t LL = (int64_t)L * L;
+  const int64_t b = row / LL;
+  const int ij = (int)(row - b * LL), i = ij / L, j = ij - i * L;
+  const int d0 = (c & 15) * 4;
+  const f32x4 q = *reinterpret_cast<const f32x4*>(qk + ((int64_t)b * L + j) * 128 + d0);
+  const f32x4 k = *reinterpret_cast<const f32x4*>(qk + ((int64_t)b * L + i) * 128 + 64 + d0);
+  f32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = c < 16 ? q[e] * k[e] : q[e] - k[e];
+  *reinterpret_cast<f32x4*>(X + row * 128 + c * 4) = o;
+}
+
+hipError_t launch_pair_features_f32(const float* qk, float* X, int nb, int L, hipStream_t stream) {
+  const int64_t n_rows = (int64_t)nb * L * L;
+  if (n_rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(pair_features_f32_kernel, dim3((unsigned)((n_rows * 32 + 255) / 256)), dim3(256), 0, stream, qk, X, L, n_rows);
+  return hipGetLastError();
+}
+
 hipError_t launch_pair_features(const bf16_t* qk, bf16_t* X, int nb, int L, hipStream_t stream) {
   const int64_t n_rows = (int64_t)nb * L * L;
   if (n_rows <= 0) return hipSuccess;
