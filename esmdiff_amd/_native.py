@@ -102,7 +102,7 @@ def lib():
     L.esmdiff_metrics_js_columns.argtypes = [vp, i32, vp, vp, i32, vp, i32, i32, i32, f64p, vp]
     L.esmdiff_metrics_validity.argtypes = [vp, i32, i32, f64, f64, i32, f64p, vp]
     L.esmdiff_metrics_bonding_validity.argtypes = [vp, i32, vp, i32, i32, f64p, vp]
-    L.esmdiff_encoder_create.argtypes = [i32] * 8 + [ctypes.POINTER(Weight), i32, i32, ctypes.POINTER(vp)]
+    L.esmdiff_encoder_create.argtypes = [i32] * 9 + [ctypes.POINTER(Weight), i32, i32, ctypes.POINTER(vp)]
     L.esmdiff_encoder_destroy.argtypes = [vp]
     L.esmdiff_encoder_destroy.restype = None
     L.esmdiff_encoder_last_error.argtypes = [vp]

@@ -171,9 +171,18 @@ __global__ __launch_bounds__(256) void codebook_kernel(const float* __restrict__
   if (tid == 0) tok[r] = has[r] ? ri[0] : ESMDIFF_MASK_ID;
 }
 
+// z[r] = has[r] ? x[r*K] : 0 in float32 (precision = F32: x already holds every residual)
+__global__ __launch_bounds__(256) void query_rows_f32_kernel(const float* __restrict__ x, const uint8_t* __restrict__ has, int K,
+                                                             int D, float* __restrict__ z) {
+  const int64_t r = blockIdx.x;
+  const bool keep = has[r] != 0;
+  for (int c = threadIdx.x; c < D; c += 256) z[r * D + c] = keep ? x[r * K * D + c] : 0.f;
+}
+
 struct Block {
   float *s_norm_w, *proj_b, *out_b, *w_rot, *w_dist, *ln_w, *ln_b, *b1, *b3;
   bf16_t *proj_w, *out_w, *w1, *w3;
+  float *fproj_w, *fout_w, *fw1, *fw3;   // precision = F32
 };
 
 }  // namespace
@@ -188,6 +197,8 @@ struct esmdiff_encoder {
   std::vector<Block> blocks;
   float *relpos = nullptr, *vq_b = nullptr, *code = nullptr;
   bf16_t* vq_w = nullptr;
+  float* fvq_w = nullptr;
+  bool strict = false;   // precision = F32: float32 weights and activations, the linears on the f32-input MFMA (csrc/strict.hip)
 };
 
 namespace {
@@ -262,9 +273,10 @@ void esmdiff_encoder_destroy(esmdiff_encoder* e) {
 }
 
 int esmdiff_encoder_create(int32_t d_model, int32_t v_heads, int32_t n_layers, int32_t ffn_hidden, int32_t d_out,
-                           int32_t n_codes, int32_t knn, int32_t relpos_bins, const esmdiff_weight* table, int32_t n,
-                           int32_t device, esmdiff_encoder** out) {
+                           int32_t n_codes, int32_t knn, int32_t relpos_bins, int32_t precision, const esmdiff_weight* table,
+                           int32_t n, int32_t device, esmdiff_encoder** out) {
   if (!table || !out || n <= 0) return efail(nullptr, ESMDIFF_E_INVALID, "null argument");
+  if (precision != ESMDIFF_PRECISION_BF16 && precision != ESMDIFF_PRECISION_F32) return efail(nullptr, ESMDIFF_E_INVALID, "precision: 0 (bf16) or 1 (f32)");
   *out = nullptr;
   if (d_model % 256 || d_model > 2048 || v_heads % 128 || ffn_hidden % 128 || d_out % 128 || n_layers <= 0 || knn <= 0 ||
       n_codes <= 0 || relpos_bins <= 0)
@@ -275,6 +287,8 @@ int esmdiff_encoder_create(int32_t d_model, int32_t v_heads, int32_t n_layers, i
   esmdiff_encoder* e = new esmdiff_encoder;
   e->device = device; e->D = d_model; e->VH = v_heads; e->FH = ffn_hidden; e->n_layers = n_layers; e->d_out = d_out;
   e->n_codes = n_codes; e->knn = knn; e->bins = relpos_bins;
+  e->strict = precision == ESMDIFF_PRECISION_F32;
+  const bool strict = e->strict;
   const int D = d_model, VH = v_heads, FH = ffn_hidden;
 #define ETRY(x)                        \
   do {                                 \
@@ -290,20 +304,22 @@ int esmdiff_encoder_create(int32_t d_model, int32_t v_heads, int32_t n_layers, i
     Block& b = e->blocks[i];
     const std::string p = "transformer.blocks." + std::to_string(i) + ".";
     ETRY(load(e, table, n, p + "geom_attn.s_norm.weight", {D}, &b.s_norm_w, nullptr));
-    ETRY(load(e, table, n, p + "geom_attn.proj.weight", {15 * VH, D}, nullptr, &b.proj_w));
+    b.proj_w = b.out_w = b.w1 = b.w3 = nullptr;
+    b.fproj_w = b.fout_w = b.fw1 = b.fw3 = nullptr;
+    ETRY(load(e, table, n, p + "geom_attn.proj.weight", {15 * VH, D}, strict ? &b.fproj_w : nullptr, &b.proj_w));
     ETRY(load(e, table, n, p + "geom_attn.proj.bias", {15 * VH}, &b.proj_b, nullptr));
-    ETRY(load(e, table, n, p + "geom_attn.out_proj.weight", {D, 3 * VH}, nullptr, &b.out_w));
+    ETRY(load(e, table, n, p + "geom_attn.out_proj.weight", {D, 3 * VH}, strict ? &b.fout_w : nullptr, &b.out_w));
     ETRY(load(e, table, n, p + "geom_attn.out_proj.bias", {D}, &b.out_b, nullptr));
     ETRY(load(e, table, n, p + "geom_attn.rotation_scale_per_head", {VH}, &b.w_rot, nullptr));
     ETRY(load(e, table, n, p + "geom_attn.distance_scale_per_head", {VH}, &b.w_dist, nullptr));
     ETRY(load(e, table, n, p + "ffn.0.weight", {D}, &b.ln_w, nullptr));
     ETRY(load(e, table, n, p + "ffn.0.bias", {D}, &b.ln_b, nullptr));
-    ETRY(load(e, table, n, p + "ffn.1.weight", {2 * FH, D}, nullptr, &b.w1));
+    ETRY(load(e, table, n, p + "ffn.1.weight", {2 * FH, D}, strict ? &b.fw1 : nullptr, &b.w1));
     ETRY(load(e, table, n, p + "ffn.1.bias", {2 * FH}, &b.b1, nullptr));
-    ETRY(load(e, table, n, p + "ffn.3.weight", {D, FH}, nullptr, &b.w3));
+    ETRY(load(e, table, n, p + "ffn.3.weight", {D, FH}, strict ? &b.fw3 : nullptr, &b.w3));
     ETRY(load(e, table, n, p + "ffn.3.bias", {D}, &b.b3, nullptr));
   }
-  ETRY(load(e, table, n, "pre_vq_proj.weight", {d_out, D}, nullptr, &e->vq_w));
+  ETRY(load(e, table, n, "pre_vq_proj.weight", {d_out, D}, strict ? &e->fvq_w : nullptr, &e->vq_w));
   ETRY(load(e, table, n, "pre_vq_proj.bias", {d_out}, &e->vq_b, nullptr));
   ETRY(load(e, table, n, "codebook.embeddings", {n_codes, d_out}, &e->code, nullptr));
   if (hipDeviceSynchronize() != hipSuccess) ETRY(efail(e, ESMDIFF_E_HIP, "weight conversion failed"));
@@ -346,6 +362,30 @@ int esmdiff_encoder_encode(esmdiff_encoder* e, const float* ca, const float* rot
                      e->bins, x, nrot, ntrans, nmask);
   HT(hipGetLastError());
   const int Mi = (int)M;
+  if (e->strict) {
+    // float32 end to end: x is updated in place by the residual epilogues (x + (acc + bias) / 1), the SwiGLU bias rides the
+    // FFN-up GEMM's store epilogue.  Same order of operations as oracle/encoder_ref.py.
+    float *fh = t.get<float>(M * D), *fP = t.get<float>(M * 15 * VH), *fG = t.get<float>(M * 3 * VH), *fU = t.get<float>(M * 2 * FH),
+          *fmid = t.get<float>(M * FH), *fz = t.get<float>(R * D);
+    if (!fh || !fP || !fG || !fU || !fmid || !fz) return efail(e, ESMDIFF_E_HIP, "encoder scratch allocation failed");
+    for (const Block& b : e->blocks) {
+      HT(launch_layernorm_f32(x, b.s_norm_w, nullptr, fh, Mi, D, st));
+      HT(launch_gemm_f32(fh, D, b.fproj_w, fP, b.proj_b, Mi, 15 * VH, D, 15 * VH, 15 * VH, 1.f, ESMDIFF_F32EPI_STORE, st));
+      HT(launch_geom_attention_f32(fP, nrot, ntrans, nmask, b.w_rot, b.w_dist, fG, (int)R, K, VH, st));
+      HT(launch_gemm_f32(fG, 3 * VH, b.fout_w, x, b.out_b, Mi, D, 3 * VH, D, D, 1.f, ESMDIFF_F32EPI_RESID_DIV, st));
+      HT(launch_layernorm_f32(x, b.ln_w, b.ln_b, fh, Mi, D, st));
+      HT(launch_gemm_f32(fh, D, b.fw1, fU, b.b1, Mi, 2 * FH, D, 2 * FH, 2 * FH, 1.f, ESMDIFF_F32EPI_STORE, st));
+      HT(launch_swiglu_f32(fU, fmid, Mi, FH, st));
+      HT(launch_gemm_f32(fmid, FH, b.fw3, x, b.b3, Mi, D, FH, D, D, 1.f, ESMDIFF_F32EPI_RESID_DIV, st));
+    }
+    hipLaunchKernelGGL(query_rows_f32_kernel, dim3((unsigned)R), dim3(256), 0, st, x, has_frame, K, D, fz);
+    HT(launch_gemm_f32(fz, D, e->fvq_w, zq, e->vq_b, (int)R, e->d_out, D, e->d_out, e->d_out, 1.f, ESMDIFF_F32EPI_STORE, st));
+    hipLaunchKernelGGL(codebook_kernel, dim3((unsigned)R), dim3(256), (size_t)e->d_out * sizeof(float), st, zq, e->code, has_frame,
+                       e->n_codes, e->d_out, tokens);
+    HT(hipGetLastError());
+    HT(hipStreamSynchronize(st));
+    return 0;
+  }
   bool pending = false;
   for (const Block& b : e->blocks) {
     // x += dF (previous block's FFN); h = s_norm(x)

@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         } else if constexpr (EPI == ESMDIFF_F32EPI_BIAS_GELU) {
           v += bv;
           *o = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-        } else {   // residual: x = x + acc / scale   (esm UnifiedTransformerBlock: x + r / scaling_factor)
-          *o = *o + v / div;
+        } else {   // residual: x = x + (acc [+ bias]) / scale   (esm UnifiedTransformerBlock: x + r / scaling_factor)
+          *o = *o + (bias ? v + bv : v) / div;
         }
       }
     }

@@ -386,8 +386,13 @@ class StructureEncoder:
     """Backbone coordinates -> structure tokens on the device (esmdiff_encoder_create / esmdiff_encoder_encode): what the
     reference gets from `model.encode(ESMProtein(coordinates=...))`, /root/reference/slm/models/utils.py:136-137."""
 
-    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], device: int = 0):
+    def __init__(self, cfg, state_dict: Dict[str, torch.Tensor], device: int = 0, precision: str = "f32"):
+        """precision defaults to "f32" (csrc/strict.hip): the encoder runs once per input structure on B*L*16 neighbourhood
+        rows, and its output is a nearest-code search where bf16 GEMM noise flips 1-2 % of the codes at near-ties."""
         _require_gpu()
+        if precision not in N.PRECISION:
+            raise ValueError(f"precision must be one of {sorted(N.PRECISION)}, got {precision!r}")
+        self.precision = precision
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         self._lib = N.lib()
@@ -404,7 +409,8 @@ class StructureEncoder:
                                     d.dim(), shape)
             torch.cuda.synchronize()
             code = self._lib.esmdiff_encoder_create(cfg.d_model, cfg.v_heads, cfg.n_layers, cfg.ffn_hidden, cfg.d_out,
-                                                    cfg.n_codes, cfg.knn, cfg.relpos_bins, table, len(state_dict), device,
+                                                    cfg.n_codes, cfg.knn, cfg.relpos_bins, N.PRECISION[precision], table,
+                                                    len(state_dict), device,
                                                     ctypes.byref(self._h))
         if code != 0:
             raise RuntimeError(f"esmdiff_encoder_create failed ({code}): {self._lib.esmdiff_encoder_last_error(None).decode()}")

@@ -329,7 +329,8 @@ def get_argparser(argv=None):
                    help="arithmetic of the sampling network: bf16 = the MFMA throughput path (default); f32 = the strict path, the "
                         "reference's own float32 arithmetic (ids equal to a float32 run of the same seed; ~1/12 of the throughput)")
     p.add_argument("--decoder_precision", choices=["f32", "bf16"], default="f32",
-                   help="arithmetic of the structure decoder: f32 (default, backbone within 1e-4 A of a float32 decode) or bf16")
+                   help="arithmetic of the VQ-VAE structure decoder (and encoder): f32 (default, backbone within 1e-4 A of a float32 "
+                        "decode, encoder codes equal to a float32 encoder's) or bf16")
     p.add_argument("--no_timestamp", action="store_true")
     return p.parse_args(argv)
 
@@ -412,7 +413,7 @@ def main(argv=None):
         ecfg = TINY_ENCODER if args.tiny else STRUCTURE_ENCODER_V0
         esd = (torch.load(args.encoder_ckpt, map_location="cpu", weights_only=True) if args.encoder_ckpt
                else random_init_encoder_state_dict(ecfg, seed=args.seed, device=f"cuda:{local_rank}"))
-        encoder = StructureEncoder(ecfg, esd, device=local_rank)
+        encoder = StructureEncoder(ecfg, esd, device=local_rank, precision=args.decoder_precision)   # same switch as the decoder
     if rank == 0:
         print(f">>> Sampling mode = {args.mode} ...")
     for name, seq in targets:

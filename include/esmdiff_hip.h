@@ -285,13 +285,16 @@ int esmdiff_decoder_decode(esmdiff_engine* dec, const int64_t* tokens, float* bb
  * relative_positional_embedding.embedding.weight, transformer.blocks.{i}.geom_attn.{s_norm.weight, proj.{weight,bias},
  * out_proj.{weight,bias}, rotation_scale_per_head, distance_scale_per_head}, transformer.blocks.{i}.ffn.{0,1,3}.{weight,
  * bias}, pre_vq_proj.{weight,bias}, codebook.embeddings.
+ * precision (ABI 4): ESMDIFF_PRECISION_F32 runs the two blocks and the projection in float32 (csrc/strict.hip) — the codes then
+ * equal a float32 encoder's except at exact distance ties; BF16 is the MFMA path (98-99 % identical codes, every difference a
+ * near-tie).
  * encode: ca f32 [B,L,3] (CA positions), rot f32 [B,L,3,3], trans f32 [B,L,3], has_frame u8 [B,L] (the frames of
  * esmdiff_set_frames; residues WITHOUT BOS/EOS) -> tokens int64 [B,L] (device), 4096 (MASK) where has_frame == 0.
  * Synchronises `stream` before returning. */
 typedef struct esmdiff_encoder esmdiff_encoder;
 int esmdiff_encoder_create(int32_t d_model, int32_t v_heads, int32_t n_layers, int32_t ffn_hidden, int32_t d_out,
-                           int32_t n_codes, int32_t knn, int32_t relpos_bins, const esmdiff_weight* table,
-                           int32_t n_weights, int32_t device, esmdiff_encoder** out);
+                           int32_t n_codes, int32_t knn, int32_t relpos_bins, int32_t precision /* esmdiff_precision */,
+                           const esmdiff_weight* table, int32_t n_weights, int32_t device, esmdiff_encoder** out);
 void esmdiff_encoder_destroy(esmdiff_encoder* enc);
 const char* esmdiff_encoder_last_error(const esmdiff_encoder* enc);
 int esmdiff_encoder_encode(esmdiff_encoder* enc, const float* ca, const float* rot, const float* trans,

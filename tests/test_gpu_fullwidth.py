@@ -361,7 +361,14 @@ def test_structure_encoder_full_size_margin(B, L):
     xyz[-1, L - 2] = float("nan")
     with torch.no_grad():
         ref, z, d2 = ref_net(xyz, return_z=True)
-    enc = StructureEncoder(cfg, sd)
+    enc32 = StructureEncoder(cfg, sd)                            # default precision: float32
+    assert enc32.precision == "f32"
+    got32 = enc32.encode(xyz).cpu()
+    enc32.close()
+    agree32 = float((got32 == ref)[ref != MASK].float().mean())
+    _record(f"encoder1024_f32_B{B}_L{L}", {"agree": agree32})
+    assert torch.equal(got32 == MASK, ref == MASK) and agree32 >= 0.999, agree32     # measured: see profiles/r03_parity_fullwidth.json
+    enc = StructureEncoder(cfg, sd, precision="bf16")            # the MFMA path: margin analysis below
     got = enc.encode(xyz).cpu()
     enc.close()
     assert torch.equal(got == MASK, ref == MASK)

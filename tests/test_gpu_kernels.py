@@ -504,8 +504,9 @@ def test_structure_decoder_vs_oracle(B, L):
     dec.close()
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f32"])
 @pytest.mark.parametrize("B,L", [(2, 40), (1, 131), (3, 9)])
-def test_structure_encoder_vs_oracle(B, L):
+def test_structure_encoder_vs_oracle(B, L, precision):
     """Coordinates -> structure tokens (esmdiff_encoder_create / _encode: kNN neighbourhoods, relative-position embedding,
     two geometric-attention + FFN blocks with biases, codebook lookup) against oracle/encoder_ref.py, with unknown
     residues; and what holds whatever esm's exact details are: tokens do not change under a rigid motion of the input."""
@@ -523,10 +524,12 @@ def test_structure_encoder_vs_oracle(B, L):
         xyz[-1, L - 2] = float("nan")
     with torch.no_grad():
         ref, _, d2 = ref_net(xyz, return_z=True)
-    enc = StructureEncoder(TINY_ENCODER, sd)
+    enc = StructureEncoder(TINY_ENCODER, sd, precision=precision)
     got = enc.encode(xyz).cpu()
     assert got.shape == ref.shape == (B, L)
     assert torch.equal(got == MASK, ref == MASK)
+    if precision == "f32":     # the strict path: the very codes of the float32 oracle (a difference would need an exact tie)
+        assert torch.equal(got, ref)
     # nearest-code lookups after bf16 GEMMs: the same code except where two codes are almost equally near IN THE
     # ORACLE'S OWN f32 distances — every disagreement must be such a near-tie, clear winners must agree
     live = ref != MASK
