@@ -515,3 +515,64 @@ def test_strict_forward_ragged_shapes(B, L):
     eng.close()
     assert err < 5e-5, err
     assert out.shape == (B, L) and int((out == MASK).sum()) == 0
+
+
+def test_bf16_vs_float32_chain_configs1_full_batch():
+    """BASELINE configs[1] at FULL size (100 samples x 256 residues, 25 steps, 48 blocks): the bf16 engine's chain against the
+    float32 chain, with the strict engine as the float32 reference (it equals the torch-CPU oracle chain id for id at B = 2 and
+    B = 4, tests above; the oracle itself would need an hour here).  Free-running agreement per step and per sample, and the
+    per-draw flip rate when every bf16 step starts from the float32 chain's state.  Recorded; asserted loosely."""
+    import time
+    from esmdiff_amd.config import ESM3_OPEN
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ESM3_OPEN
+    sd = random_init_state_dict(cfg, seed=11, device="cuda")
+    B, L, T = 100, 258, 25
+    strict = Engine(cfg, sd, max_batch=B, max_len=L, precision="f32")
+    fast = Engine(cfg, sd, max_batch=B, max_len=L)
+    del sd
+    g = torch.Generator().manual_seed(258)
+    seq = _seq(B, L, g).cuda()
+    sch = ddpm_schedule(T, freq_dim=cfg.freq_dim)
+    tf = strict.conditioning_rows(sch.t_freq)
+
+    def chain(eng, teacher=None):
+        x = torch.full((B, L), MASK, dtype=torch.int64, device="cuda")
+        ids = []
+        for i in range(T + 1):
+            fin = i == T
+            if teacher is not None and i > 0:
+                x = teacher[i - 1].clone()
+            lg = eng.forward_logits(x, seq, tf[i])
+            x = eng.ddpm_step(x.clone(), lg, 0.0 if fin else sch.mc_t[i].item(), 0.0 if fin else sch.mc_s[i].item(), final=fin,
+                              seed=23, step=i)
+            ids.append(x.clone())
+        return ids
+
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ref = chain(strict)
+    torch.cuda.synchronize(); t_strict = time.perf_counter() - t0
+    assert torch.equal(ref[-1], strict.ddpm_sample(seq, sch, seed=23))            # the device loop is the same chain
+    t0 = time.perf_counter()
+    free = chain(fast)
+    torch.cuda.synchronize(); t_fast = time.perf_counter() - t0
+    forced = chain(fast, teacher=ref)
+    per_step = [float((free[i] == ref[i]).float().mean()) for i in range(T + 1)]
+    per_sample_final = (free[-1] == ref[-1]).float().mean(1)
+    flips = [int((forced[i] != ref[i]).sum()) for i in range(T + 1)]
+    draws = int(sum(int((ref[i - 1] == MASK).sum()) if i else B * L for i in range(T + 1)))
+    rec = {"B": B, "L_tok": L, "steps": T, "layers": cfg.n_layers,
+           "free_running_agreement_per_step": [round(a, 4) for a in per_step],
+           "final_agreement_mean": float(per_sample_final.mean()), "final_agreement_min_sample": float(per_sample_final.min()),
+           "samples_fully_identical": int((per_sample_final == 1.0).sum()),
+           "teacher_forced_flips_per_step": flips, "teacher_forced_flips_total": int(sum(flips)), "masked_draws_total": draws,
+           "flip_rate_per_masked_draw": sum(flips) / max(draws, 1),
+           "strict_chain_seconds_stepwise": round(t_strict, 2), "bf16_chain_seconds_stepwise": round(t_fast, 2),
+           "strict_samples_per_s": round(B / t_strict, 2)}
+    _record("full48_configs1_full_batch_bf16_vs_f32_chain", rec)
+    strict.close()
+    fast.close()
+    assert rec["flip_rate_per_masked_draw"] < 2e-3, rec
+    assert rec["final_agreement_mean"] > 0.9, rec
