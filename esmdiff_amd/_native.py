@@ -16,7 +16,7 @@ c_i64p = ctypes.POINTER(ctypes.c_int64)
 
 EPI_BF16, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_F32 = range(5)
 DT_F32, DT_BF16 = 0, 1
-PRECISION = {"bf16": 0, "f32": 1}       # esmdiff_precision
+PRECISION = {"bf16": 0, "f32": 1, "f32_split": 2}       # esmdiff_precision
 F32EPI_STORE, F32EPI_BIAS_GELU, F32EPI_RESID_DIV = range(3)
 SECTIONS = ["embed", "layernorm", "gemm_qkv", "qk_norm_rope", "attention", "gemm_out", "gemm_ffn_up",
             "gemm_ffn_down", "head", "sampler"]
@@ -26,7 +26,7 @@ class Config(ctypes.Structure):
     _fields_ = [("d_model", ctypes.c_int32), ("n_heads", ctypes.c_int32), ("n_layers", ctypes.c_int32),
                 ("ffn_hidden", ctypes.c_int32), ("vocab_out", ctypes.c_int32), ("freq_dim", ctypes.c_int32),
                 ("max_batch", ctypes.c_int32), ("max_len", ctypes.c_int32), ("residue_scale", ctypes.c_float),
-                ("time_conditioning", ctypes.c_int32), ("precision", ctypes.c_int32)]
+                ("time_conditioning", ctypes.c_int32), ("precision", ctypes.c_int32), ("head_precision", ctypes.c_int32)]
 
 
 class Weight(ctypes.Structure):
@@ -41,13 +41,14 @@ class Rng(ctypes.Structure):
 EXPORTS = [
     "esmdiff_abi_version", "esmdiff_engine_create", "esmdiff_engine_destroy", "esmdiff_last_error",
     "esmdiff_forward_logits", "esmdiff_ddpm_step", "esmdiff_ddpm_sample", "esmdiff_gibbs_step",
-    "esmdiff_gibbs_sample", "esmdiff_gemm_bf16", "esmdiff_debug_graph_ab", "esmdiff_branch_linear_layernorm",
-    "esmdiff_gemm_bf16_timed", "esmdiff_layernorm_bf16", "esmdiff_attention_bf16", "esmdiff_set_profiling",
+    "esmdiff_gibbs_sample", "esmdiff_gemm_bf16", "esmdiff_branch_linear_layernorm",
+    "esmdiff_layernorm_bf16", "esmdiff_attention_bf16", "esmdiff_set_profiling",
     "esmdiff_get_profile", "esmdiff_set_frames", "esmdiff_gemm_bf16_ws", "esmdiff_decoder_create",
     "esmdiff_decoder_decode", "esmdiff_metrics_js_pwd", "esmdiff_metrics_js_rg", "esmdiff_metrics_validity",
     "esmdiff_metrics_bonding_validity", "esmdiff_metrics_pwd", "esmdiff_metrics_js_columns", "esmdiff_encoder_create", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error",
     "esmdiff_encoder_encode", "esmdiff_gemm_f32", "esmdiff_set_step0_sharing", "esmdiff_get_counters",
-    "esmdiff_set_gibbs_options",
+    "esmdiff_set_gibbs_options", "esmdiff_split_rows", "esmdiff_split_weight", "esmdiff_gemm_split",
+    "esmdiff_get_embeddings",
 ]
 
 
@@ -85,8 +86,11 @@ def lib():
     L.esmdiff_gibbs_step.argtypes = [vp, vp, vp, vp, i32, f32, f32, vp, vp, ctypes.POINTER(Rng), i32, i32, i32, vp]
     L.esmdiff_gibbs_sample.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, ctypes.POINTER(i32), ctypes.POINTER(Rng), vp]
     L.esmdiff_gemm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
-    L.esmdiff_gemm_bf16_timed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, c_f32p, vp]
-    L.esmdiff_debug_graph_ab.argtypes = [vp, vp, vp, i32, i32, i32, c_f32p, c_f32p]
+    if hasattr(L, "esmdiff_gemm_bf16_timed"):      # -DED_DEBUG builds only (scratch/ A-B scripts)
+        L.esmdiff_gemm_bf16_timed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, c_f32p, vp]
+        L.esmdiff_gemm_bf16_timed.restype = ctypes.c_int
+        L.esmdiff_debug_graph_ab.argtypes = [vp, vp, vp, i32, i32, i32, c_f32p, c_f32p]
+        L.esmdiff_debug_graph_ab.restype = ctypes.c_int
     L.esmdiff_branch_linear_layernorm.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, i32, i32, i32, ctypes.POINTER(i32), vp]
     L.esmdiff_layernorm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     L.esmdiff_attention_bf16.argtypes = [vp, vp, vp, vp, vp, i32, i32, vp]
@@ -112,11 +116,15 @@ def lib():
     L.esmdiff_set_step0_sharing.argtypes = [vp, i32]
     L.esmdiff_get_counters.argtypes = [vp, c_i64p, c_i64p, i32]
     L.esmdiff_gemm_f32.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
+    L.esmdiff_get_embeddings.argtypes = [vp, vp, i32, i32, vp]
+    L.esmdiff_split_rows.argtypes = [vp, i32, vp, vp, i32, i32, vp]
+    L.esmdiff_split_weight.argtypes = [vp, vp, i32, i32, i32, c_f32p]
+    L.esmdiff_gemm_split.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, f32, i32, vp]
     L.esmdiff_gemm_bf16_ws.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     for n in EXPORTS:
         if n not in ("esmdiff_engine_destroy", "esmdiff_last_error", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error"):
             getattr(L, n).restype = ctypes.c_int
-    if L.esmdiff_abi_version() != 4:
+    if L.esmdiff_abi_version() != 5:
         raise RuntimeError("libesmdiff_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -25,6 +25,7 @@ UNITS = {
     "gemm": [],
     "gemm256": [],
     "gemm256w4": [],
+    "gemm_split": [],
     "strict": [],
     "geom": [],
     "encoder": [],

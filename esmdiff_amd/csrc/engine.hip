@@ -33,11 +33,18 @@ thread_local std::string g_create_error;
 
 enum Section { S_EMBED = 0, S_LN, S_QKV, S_QKROPE, S_ATTN, S_OUT, S_FFN_UP, S_FFN_DOWN, S_HEAD, S_SAMPLER, S_COUNT };
 
+struct SplitW {
+  uint16_t* w = nullptr;
+  float inv = 1.f;
+};
+
 struct Layer {
   float *ln1_w, *ln1_b, *q_ln_w, *k_ln_w, *ln2_w, *ln2_b;
   bf16_t *w_qkv, *w_out, *w_up, *w_down;
   // precision = F32 (csrc/strict.hip): the linears as float32 in the checkpoint's own row order (no SwiGLU interleave)
   float *fw_qkv, *fw_out, *fw_up, *fw_down;
+  // precision = F32_SPLIT (csrc/gemm_split.hip): the linears as scaled f16 [lo | hi] plane pairs + 1 / scale
+  SplitW s_qkv, s_out, s_up, s_down;
 };
 
 }  // namespace
@@ -92,12 +99,20 @@ struct esmdiff_engine {
   hipEvent_t ev_fork = nullptr;
   int64_t dual_min_tokens = 2200, dual_small_max_tokens = 1024;  // two streams from / small window up to (tokens), see forward()
   int stream_offset_us = 0;  // phase offset of the second sub-batch stream (ESMDIFF_STREAM_OFFSET_US), see forward()
-  int debug_skip = 0;  // ESMDIFF_DEBUG_SKIP bits (timing experiments only, results are wrong): 1 rope, 2 attention, 4 / 8 the two add+LN
+  int debug_skip = 0;  // -DED_DEBUG builds only: ESMDIFF_DEBUG_SKIP bits (timing experiments, results are wrong): 1 rope, 2 attention, 4 / 8 the two add+LN; always 0 otherwise
   ed::GemmWorkspace gemm_ws[4] = {};  // split-K partials of the small-M GEMM path, one per launch queue
   ed::GemmWorkspace gemm_ws2[4] = {}; // ... a second set: the out-projection's K slices stay live next to the FFN-down's
   int small_fused = 1;                // ESMDIFF_SMALL_FUSED=0: branch linears write bf16 deltas at every size (A/B runs)
   // precision = ESMDIFF_PRECISION_F32: float32 weights / activations (forward_strict); the bf16 members above stay null
   bool strict = false;
+  // precision = ESMDIFF_PRECISION_F32_SPLIT: forward_strict with every large linear as three f16 MFMA passes over split
+  // operands (gemm_split.hip); a2 / rs: the split activation rows feeding the next linear and their row scales
+  bool split = false;
+  bool head_split = false;   // bf16 engine with esmdiff_config.head_precision = 1: final LayerNorm + head on the split kernels
+  SplitW s_head0, s_head3, s_pl0, s_pl3, s_gproj, s_gout;
+  uint16_t* a2 = nullptr;
+  float* rs = nullptr;
+  uint32_t* scratch_bits = nullptr;
   float *fhead_w0 = nullptr, *fhead_w3 = nullptr, *fpl_w0 = nullptr, *fpl_w3 = nullptr, *fpw_down = nullptr;
   float *fg_proj = nullptr, *fg_out = nullptr, *fgp = nullptr, *fgctx = nullptr;
   float *fpw_l1 = nullptr, *fpw_l2 = nullptr, *fpair_x = nullptr, *fpair_h = nullptr;   // pairwise head in float32
@@ -112,6 +127,8 @@ struct esmdiff_engine {
   uint32_t* g_inv_mask = nullptr;
   bool g_inv_on = false;
   int64_t stat_forwards = 0, stat_rows = 0;
+  int last_B = 0, last_L = 0;       // shape of the last forward, and whether its last FFN-down delta is still outside x
+  bool last_pending_delta = false;  // (regular bf16 path: the final add+LayerNorm forms x + dF in registers only)
   // profiling
   int profiling = 0;  // 0 off, 1 every launch, 2 only the dominant kernel (FFN-up GEMM)
   std::vector<hipEvent_t> ev;
@@ -202,6 +219,19 @@ int load_bf16(esmdiff_engine* e, const Table& t, const std::string& name, std::i
   return 0;
 }
 
+// precision = F32_SPLIT: a linear's weight as split f16 planes [rows padded to pad_rows_to, 2K] + its inverse scale
+int load_split(esmdiff_engine* e, const Table& t, const std::string& name, std::initializer_list<int64_t> shape, SplitW* dst,
+               int64_t pad_rows_to = 0) {
+  const esmdiff_weight* w;
+  if (int r = need(e, t, name, shape, &w)) return r;
+  const int64_t rows = w->shape[0], K = numel(w) / rows;
+  const int64_t rows_p = pad_rows_to > rows ? pad_rows_to : rows;
+  if (K % 128 || rows_p % 256) return fail(e, ESMDIFF_E_SHAPE, "weight '%s': [%lld, %lld] does not fit the split GEMM (rows %% 256, K %% 128)", name.c_str(), (long long)rows_p, (long long)K);
+  if (int r = dalloc(e, &dst->w, (size_t)(rows_p * 3 * K), rows_p != rows)) return r;
+  HIP_TRY(e, split_weight(w->data, w->dtype, dst->w, rows, (int)K, e->scratch_bits, &dst->inv));
+  return 0;
+}
+
 // RAII-less section timer: when profiling, records an event before/after each launch.
 struct Prof {
   esmdiff_engine* e;
@@ -276,6 +306,8 @@ struct Part {
   float *x, *logits, *pl_logits;
   bf16_t *h, *h2, *qkv, *q, *k, *ctx, *mid, *dlt, *dlt2;
   bf16_t *gp, *gctx;
+  uint16_t* a2;   // head_split: split rows feeding the two head linears, their row scales, the f32 Linear-0 output
+  float *rs, *fh2;
   const float *f_rot, *f_trans;
   const uint8_t* f_mask;
   int B;
@@ -291,6 +323,7 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
   return Part{seq + t0, xtok + t0, e->x + t0 * D, logits + t0 * ld, e->pl_logits ? e->pl_logits + t0 * e->ld_plddt : nullptr, e->h + t0 * D, e->h2 + t0 * D, e->qkv + t0 * 3 * D,
               e->q + t0 * D, e->k + t0 * D, e->ctx + t0 * D, e->mid + t0 * c.ffn_hidden, e->dlt + t0 * D, e->dlt2 + t0 * D,
               e->gp ? e->gp + t0 * 15 * e->v_heads : nullptr, e->gctx ? e->gctx + t0 * 3 * e->v_heads : nullptr,
+              e->a2 ? e->a2 + t0 * 3 * D : nullptr, e->rs ? e->rs + t0 : nullptr, e->fh2 ? e->fh2 + t0 * D : nullptr,
               e->f_rot ? e->f_rot + t0 * 9 : nullptr, e->f_trans ? e->f_trans + t0 * 3 : nullptr,
               e->f_mask ? e->f_mask + t0 : nullptr, nb, st,
               e->gemm_ws[queue].partial ? &e->gemm_ws[queue] : nullptr,
@@ -348,24 +381,58 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
   if (geom && (e->frames_B != B || e->frames_L != L))
     return fail(e, ESMDIFF_E_INVALID, "frames were set for B=%d L=%d, forward called with B=%d L=%d", e->frames_B, e->frames_L, B, L);
   const int VH = e->v_heads;
+  // precision = F32_SPLIT: the same op sequence; every LayerNorm / SwiGLU / attention output that feeds a linear is written
+  // as a split row (a2, rs) and the linear runs as three f16 MFMA passes (gemm_split.hip); everything else is unchanged
+  const bool sp = e->split;
+  uint16_t* a2 = e->a2;
+  float* rs = e->rs;
+#define LIN(section, sw, fw, A32, lda, Kdim, out, bias, n_rows, ldc, n_valid, div, epi)                                  \
+  do {                                                                                                                   \
+    if (sp && (sw).w) RUN(section, launch_gemm256w4_split(a2, rs, (sw).w, (sw).inv, out, bias, M, round_up(n_rows, 256), Kdim, ldc, div, epi, st)); \
+    else RUN(section, launch_gemm_f32(A32, lda, fw, out, bias, M, n_rows, Kdim, ldc, n_valid, div, epi, st));             \
+  } while (0)
   for (int i = 0; i < c.n_layers; ++i) {
     const Layer& ly = e->layers[i];
-    RUN(S_LN, launch_layernorm_f32(e->x, ly.ln1_w, ly.ln1_b, e->fh, M, D, st));
-    RUN(S_QKV, launch_gemm_f32(e->fh, D, ly.fw_qkv, e->fqkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_F32EPI_STORE, st));
+    if (sp) RUN(S_LN, launch_layernorm_split(e->x, ly.ln1_w, ly.ln1_b, a2, rs, nullptr, M, D, 0, st));
+    else RUN(S_LN, launch_layernorm_f32(e->x, ly.ln1_w, ly.ln1_b, e->fh, M, D, st));
+    LIN(S_QKV, ly.s_qkv, ly.fw_qkv, e->fh, D, D, e->fqkv, nullptr, 3 * D, 3 * D, 3 * D, 1.f, ESMDIFF_F32EPI_STORE);
     RUN(S_QKROPE, launch_qk_norm_rope_f32(e->fqkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, e->fq, e->fk, B, L, H, st));
     RUN(S_ATTN, launch_attention_f32(e->fq, e->fk, e->fqkv, e->fctx, B, L, H, st));
-    RUN(S_OUT, launch_gemm_f32(e->fctx, D, ly.fw_out, e->x, nullptr, M, D, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
+    if (sp) RUN(S_ATTN, launch_split_rows(e->fctx, D, a2, rs, M, D, st));
+    LIN(S_OUT, ly.s_out, ly.fw_out, e->fctx, D, D, e->x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
     if (i == 0 && geom) {   // x = x + geom_attn(s_norm(x), frames) / scaling_factor
-      RUN(S_LN, launch_layernorm_f32(e->x, e->g_snorm_w, nullptr, e->fh, M, D, st));
-      RUN(S_ATTN, launch_gemm_f32(e->fh, D, e->fg_proj, e->fgp, nullptr, M, 15 * VH, D, 15 * VH, 15 * VH, 1.f, ESMDIFF_F32EPI_STORE, st));
+      const bool gs = sp && e->s_gproj.w;
+      if (gs) RUN(S_LN, launch_layernorm_split(e->x, e->g_snorm_w, nullptr, a2, rs, nullptr, M, D, 0, st));
+      else RUN(S_LN, launch_layernorm_f32(e->x, e->g_snorm_w, nullptr, e->fh, M, D, st));
+      LIN(S_ATTN, e->s_gproj, e->fg_proj, e->fh, D, D, e->fgp, nullptr, 15 * VH, 15 * VH, 15 * VH, 1.f, ESMDIFF_F32EPI_STORE);
       RUN(S_ATTN, launch_geom_attention_f32(e->fgp, e->f_rot, e->f_trans, e->f_mask, e->g_wrot, e->g_wdist, e->fgctx, B, L, VH, st));
-      RUN(S_ATTN, launch_gemm_f32(e->fgctx, 3 * VH, e->fg_out, e->x, nullptr, M, D, 3 * VH, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
+      if (gs) RUN(S_ATTN, launch_split_rows(e->fgctx, 3 * VH, a2, rs, M, 3 * VH, st));
+      LIN(S_ATTN, e->s_gout, e->fg_out, e->fgctx, 3 * VH, 3 * VH, e->x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
     }
-    RUN(S_LN, launch_layernorm_f32(e->x, ly.ln2_w, ly.ln2_b, e->fh, M, D, st));
-    RUN(S_FFN_UP, launch_gemm_f32(e->fh, D, ly.fw_up, e->fgu, nullptr, M, 2 * FH, D, 2 * FH, 2 * FH, 1.f, ESMDIFF_F32EPI_STORE, st));
-    RUN(S_FFN_UP, launch_swiglu_f32(e->fgu, e->fmid, M, FH, st));
-    RUN(S_FFN_DOWN, launch_gemm_f32(e->fmid, FH, ly.fw_down, e->x, nullptr, M, D, FH, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
+    if (sp) RUN(S_LN, launch_layernorm_split(e->x, ly.ln2_w, ly.ln2_b, a2, rs, nullptr, M, D, 0, st));
+    else RUN(S_LN, launch_layernorm_f32(e->x, ly.ln2_w, ly.ln2_b, e->fh, M, D, st));
+    LIN(S_FFN_UP, ly.s_up, ly.fw_up, e->fh, D, D, e->fgu, nullptr, 2 * FH, 2 * FH, 2 * FH, 1.f, ESMDIFF_F32EPI_STORE);
+    if (sp) RUN(S_FFN_UP, launch_swiglu_split(e->fgu, a2, rs, M, FH, st));
+    else RUN(S_FFN_UP, launch_swiglu_f32(e->fgu, e->fmid, M, FH, st));
+    LIN(S_FFN_DOWN, ly.s_down, ly.fw_down, e->fmid, FH, FH, e->x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
   }
+  if (sp) {
+    // head: Linear + bias -> GELU -> LayerNorm -> Linear + bias; the GELU is applied by the LayerNorm as it loads the row
+    // (the same erff expression on the same f32 value).  The final norm's f32 rows are kept only for the 128-wide pairwise
+    // down-projection, which stays on the exact-f32 kernel.
+    RUN(S_LN, launch_layernorm_split(e->x, e->final_ln_w, nullptr, a2, rs, e->has_pair ? e->fh : nullptr, M, D, 0, st));
+    RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_head0.w, e->s_head0.inv, e->fh2, e->head_b0, M, D, D, D, 1.f, ESMDIFF_F32EPI_STORE, st));
+    if (e->has_plddt) RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_pl0.w, e->s_pl0.inv, e->fctx, e->pl_b0, M, D, D, D, 1.f, ESMDIFF_F32EPI_STORE, st));
+    if (e->has_pair) RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fpw_down, e->fpair_qk, nullptr, M, 128, D, 128, 128, 1.f, ESMDIFF_F32EPI_STORE, st));
+    RUN(S_LN, launch_layernorm_split(e->fh2, e->head_ln_w, e->head_ln_b, a2, rs, nullptr, M, D, 1, st));
+    RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_head3.w, e->s_head3.inv, logits, e->head_b3, M, e->vocab_pad, D, ld, 1.f, ESMDIFF_F32EPI_STORE, st));
+    if (e->has_plddt) {
+      RUN(S_LN, launch_layernorm_split(e->fctx, e->pl_ln_w, e->pl_ln_b, a2, rs, nullptr, M, D, 1, st));
+      RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_pl3.w, e->s_pl3.inv, e->pl_logits, e->pl_b3, M, 256, D, e->ld_plddt, 1.f, ESMDIFF_F32EPI_STORE, st));
+    }
+    return 0;
+  }
+#undef LIN
   RUN(S_LN, launch_layernorm_f32(e->x, e->final_ln_w, nullptr, e->fh, M, D, st));
   RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fhead_w0, e->fh2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_F32EPI_BIAS_GELU, st));
   if (e->has_plddt) RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fpl_w0, e->fctx, e->pl_b0, M, D, D, D, D, 1.f, ESMDIFF_F32EPI_BIAS_GELU, st));
@@ -400,6 +467,9 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
 //     matrix for half the rows and lose (B = 4 at L_tok = 60: 87.0 / 95.8 ms), and B = 3 at L_tok = 258 cuts into 1 + 2.
 int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const float* t_freq_dev, float* logits,
             int ld, int B, int L, hipStream_t st) {
+  e->last_B = B;
+  e->last_L = L;
+  e->last_pending_delta = false;
   if (e->strict) {
     e->stat_forwards += 1;
     e->stat_rows += (int64_t)B * L;
@@ -508,6 +578,23 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
     if (small) EACH(S_FFN_DOWN, launch_gemm_partials(w.mid, ly.w_down, w.gws, M, D, FH, w.st, &PF[pi]));
     else EACH(S_FFN_DOWN, launch_gemm_bf16(w.mid, ly.w_down, w.dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
     pending = true;
+  }
+  e->last_pending_delta = !small && pending;
+  if (e->head_split) {
+    // f32-grade head on the bf16 body (esmdiff_config.head_precision = 1): final LayerNorm of the f32 residual stream (plus
+    // the last FFN-down delta, which the regular path keeps outside x) -> Linear + bias -> GELU -> LayerNorm -> Linear + bias,
+    // LayerNorms in the strict path's arithmetic, linears as three f16 MFMA passes over split rows (gemm_split.hip)
+    if (small && pending) EACH(S_LN, launch_add_partials_layernorm_bf16(w.x, PF[pi], D, inv_scale, e->final_ln_w, nullptr, w.h, M, D, w.st));  // x += dF
+    EACH(S_LN, launch_layernorm_split(w.x, e->final_ln_w, nullptr, w.a2, w.rs, nullptr, M, D, 0, w.st,
+                                      (!small && pending) ? w.dlt : nullptr));
+    EACH(S_HEAD, launch_gemm256w4_split(w.a2, w.rs, e->s_head0.w, e->s_head0.inv, w.fh2, e->head_b0, M, D, D, D, 1.f, ESMDIFF_F32EPI_STORE, w.st));
+    EACH(S_LN, launch_layernorm_split(w.fh2, e->head_ln_w, e->head_ln_b, w.a2, w.rs, nullptr, M, D, 1, w.st));
+    EACH(S_HEAD, launch_gemm256w4_split(w.a2, w.rs, e->s_head3.w, e->s_head3.inv, w.logits, e->head_b3, M, e->vocab_pad, D, ld, 1.f, ESMDIFF_F32EPI_STORE, w.st));
+    for (int pi = 1; pi < np; ++pi) {
+      HIP_TRY(e, hipEventRecord(e->ev_join[pi - 1], e->side[pi - 1]));
+      HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[pi - 1], 0));
+    }
+    return 0;
   }
   if (small && pending) EACH(S_LN, launch_add_partials_layernorm_bf16(w.x, PF[pi], D, inv_scale, e->final_ln_w, nullptr, w.h, M, D, w.st));
   else EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, e->final_ln_w, nullptr, w.h, M, D, w.st));
@@ -622,14 +709,20 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       (kind == 0 && (V < ESMDIFF_MASK_ID || V > 5120 || F <= 0)) || (kind == 1 && V != 23))
     return fail(nullptr, ESMDIFF_E_INVALID, "invalid configuration");
 
-  if (cfg->precision != ESMDIFF_PRECISION_BF16 && cfg->precision != ESMDIFF_PRECISION_F32)
-    return fail(nullptr, ESMDIFF_E_INVALID, "precision %d: expected ESMDIFF_PRECISION_BF16 (0) or ESMDIFF_PRECISION_F32 (1)", cfg->precision);
+  if (cfg->precision != ESMDIFF_PRECISION_BF16 && cfg->precision != ESMDIFF_PRECISION_F32 && cfg->precision != ESMDIFF_PRECISION_F32_SPLIT)
+    return fail(nullptr, ESMDIFF_E_INVALID, "precision %d: expected ESMDIFF_PRECISION_BF16 (0), ESMDIFF_PRECISION_F32 (1) or ESMDIFF_PRECISION_F32_SPLIT (2)", cfg->precision);
   esmdiff_engine* e = new esmdiff_engine;
   e->cfg = *cfg;
   e->kind = kind;
   e->device = device;
-  e->strict = cfg->precision == ESMDIFF_PRECISION_F32;
-  const bool strict = e->strict;
+  e->strict = cfg->precision != ESMDIFF_PRECISION_BF16;
+  e->split = cfg->precision == ESMDIFF_PRECISION_F32_SPLIT;
+  e->head_split = !e->strict && kind == 0 && cfg->head_precision == 1;
+  if (cfg->head_precision != 0 && cfg->head_precision != 1)
+    return (delete e, fail(nullptr, ESMDIFF_E_INVALID, "head_precision %d: 0 (as precision) or 1 (float32 grade)", cfg->head_precision));
+  const bool strict = e->strict, split = e->split, head_split = e->head_split;
+  if (split && (D % 128 || FH % 128))
+    return (delete e, fail(nullptr, ESMDIFF_E_INVALID, "precision F32_SPLIT needs d_model and ffn_hidden to be multiples of 128"));
   auto bail = [&](int code) {
     g_create_error = e->err;
     esmdiff_engine_destroy(e);
@@ -646,6 +739,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     if (int _r = (x)) return bail(_r); \
   } while (0)
 
+  if (split || head_split) TRY(dalloc(e, &e->scratch_bits, (size_t)4, true));
   // kind 1 (esm StructureTokenDecoder, SURVEY.md 8f-1 [ESM-RECALL]): the same block stack under decoder_stack.*, a single
   // token embedding, and affine_output_projection (Linear -> GELU -> LayerNorm -> Linear(23)) in place of the head
   const std::string stack = kind == 1 ? "decoder_stack." : "transformer.";
@@ -660,15 +754,20 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(load_f32(e, t, b + "attn.layernorm_qkv.0.bias", {D}, &ly.ln1_b));
     ly.w_qkv = ly.w_out = ly.w_up = ly.w_down = nullptr;
     ly.fw_qkv = ly.fw_out = ly.fw_up = ly.fw_down = nullptr;
-    if (strict) TRY(load_f32(e, t, b + "attn.layernorm_qkv.1.weight", {3 * D, D}, &ly.fw_qkv));
+    if (split) TRY(load_split(e, t, b + "attn.layernorm_qkv.1.weight", {3 * D, D}, &ly.s_qkv));
+    else if (strict) TRY(load_f32(e, t, b + "attn.layernorm_qkv.1.weight", {3 * D, D}, &ly.fw_qkv));
     else TRY(load_bf16(e, t, b + "attn.layernorm_qkv.1.weight", {3 * D, D}, &ly.w_qkv));
     TRY(load_f32(e, t, b + "attn.q_ln.weight", {D}, &ly.q_ln_w));
     TRY(load_f32(e, t, b + "attn.k_ln.weight", {D}, &ly.k_ln_w));
-    if (strict) TRY(load_f32(e, t, b + "attn.out_proj.weight", {D, D}, &ly.fw_out));
+    if (split) TRY(load_split(e, t, b + "attn.out_proj.weight", {D, D}, &ly.s_out));
+    else if (strict) TRY(load_f32(e, t, b + "attn.out_proj.weight", {D, D}, &ly.fw_out));
     else TRY(load_bf16(e, t, b + "attn.out_proj.weight", {D, D}, &ly.w_out));
     TRY(load_f32(e, t, b + "ffn.0.weight", {D}, &ly.ln2_w));
     TRY(load_f32(e, t, b + "ffn.0.bias", {D}, &ly.ln2_b));
-    if (strict) {
+    if (split) {
+      TRY(load_split(e, t, b + "ffn.1.weight", {2 * FH, D}, &ly.s_up));
+      TRY(load_split(e, t, b + "ffn.3.weight", {D, FH}, &ly.s_down));
+    } else if (strict) {
       TRY(load_f32(e, t, b + "ffn.1.weight", {2 * FH, D}, &ly.fw_up));
       TRY(load_f32(e, t, b + "ffn.3.weight", {D, FH}, &ly.fw_down));
     } else {
@@ -681,13 +780,15 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     }
   }
   TRY(load_f32(e, t, stack + "norm.weight", {D}, &e->final_ln_w));
-  if (strict) TRY(load_f32(e, t, head0 + "weight", {D, D}, &e->fhead_w0));
+  if (split || head_split) TRY(load_split(e, t, head0 + "weight", {D, D}, &e->s_head0));
+  else if (strict) TRY(load_f32(e, t, head0 + "weight", {D, D}, &e->fhead_w0));
   else TRY(load_bf16(e, t, head0 + "weight", {D, D}, &e->head_w0));
   TRY(load_f32(e, t, head0 + "bias", {D}, &e->head_b0));
   TRY(load_f32(e, t, head2 + "weight", {D}, &e->head_ln_w));
   TRY(load_f32(e, t, head2 + "bias", {D}, &e->head_ln_b));
   e->vocab_pad = round_up(V, 256);  // 4101 -> 4352: 17 column tiles of the 256x256 kernel (the 128x128 kernel took 0.40 ms at M = 25 800)
-  if (strict) TRY(load_f32(e, t, head3 + "weight", {V, D}, &e->fhead_w3));
+  if (split || head_split) TRY(load_split(e, t, head3 + "weight", {V, D}, &e->s_head3, e->vocab_pad));
+  else if (strict) TRY(load_f32(e, t, head3 + "weight", {V, D}, &e->fhead_w3));
   else TRY(load_bf16(e, t, head3 + "weight", {V, D}, &e->head_w3, e->vocab_pad));
   {
     const esmdiff_weight* w;
@@ -701,13 +802,15 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       const int nb = pw->ndim == 2 ? (int)pw->shape[0] : 0;
       if (nb <= 0 || nb > 128) return bail(fail(e, ESMDIFF_E_INVALID, "plddt_head.3.weight: %d bins unsupported (1..128)", nb));
       e->plddt_bins = nb;
-      e->ld_plddt = round_up(nb, 4);
-      if (strict) TRY(load_f32(e, t, "plddt_head.0.weight", {D, D}, &e->fpl_w0));
+      e->ld_plddt = split ? 256 : round_up(nb, 4);   // the split GEMM has no column bound: its output row holds all N_pad columns
+      if (split) TRY(load_split(e, t, "plddt_head.0.weight", {D, D}, &e->s_pl0));
+      else if (strict) TRY(load_f32(e, t, "plddt_head.0.weight", {D, D}, &e->fpl_w0));
       else TRY(load_bf16(e, t, "plddt_head.0.weight", {D, D}, &e->pl_w0));
       TRY(load_f32(e, t, "plddt_head.0.bias", {D}, &e->pl_b0));
       TRY(load_f32(e, t, "plddt_head.2.weight", {D}, &e->pl_ln_w));
       TRY(load_f32(e, t, "plddt_head.2.bias", {D}, &e->pl_ln_b));
-      if (strict) TRY(load_f32(e, t, "plddt_head.3.weight", {nb, D}, &e->fpl_w3));
+      if (split) TRY(load_split(e, t, "plddt_head.3.weight", {nb, D}, &e->s_pl3, 256));
+      else if (strict) TRY(load_f32(e, t, "plddt_head.3.weight", {nb, D}, &e->fpl_w3));
       else TRY(load_bf16(e, t, "plddt_head.3.weight", {nb, D}, &e->pl_w3, 128));
       const esmdiff_weight* w;
       TRY(need(e, t, "plddt_head.3.bias", {nb}, &w));
@@ -746,7 +849,10 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     if (VH <= 0 || (15 * VH) % 128 || (3 * VH) % 64) return bail(fail(e, ESMDIFF_E_INVALID, "geom_attn v_heads=%d unsupported", VH));
     e->v_heads = VH;
     TRY(load_f32(e, t, ga + "s_norm.weight", {D}, &e->g_snorm_w));
-    if (strict) {
+    if (split && (15 * VH) % 256 == 0 && (3 * VH) % 128 == 0) {
+      TRY(load_split(e, t, ga + "proj.weight", {15 * VH, D}, &e->s_gproj));
+      TRY(load_split(e, t, ga + "out_proj.weight", {D, 3 * VH}, &e->s_gout));
+    } else if (strict) {
       TRY(load_f32(e, t, ga + "proj.weight", {15 * VH, D}, &e->fg_proj));
       TRY(load_f32(e, t, ga + "out_proj.weight", {D, 3 * VH}, &e->fg_out));
     } else {
@@ -821,7 +927,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
   // workspace
   {
     const size_t Mx = (size_t)cfg->max_batch * cfg->max_len;
-    e->ld_logits = round_up(V, 4);
+    e->ld_logits = (split || head_split) ? e->vocab_pad : round_up(V, 4);   // (split: see ld_plddt)
     TRY(dalloc(e, &e->x, Mx * D));
     if (strict) {
       TRY(dalloc(e, &e->fh, Mx * D));
@@ -833,6 +939,10 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       TRY(dalloc(e, &e->fgu, Mx * 2 * FH));
       TRY(dalloc(e, &e->fmid, Mx * FH));
       if (e->has_pair) TRY(dalloc(e, &e->fpair_qk, Mx * 128));
+      if (split) {
+        TRY(dalloc(e, &e->a2, Mx * 3 * (size_t)std::max(D, FH)));
+        TRY(dalloc(e, &e->rs, Mx));
+      }
     } else {
       TRY(dalloc(e, &e->h, Mx * D));
       TRY(dalloc(e, &e->h2, Mx * D));
@@ -842,6 +952,11 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       TRY(dalloc(e, &e->ctx, Mx * D));
       TRY(dalloc(e, &e->dlt, Mx * D));
       TRY(dalloc(e, &e->dlt2, Mx * D));
+      if (head_split) {
+        TRY(dalloc(e, &e->a2, Mx * 3 * (size_t)D));
+        TRY(dalloc(e, &e->rs, Mx));
+        TRY(dalloc(e, &e->fh2, Mx * D));
+      }
     }
     if (e->has_geom) {
       if (strict) {
@@ -901,7 +1016,14 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       e->side.push_back(sd);
       e->ev_join.push_back(ev);
     }
+#ifdef ED_DEBUG
     if (const char* ds = getenv("ESMDIFF_DEBUG_SKIP")) e->debug_skip = atoi(ds);
+#else
+    // the launch-skipping switch of the timing experiments (results are wrong by construction) exists in -DED_DEBUG builds only;
+    // a product library that finds it in the environment refuses to start rather than silently ignore a request it once honoured
+    if (getenv("ESMDIFF_DEBUG_SKIP"))
+      return bail(fail(e, ESMDIFF_E_INVALID, "ESMDIFF_DEBUG_SKIP is set, but this libesmdiff_hip.so was built without -DED_DEBUG: unset it"));
+#endif
     if (const char* so = getenv("ESMDIFF_STREAM_OFFSET_US")) e->stream_offset_us = atoi(so);
     if (const char* sf = getenv("ESMDIFF_SMALL_FUSED")) e->small_fused = atoi(sf);
     if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_MIN_TOKENS")) e->dual_min_tokens = atoll(mt);
@@ -996,7 +1118,29 @@ int esmdiff_forward_logits(esmdiff_engine* e, const int64_t* seq, const int64_t*
   if (!seq || !x || !logits_out) return fail(e, ESMDIFF_E_INVALID, "null pointer");
   if (ld_logits < e->cfg.vocab_out || (ld_logits & 3)) return fail(e, ESMDIFF_E_INVALID, "ld_logits (%d) must be >= vocab (%d) rounded up to a multiple of 4", ld_logits, e->cfg.vocab_out);
   if (int r = check_bl(e, B, L)) return r;
+  if ((e->split || e->head_split) && ld_logits < e->vocab_pad) {
+    // the split head GEMM writes whole padded rows: run into the engine's own [M, vocab_pad] buffer, copy the valid columns
+    if (int r = forward(e, seq, x, t_freq, e->logits, e->ld_logits, B, L, (hipStream_t)stream)) return r;
+    HIP_TRY(e, hipMemcpy2DAsync(logits_out, (size_t)ld_logits * 4, e->logits, (size_t)e->ld_logits * 4, (size_t)e->cfg.vocab_out * 4,
+                                (size_t)B * L, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+  }
   return forward(e, seq, x, t_freq, logits_out, ld_logits, B, L, (hipStream_t)stream);
+}
+
+int esmdiff_get_embeddings(esmdiff_engine* e, float* out, int32_t B, int32_t L, void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!out) return fail(e, ESMDIFF_E_INVALID, "null pointer");
+  if (B != e->last_B || L != e->last_L || B <= 0)
+    return fail(e, ESMDIFF_E_INVALID, "embeddings of a (%d, %d) forward requested, the last forward was (%d, %d)", B, L, e->last_B, e->last_L);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t M = (size_t)B * L, D = e->cfg.d_model;
+  HIP_TRY(e, hipMemcpyAsync(out, e->x, M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // regular bf16 path: the last block's FFN-down delta is added by the final add+LayerNorm in registers; add it here the
+  // same way (out = out + dF, one f32 addition per element; the normalised row goes to a scratch buffer nobody reads)
+  if (e->last_pending_delta)
+    HIP_TRY(e, launch_add_layernorm_bf16(out, e->dlt, nullptr, 1, e->final_ln_w, nullptr, e->q, (int)M, (int)D, st));
+  return 0;
 }
 
 int esmdiff_ddpm_step(esmdiff_engine* e, int64_t* x_inout, const float* logits, int32_t ld_logits,
@@ -1090,6 +1234,7 @@ int esmdiff_gibbs_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout
   return 0;
 }
 
+#ifdef ED_DEBUG
 // Measurement aid: the same forward `n` times as plain launches and as `n` replays of ONE captured hipGraph of it, on an
 // engine-owned stream; milliseconds per forward of each into ms_direct / ms_graph [host].
 int esmdiff_debug_graph_ab(esmdiff_engine* e, const int64_t* seq, const int64_t* x, int32_t B, int32_t L, int32_t n,
@@ -1138,6 +1283,8 @@ int esmdiff_debug_graph_ab(esmdiff_engine* e, const int64_t* seq, const int64_t*
   return r;
 }
 
+#endif  // ED_DEBUG
+
 int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N, int32_t K,
                       int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream) {
   if (!A || !W || !out) return ESMDIFF_E_INVALID;
@@ -1155,6 +1302,35 @@ int esmdiff_gemm_f32(const float* A, int32_t lda, const float* W, float* out, co
   return 0;
 }
 
+int esmdiff_split_rows(const float* src, int32_t ld, void* a2, float* rs, int32_t M, int32_t K, void* stream) {
+  if (!src || !a2 || !rs) return ESMDIFF_E_INVALID;
+  hipError_t s = launch_split_rows(src, ld, (uint16_t*)a2, rs, M, K, (hipStream_t)stream);
+  if (s != hipSuccess) return fail(nullptr, s == hipErrorInvalidValue ? ESMDIFF_E_INVALID : ESMDIFF_E_HIP, "split_rows: %s", hipGetErrorString(s));
+  return 0;
+}
+
+int esmdiff_split_weight(const float* src, void* w2, int32_t N, int32_t N_pad, int32_t K, float* inv_scale_out) {
+  if (!src || !w2 || !inv_scale_out || N <= 0 || N_pad < N || N_pad % 256 || K <= 0 || K % 128) return ESMDIFF_E_INVALID;
+  uint32_t* bits = nullptr;
+  if (hipMalloc(&bits, 4) != hipSuccess) return fail(nullptr, ESMDIFF_E_HIP, "split_weight: hipMalloc failed");
+  hipError_t s = hipSuccess;
+  if (N_pad > N) s = hipMemset((uint16_t*)w2 + (size_t)N * 3 * K, 0, (size_t)(N_pad - N) * 3 * K * 2);
+  if (s == hipSuccess) s = split_weight(src, ESMDIFF_F32, (uint16_t*)w2, N, K, bits, inv_scale_out);
+  if (s == hipSuccess) s = hipDeviceSynchronize();
+  hipFree(bits);
+  if (s != hipSuccess) return fail(nullptr, ESMDIFF_E_HIP, "split_weight: %s", hipGetErrorString(s));
+  return 0;
+}
+
+int esmdiff_gemm_split(const void* a2, const float* rs, const void* w2, float w_inv_scale, float* out, const float* bias,
+                       int32_t M, int32_t N, int32_t K, int32_t ldc, float div, int32_t epilogue, void* stream) {
+  if (!a2 || !w2 || !out) return ESMDIFF_E_INVALID;
+  hipError_t s = launch_gemm256w4_split((const uint16_t*)a2, rs, (const uint16_t*)w2, w_inv_scale, out, bias, M, N, K, ldc, div,
+                                        epilogue, (hipStream_t)stream);
+  if (s != hipSuccess) return fail(nullptr, s == hipErrorInvalidValue ? ESMDIFF_E_INVALID : ESMDIFF_E_HIP, "gemm_split: %s", hipGetErrorString(s));
+  return 0;
+}
+
 int esmdiff_gemm_bf16_ws(esmdiff_engine* e, const void* A, const void* W, void* out, const float* bias, int32_t M,
                          int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream) {
   if (!e || !A || !W || !out) return ESMDIFF_E_INVALID;
@@ -1164,6 +1340,7 @@ int esmdiff_gemm_bf16_ws(esmdiff_engine* e, const void* A, const void* W, void* 
   return 0;
 }
 
+#ifdef ED_DEBUG
 int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N,
                             int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, int32_t iters,
                             float* ms_out, void* stream) {
@@ -1184,6 +1361,7 @@ int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float
   hipEventDestroy(b);
   return r;
 }
+#endif  // ED_DEBUG
 
 int esmdiff_branch_linear_layernorm(esmdiff_engine* e, const void* A, const void* W, float* x, float alpha, const float* w,
                                     const float* b, void* y, int32_t M, int32_t N, int32_t K, int32_t* splits_out,

@@ -100,10 +100,18 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // v_cvt_pk
   return u;
 }
 
-template <int EPI>
+// SPLIT = 1 (gemm_split.hip's launcher, the float32-grade "split" linears of the strict path): the operands are f16 plane
+// triples per row — A [M, 3K1] = [hi | lo | hi], W [N, 3K1] = [lo | hi | hi] with x ~ hi + lo to 2^-22 — so that ONE linear
+// walk over K = 3 K1 accumulates A_hi.W_lo + A_lo.W_hi + A_hi.W_hi (small terms first) into the same f32 accumulators on
+// v_mfma_f32_32x32x16_f16: the main loop is the bf16 one with another opcode and not one scalar more (a two-plane layout
+// with a jump back for the third pass cost 5 SGPRs, the kernel spilled, and hipcc's v_readlane reloads landed directly in
+// front of the inline-asm LDS-DMA that consumed them: a VALU-writes-SGPR -> VMEM hazard it does not pad inside asm).
+// EPI is then one of esmdiff_gemm_f32_epilogue, outputs are f32, scaled per row by rs[m] * alpha (powers of two: exact).
+template <int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                            void* __restrict__ out, const float* __restrict__ bias, int M,
-                                                           int N, int K, int ldc, float alpha, int tiles_m, int tiles_n) {
+                                                           int N, int K, int ldc, float alpha, int tiles_m, int tiles_n,
+                                                           const float* __restrict__ rs = nullptr, float div = 1.f) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x 64 KiB
 
   const int n_tiles = tiles_m * tiles_n, bid = blockIdx.x;
@@ -203,14 +211,16 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16_t* __restr
   } while (0)
 #define W4_MFMA(acc_, b_, a_)                                                                         \
   do {                                                                                                \
-    if (!W4_ABL(4)) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc_) : "v"(b_), "v"(a_)); \
-    else asm volatile("" : "+a"(acc_) : "v"(b_), "v"(a_));                                            \
+    if (W4_ABL(4)) asm volatile("" : "+a"(acc_) : "v"(b_), "v"(a_));                                  \
+    else if constexpr (SPLIT) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc_) : "v"(b_), "v"(a_)); \
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc_) : "v"(b_), "v"(a_));     \
   } while (0)
 // first k-step of a tile: D = B x A + 0 (no zeroing pass over the 256 accumulator registers)
 #define W4_MFMA0(acc_, b_, a_)                                                                        \
   do {                                                                                                \
-    if (!W4_ABL(4)) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc_) : "v"(b_), "v"(a_)); \
-    else asm volatile("" : "=a"(acc_) : "v"(b_), "v"(a_));                                            \
+    if (W4_ABL(4)) asm volatile("" : "=a"(acc_) : "v"(b_), "v"(a_));                                  \
+    else if constexpr (SPLIT) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc_) : "v"(b_), "v"(a_)); \
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc_) : "v"(b_), "v"(a_));      \
   } while (0)
 #define W4_WAIT_LGKM0(s_)                                                                                          \
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                              \
@@ -335,7 +345,36 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16_t* __restr
       }
       const int m = m0 + wm * 128 + i * 32 + lrow;
       const bool live = m < M && !(W4_ABL(8) && alpha != 12345.f);
-      if constexpr (EPI == ESMDIFF_EPI_SWIGLU_BF16) {
+      if constexpr (SPLIT) {   // f32 outputs of the split linears: acc * (row scale * weight scale), both powers of two
+        const float sc = (rs && m < M) ? rs[m] * alpha : alpha;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            // no column bound: the launcher requires ldc >= N (a bound check per 8-column group becomes 16 hoisted lane
+            // masks or scalar flags = 32+ SGPRs, the kernel spills, and hipcc's v_readlane reloads land in front of the
+            // inline-asm LDS-DMA that reads them: a VALU-writes-SGPR -> VMEM hazard nobody pads inside asm)
+            const int n = n0 + wn * 128 + j * 32 + g * 8 + lhi * 4;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][g * 4 + e] * sc;
+            if (!live) continue;
+            float* o = reinterpret_cast<float*>(out) + (int64_t)m * ldc + n;
+            if constexpr (EPI == ESMDIFF_F32EPI_RESID_DIV) {   // x = x + r / scaling_factor (esm's own expression)
+              f32x4 x = *reinterpret_cast<const f32x4*>(o);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) x[e] = x[e] + v[e] / div;
+              *reinterpret_cast<f32x4*>(o) = x;
+            } else {
+              if constexpr (EPI != ESMDIFF_F32EPI_STORE) {   // 3: the launcher's code for STORE with a bias
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += bb[e];
+              }
+              *reinterpret_cast<f32x4*>(o) = v;
+            }
+          }
+      } else if constexpr (EPI == ESMDIFF_EPI_SWIGLU_BF16) {
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
           bf16_t* orow = reinterpret_cast<bf16_t*>(out) + (int64_t)m * ldc + (n0 + wn * 128 + jp * 64) / 2 + lhi * 8;
@@ -423,6 +462,46 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16_t* __restr
   }
 }
 }  // namespace g4
+
+// The split linears (see the kernel's SPLIT note; operand preparation: gemm_split.hip).  A3 f16 [M, 3K] = [hi | lo | hi] with
+// per-row scale rs[M] (NULL: 1), W3 f16 [N, 3K] = [lo | hi | hi] scaled by 1 / w_scale; out f32 [M, ldc]; N % 256 == 0,
+// K % 128 == 0 (so that 3 K / 64 is even).
+hipError_t launch_gemm256w4_split(const uint16_t* A2, const float* rs, const uint16_t* W2, float w_scale, float* out,
+                                  const float* bias, int M, int N, int K, int ldc, float div, int epi, hipStream_t stream) {
+  using namespace g4;
+  if (M <= 0) return hipSuccess;
+  if (N % BN != 0 || K % (2 * BK) != 0 || (ldc & 3) || ldc < N) return hipErrorInvalidValue;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+  int dev = 0, n_cu = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+  n_cu = n_cu >= 8 ? (n_cu / 8) * 8 : 8;
+  const int n_tiles = tiles_m * tiles_n;
+  dim3 grid(n_tiles < n_cu ? n_tiles : n_cu), block(256);
+  const size_t lds = 2 * STAGE_BYTES;
+  static bool attr_done[4][16] = {};
+  // (no bias + GELU epilogue here: erff on 256 accumulators spills; the consumer LayerNorm applies the GELU on load)
+#define ED_GEMM_S(E)                                                                                                \
+  do {                                                                                                              \
+    if (dev < 16 && !attr_done[E][dev]) {                                                                           \
+      if (hipFuncSetAttribute((const void*)gemm256w4_kernel<E, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
+                              (int)lds) != hipSuccess)                                                             \
+        return hipErrorInvalidValue;                                                                                \
+      attr_done[E][dev] = true;                                                                                     \
+    }                                                                                                               \
+    hipLaunchKernelGGL((gemm256w4_kernel<E, 1>), grid, block, lds, stream, A2, W2, (void*)out, bias, M, N, 3 * K, ldc, \
+                       w_scale, tiles_m, tiles_n, rs, div);                                                      \
+  } while (0)
+  switch (epi) {
+    case ESMDIFF_F32EPI_STORE:
+      if (bias) ED_GEMM_S(3);
+      else ED_GEMM_S(ESMDIFF_F32EPI_STORE);
+      break;
+    case ESMDIFF_F32EPI_RESID_DIV: ED_GEMM_S(ESMDIFF_F32EPI_RESID_DIV); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef ED_GEMM_S
+  return hipGetLastError();
+}
 
 hipError_t launch_gemm256w4_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N, int K,
                                  int ldc, float alpha, int epilogue, hipStream_t stream) {

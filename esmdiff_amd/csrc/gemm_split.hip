@@ -1,0 +1,325 @@
+// gemm_split.hip — operand preparation for the float32-grade "split" linears (precision = ESMDIFF_PRECISION_F32_SPLIT).
+//
+// Why: the reference runs this path in float32 (/root/reference/slm/utils/checkpoint_utils.py:59-73), and north_star's id
+// criterion is stated against that arithmetic.  The exact-f32 matrix instruction (strict.hip) runs at 1/16 of the 16-bit
+// MFMA rate.  A float32 value splits EXACTLY enough into two f16 numbers, x = hi + lo + r with |r| <= 2^-22 |x| (11 + 11
+// significand bits), and the product of two f16 numbers is exact in f32, so
+//     a . w  =  a_hi . w_hi  +  a_hi . w_lo  +  a_lo . w_hi      (+ a_lo . w_lo ~ 2^-22, dropped)
+// is three passes of v_mfma_f32_32x32x16_f16 into one f32 accumulator (gemm256w4.hip, SPLIT = 1): float32-grade products
+// (error 3 x 2^-22 per term, below the f32 accumulation round-off of a K >= 1536 dot product) at 1/3 of the bf16 rate
+// instead of 1/16.  (A bf16 split needs three parts and six passes for the same 22+ bits.)
+//
+// f16 has 5 exponent bits, so every operand row is scaled by a power of two before it is split (exact, undone in the GEMM
+// epilogue): activations per ROW (the producer knows the row's largest magnitude: it is mapped into [2^14, 2^15), so elements
+// down to 2^-17 of the row maximum keep all 22 bits and smaller ones an absolute error of 2^-39 of the maximum), weights per
+// MATRIX.  No value can overflow and no fixed scale has to be guessed for real checkpoints.
+//
+// Layouts (f16 bits as uint16_t):  A3 [M, 3K] = [hi | lo | hi], rs[M] = 1 / row scale;  W3 [N_pad, 3K] = [lo | hi | hi]: ONE
+// linear walk over 3K accumulates hi.lo + lo.hi + hi.hi (small terms first), so the GEMM main loop is the bf16 kernel's with
+// another opcode (the hi plane is stored twice: 2 more bytes per element on HBM-bound producers, no scalar more in the loop).
+//
+// Kernels here (all HBM-bound, one wave per row):
+//   split_rows_kernel          f32 [M, K] -> A3, rs
+//   layernorm_split_kernel     LayerNorm (optionally of GELU(x): the head's Linear -> GELU -> LayerNorm) -> A3, rs
+//   swiglu_split_kernel        silu(gate) * up of the FFN-up output [M, 2 FH] -> A3 [M, 3 FH], rs
+//   weight_absmax / split_weight_kernel   create-time weight conversion
+#include <string.h>
+
+#include <algorithm>
+
+#include "kernels.h"
+
+namespace ed {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+
+namespace {
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wmax64(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// power-of-two scale that maps `amax` into [2^14, 2^15) and its inverse; amax = 0 / subnormal / inf / nan -> clamped exponents
+__device__ __forceinline__ void row_scale(float amax, float& s, float& inv) {
+  int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);   // biased exponent of the row maximum
+  eb = eb < 20 ? 20 : (eb > 250 ? 250 : eb);
+  s = __uint_as_float((uint32_t)(268 - eb) << 23);         // 2^(14 - (eb - 127))
+  inv = __uint_as_float((uint32_t)(eb - 14) << 23);        // 2^((eb - 127) - 14)
+}
+
+__device__ __forceinline__ void split4(const f32x4 v, float s, f16x4& hi, f16x4& lo) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float a = v[e] * s;                 // exact (power of two, below 2^15)
+    const _Float16 h = (_Float16)a;           // round to nearest even
+    hi[e] = h;
+    lo[e] = (_Float16)(a - (float)h);         // a - h is exact in f32
+  }
+}
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// f32 rows -> split rows.  Two passes over the row (the second one hits L2 / TCP): any K % 4 == 0.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int ld, uint16_t* __restrict__ dst,
+                                                         float* __restrict__ rs, int M, int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* x = src + (int64_t)row * ld;
+  float amax = 0.f;
+  for (int c = lane * 4; c < K; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  amax = wmax64(amax);
+  float s, inv;
+  row_scale(amax, s, inv);
+  if (lane == 0) rs[row] = inv;
+  uint16_t* d = dst + (int64_t)row * 3 * K;
+  for (int c = lane * 4; c < K; c += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + c);
+    f16x4 hi, lo;
+    split4(v, s, hi, lo);
+    *reinterpret_cast<f16x4*>(d + c) = hi;
+    *reinterpret_cast<f16x4*>(d + K + c) = lo;
+    *reinterpret_cast<f16x4*>(d + 2 * K + c) = hi;
+  }
+}
+
+// y = LayerNorm(GELU_IN ? gelu(x) : x) * w (+ b) in the strict path's arithmetic (strict.hip::layernorm_f32_kernel: two-pass
+// statistics, 1 / sqrtf(var + 1e-5), correctly rounded), written as a split row.  One wave per row, D <= 2048.
+template <int NV, bool GELU_IN>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ b, uint16_t* __restrict__ dst,
+                                                              float* __restrict__ rs, float* __restrict__ y32, int M, int D,
+                                                              const uint16_t* __restrict__ delta) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < D) {
+      v[j] = *reinterpret_cast<const f32x4*>(x + (int64_t)row * D + c);
+      if (delta) {   // bf16 engine with an f32-grade head: the last FFN-down delta is still outside x (one f32 add per element)
+        const uint2 dd = *reinterpret_cast<const uint2*>(delta + (int64_t)row * D + c);
+        v[j][0] += __uint_as_float(dd.x << 16);
+        v[j][1] += __uint_as_float(dd.x & 0xffff0000u);
+        v[j][2] += __uint_as_float(dd.y << 16);
+        v[j][3] += __uint_as_float(dd.y & 0xffff0000u);
+      }
+      if constexpr (GELU_IN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] = gelu_erf(v[j][e]);
+      }
+      s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    } else {
+      v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wsum64(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < D) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float d = v[j][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wsum64(q) / (float)D + 1e-5f);
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < D) {
+      const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * ww[e];
+      if (b) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] += bb[e];
+      }
+      v[j] = o;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    }
+  }
+  amax = wmax64(amax);
+  float sc, inv;
+  row_scale(amax, sc, inv);
+  if (lane == 0) rs[row] = inv;
+  uint16_t* d = dst + (int64_t)row * 3 * D;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < D) {
+      f16x4 hi, lo;
+      split4(v[j], sc, hi, lo);
+      *reinterpret_cast<f16x4*>(d + c) = hi;
+      *reinterpret_cast<f16x4*>(d + D + c) = lo;
+      *reinterpret_cast<f16x4*>(d + 2 * D + c) = hi;
+      if (y32) *reinterpret_cast<f32x4*>(y32 + (int64_t)row * D + c) = v[j];   // consumers that stay on the exact-f32 kernel
+    }
+  }
+}
+
+// mid = silu(gate) * up (strict.hip::swiglu_f32_kernel's arithmetic) of one [2 FH] row, as a split row.  FH <= 256 * NV.
+template <int NV>
+__global__ __launch_bounds__(256) void swiglu_split_kernel(const float* __restrict__ gu, uint16_t* __restrict__ dst,
+                                                           float* __restrict__ rs, int M, int FH) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* g = gu + (int64_t)row * 2 * FH;
+  f32x4 v[NV];
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < FH) {
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
+      const f32x4 uu = *reinterpret_cast<const f32x4*>(g + FH + c);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (gg[e] / (1.0f + expf(-gg[e]))) * uu[e];
+      v[j] = o;
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+    }
+  }
+  amax = wmax64(amax);
+  float sc, inv;
+  row_scale(amax, sc, inv);
+  if (lane == 0) rs[row] = inv;
+  uint16_t* d = dst + (int64_t)row * 3 * FH;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (c < FH) {
+      f16x4 hi, lo;
+      split4(v[j], sc, hi, lo);
+      *reinterpret_cast<f16x4*>(d + c) = hi;
+      *reinterpret_cast<f16x4*>(d + FH + c) = lo;
+      *reinterpret_cast<f16x4*>(d + 2 * FH + c) = hi;
+    }
+  }
+}
+
+// ---- weights (engine create) ----------------------------------------------------------------------------------
+__device__ __forceinline__ float load_w(const void* src, int dt, int64_t i) {
+  if (dt == ESMDIFF_F32) return reinterpret_cast<const float*>(src)[i];
+  return __uint_as_float((uint32_t)reinterpret_cast<const uint16_t*>(src)[i] << 16);
+}
+
+__global__ __launch_bounds__(256) void weight_absmax_kernel(const void* __restrict__ src, int dt, int64_t n,
+                                                            uint32_t* __restrict__ out_bits) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float a = fabsf(load_w(src, dt, i));
+    if (a == a) m = fmaxf(m, a);
+  }
+  m = wmax64(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
+__global__ __launch_bounds__(256) void split_weight_kernel(const void* __restrict__ src, int dt, uint16_t* __restrict__ dst,
+                                                           int64_t n, int K, float s) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t r = i / K;
+  const int c = (int)(i - r * K);
+  const float a = load_w(src, dt, i) * s;
+  const _Float16 h = (_Float16)a;
+  const _Float16 l = (_Float16)(a - (float)h);
+  uint16_t hb, lb;
+  __builtin_memcpy(&hb, &h, 2);
+  __builtin_memcpy(&lb, &l, 2);
+  dst[r * 3 * K + c] = lb;        // [lo | hi | hi]
+  dst[r * 3 * K + K + c] = hb;
+  dst[r * 3 * K + 2 * K + c] = hb;
+}
+
+}  // namespace
+
+hipError_t launch_split_rows(const float* src, int ld, uint16_t* dst, float* rs, int M, int K, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  if (K % 4 || ld % 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(split_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, src, ld, dst, rs, M, K);
+  return hipGetLastError();
+}
+
+hipError_t launch_layernorm_split(const float* x, const float* w, const float* b, uint16_t* dst, float* rs, float* y32,
+                                  int M, int D, int gelu_in, hipStream_t stream, const uint16_t* delta) {
+  if (M <= 0) return hipSuccess;
+  if (D % 4 != 0 || D > 2048) return hipErrorInvalidValue;
+  const int nv = (D + 255) / 256;
+  dim3 grid((M + 3) / 4), block(256);
+#define ED_LN(N)                                                                                                       \
+  do {                                                                                                                 \
+    if (gelu_in) hipLaunchKernelGGL((layernorm_split_kernel<N, true>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta);  \
+    else hipLaunchKernelGGL((layernorm_split_kernel<N, false>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta);         \
+  } while (0)
+  switch (nv) {
+    case 1: ED_LN(1); break;
+    case 2: ED_LN(2); break;
+    case 3: ED_LN(3); break;
+    case 4: ED_LN(4); break;
+    case 5: ED_LN(5); break;
+    case 6: ED_LN(6); break;
+    case 7: ED_LN(7); break;
+    default: ED_LN(8); break;
+  }
+#undef ED_LN
+  return hipGetLastError();
+}
+
+hipError_t launch_swiglu_split(const float* gu, uint16_t* dst, float* rs, int M, int FH, hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  if (FH % 4 || FH > 4096) return hipErrorInvalidValue;
+  dim3 grid((M + 3) / 4), block(256);
+  const int nv = (FH + 255) / 256;
+  if (nv <= 4) hipLaunchKernelGGL((swiglu_split_kernel<4>), grid, block, 0, stream, gu, dst, rs, M, FH);
+  else if (nv <= 8) hipLaunchKernelGGL((swiglu_split_kernel<8>), grid, block, 0, stream, gu, dst, rs, M, FH);
+  else if (nv <= 14) hipLaunchKernelGGL((swiglu_split_kernel<14>), grid, block, 0, stream, gu, dst, rs, M, FH);
+  else hipLaunchKernelGGL((swiglu_split_kernel<16>), grid, block, 0, stream, gu, dst, rs, M, FH);
+  return hipGetLastError();
+}
+
+// dst f16 [rows_pad >= rows, 3K] (zero-filled by the caller beyond `rows`) = [lo | hi | hi] of src * 2^k, k chosen so that the
+// matrix maximum lands in [2^14, 2^15); *inv_scale_out = 2^-k for the GEMM epilogue.  Synchronous (create time).
+hipError_t split_weight(const void* src, int src_dtype, uint16_t* dst, int64_t rows, int K, uint32_t* scratch_bits,
+                        float* inv_scale_out) {
+  const int64_t n = rows * K;
+  hipError_t s = hipMemset(scratch_bits, 0, 4);
+  if (s != hipSuccess) return s;
+  const int blocks = (int)std::min<int64_t>((n + 255) / 256, 4096);
+  hipLaunchKernelGGL(weight_absmax_kernel, dim3(blocks), dim3(256), 0, 0, src, src_dtype, n, scratch_bits);
+  uint32_t bits = 0;
+  s = hipMemcpy(&bits, scratch_bits, 4, hipMemcpyDeviceToHost);
+  if (s != hipSuccess) return s;
+  int eb = (int)((bits >> 23) & 0xffu);
+  eb = eb < 20 ? 20 : (eb > 250 ? 250 : eb);
+  const uint32_t sb = (uint32_t)(268 - eb) << 23, ib = (uint32_t)(eb - 14) << 23;
+  float sc, inv;
+  memcpy(&sc, &sb, 4);
+  memcpy(&inv, &ib, 4);
+  hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, src, src_dtype, dst, n, K, sc);
+  *inv_scale_out = inv;
+  return hipGetLastError();
+}
+
+}  // namespace ed

@@ -129,6 +129,22 @@ hipError_t launch_qk_norm_rope_f32(const float* qkv, const float* q_ln_w, const 
 hipError_t launch_attention_f32(const float* q, const float* k, const float* qkv, float* ctx, int B, int L, int H,
                                 hipStream_t stream);
 
+// ---- gemm_split.hip + gemm256w4.hip (SPLIT): float32-grade linears as three f16 MFMA passes over split operands ----
+// A3 f16 [M, 3K] = [hi | lo | hi] scaled per row (rs[M] = 1 / row scale), W3 f16 [N_pad, 3K] = [lo | hi | hi] scaled per
+// matrix (w_inv_scale = 1 / scale); out f32 [M, ldc] = epi(rs[m] * w_inv_scale * A . W^T); N % 256 == 0, K % 128 == 0,
+// ldc >= N (no column bound in the kernel); epi: ESMDIFF_F32EPI_STORE (+ bias[N] when non-null) or ESMDIFF_F32EPI_RESID_DIV.
+hipError_t launch_gemm256w4_split(const uint16_t* A2, const float* rs, const uint16_t* W2, float w_inv_scale, float* out,
+                                  const float* bias, int M, int N, int K, int ldc, float div, int epi, hipStream_t stream);
+hipError_t launch_split_rows(const float* src, int ld, uint16_t* dst, float* rs, int M, int K, hipStream_t stream);
+// LayerNorm (of gelu(x) when gelu_in; of x + delta when delta, a bf16 [M, D] branch output, is non-null) in the strict path's
+// arithmetic -> split row (+ the f32 row into y32 when non-null)
+hipError_t launch_layernorm_split(const float* x, const float* w, const float* b, uint16_t* dst, float* rs, float* y32,
+                                  int M, int D, int gelu_in, hipStream_t stream, const uint16_t* delta = nullptr);
+hipError_t launch_swiglu_split(const float* gu, uint16_t* dst, float* rs, int M, int FH, hipStream_t stream);
+// create time, synchronous: dst [rows_pad, 3K] (caller zero-fills the padding rows); scratch_bits: 4 device bytes
+hipError_t split_weight(const void* src, int src_dtype, uint16_t* dst, int64_t rows, int K, uint32_t* scratch_bits,
+                        float* inv_scale_out);
+
 // ---- convert.hip (weight preparation at engine create) ---------------------------------------
 hipError_t launch_to_bf16(const void* src, int src_dtype, bf16_t* dst, int64_t n, hipStream_t stream);
 hipError_t launch_to_f32(const void* src, int src_dtype, float* dst, int64_t n, hipStream_t stream);

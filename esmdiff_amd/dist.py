@@ -44,3 +44,33 @@ def gather_ids(local_ids: torch.Tensor, num_samples: int) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return local_ids
     return gather_rows(local_ids.to(torch.int16).contiguous(), num_samples).to(torch.int64)
+
+
+def pin_to_gpu_numa(local_rank):
+    """Pin this process's host threads to the CPUs of the NUMA node its GPU hangs off (one process per GPU: the sampling loop's
+    launch thread, the weight upload and the PDB writer should not cross sockets).  Returns {"node", "cpus"} or None when
+    the topology files are missing, the node is unknown (-1) or there is no GPU (stub engines).  Never raises."""
+    import glob
+    import os
+    try:
+        if local_rank is None or not torch.cuda.is_available():
+            return None
+        p = torch.cuda.get_device_properties(local_rank)
+        want = "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+        for d in glob.glob("/sys/bus/pci/devices/*"):
+            if os.path.basename(d).startswith(want):
+                node = int(open(os.path.join(d, "numa_node")).read().strip())
+                if node < 0:
+                    return None
+                cpus = set()
+                for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+                    a, _, b = part.partition("-")
+                    cpus.update(range(int(a), int(b or a) + 1))
+                cpus &= os.sched_getaffinity(0)
+                if not cpus:
+                    return None
+                os.sched_setaffinity(0, cpus)
+                return {"node": node, "cpus": len(cpus)}
+    except Exception:
+        return None
+    return None

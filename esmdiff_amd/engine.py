@@ -37,21 +37,27 @@ class Engine:
     """One engine per (process, device).  Not thread-safe.  All work is enqueued on torch's current stream."""
 
     def __init__(self, cfg: ModelConfig, state_dict: Dict[str, torch.Tensor], max_batch: int, max_len: int,
-                 device: int = 0, precision: str = "bf16"):
-        """precision: "bf16" (the throughput path: bf16 MFMA, f32 accumulate and residual stream) or "f32" (the strict
+                 device: int = 0, precision: str = "bf16", head_precision: Optional[str] = None):
+        """precision: "bf16" (the throughput path: bf16 MFMA, f32 accumulate and residual stream), "f32" (the strict
         path, csrc/strict.hip: float32 weights and activations on the f32-input MFMA — the reference's own arithmetic,
-        checkpoint_utils.py:59-73; ~1/12 of the throughput)."""
+        checkpoint_utils.py:59-73; ~1/12 of the throughput; the referee) or "f32_split" (the strict path with every large
+        linear as three f16 MFMA passes over split operands, csrc/gemm_split.hip: float32-grade, ~1/4 of the bf16 throughput).
+        head_precision="f32" (bf16 engines only): final LayerNorm + output head in float32 grade on the split kernels."""
         _require_gpu()
         if precision not in N.PRECISION:
             raise ValueError(f"precision must be one of {sorted(N.PRECISION)}, got {precision!r}")
+        if head_precision not in (None, "bf16", "f32"):
+            raise ValueError(f"head_precision must be None, 'bf16' or 'f32', got {head_precision!r}")
         self.precision = precision
+        self.head_precision = "f32" if (head_precision == "f32" or precision != "bf16") else "bf16"
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         self.max_batch, self.max_len = max_batch, max_len
         self._lib = N.lib()
         self._h = ctypes.c_void_p(0)
         c = N.Config(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden, cfg.n_structure_heads, cfg.freq_dim,
-                     max_batch, max_len, cfg.residue_scale, int(cfg.time_conditioning), N.PRECISION[precision])
+                     max_batch, max_len, cfg.residue_scale, int(cfg.time_conditioning), N.PRECISION[precision],
+                     1 if (head_precision == "f32" and precision == "bf16") else 0)
         # upload the caller's tensors (any float dtype) as device containers; the engine makes its own
         # bf16 / re-laid-out copies, after which these are released.
         keep, table = [], (N.Weight * len(state_dict))()
@@ -147,6 +153,12 @@ class Engine:
         self._chk(self._lib.esmdiff_forward_logits(self._h, _ptr(seq), _ptr(x), _ptr(tf), _ptr(out), out.shape[-1],
                                                    B, L, _stream()))
         return out[..., :self.cfg.n_structure_heads]
+
+    def embeddings(self, B: int, L: int) -> torch.Tensor:
+        """ESMOutput.embeddings of the forward that just ran (net.py:468-469): the pre-norm hidden state, (B, L, d) f32."""
+        out = torch.empty(B, L, self.cfg.d_model, dtype=torch.float32, device=self.device)
+        self._chk(self._lib.esmdiff_get_embeddings(self._h, _ptr(out), B, L, _stream()))
+        return out
 
     def ddpm_step(self, x: torch.Tensor, logits: torch.Tensor, mc_t: float, mc_s: float, *, final: bool = False,
                   u: Optional[torch.Tensor] = None, seed: Optional[int] = None, sample_offset: int = 0,
@@ -324,7 +336,7 @@ class StructureDecoder:
         self._lib = N.lib()
         self._h = ctypes.c_void_p(0)
         c = N.Config(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden, 23, 1, max_batch, max_len, 1.0, 0,
-                     N.PRECISION[precision])
+                     N.PRECISION[precision], 0)
         keep, table = [], (N.Weight * len(state_dict))()
         with torch.cuda.device(self.device):
             for i, (name, t) in enumerate(state_dict.items()):
@@ -481,9 +493,57 @@ def gemm_f32(A: torch.Tensor, W: torch.Tensor, epilogue: int = 0, *, out: Option
     return out
 
 
-def gemm_bf16_timed(A, W, out, epilogue, iters=20, bias=None, alpha=1.0) -> float:
-    """Average milliseconds per launch, HIP events on the launch stream (esmdiff_gemm_bf16_timed)."""
+def split_rows(A: torch.Tensor):
+    """f32 [M,K] -> (a3 f16 [M,3K] = [hi | lo | hi] of the row scaled by a power of two, rs f32 [M] = 1 / scale): the
+    activation operand of the F32_SPLIT linears (esmdiff_split_rows)."""
     _require_gpu()
+    M, K = A.shape
+    assert A.dtype == torch.float32 and A.stride(1) == 1
+    a2 = torch.empty(M, 3 * K, dtype=torch.float16, device=A.device)
+    rs = torch.empty(M, dtype=torch.float32, device=A.device)
+    N.check(N.lib().esmdiff_split_rows(_ptr(A), A.stride(0), _ptr(a2), _ptr(rs), M, K, _stream()))
+    return a2, rs
+
+
+def split_weight(W: torch.Tensor):
+    """f32 [N,K] -> (w3 f16 [N_pad,3K] = [lo | hi | hi] of W * 2^k, rows padded with zeros to a multiple of 256, 2^-k)."""
+    _require_gpu()
+    Nn, K = W.shape
+    assert W.dtype == torch.float32 and W.is_contiguous()
+    n_pad = (Nn + 255) // 256 * 256
+    w2 = torch.empty(n_pad, 3 * K, dtype=torch.float16, device=W.device)
+    inv = ctypes.c_float(0)
+    torch.cuda.synchronize()
+    N.check(N.lib().esmdiff_split_weight(_ptr(W), _ptr(w2), Nn, n_pad, K, ctypes.byref(inv)))
+    return w2, float(inv.value)
+
+
+def gemm_split(a2: torch.Tensor, rs: Optional[torch.Tensor], w2: torch.Tensor, w_inv: float, n_out: int,
+               epilogue: int = 0, *, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+               div: float = 1.0) -> torch.Tensor:
+    """out f32 [M, n_out] = epi(A . W^T) from split operands on three f16 MFMA passes (esmdiff_gemm_split)."""
+    _require_gpu()
+    M, K3 = a2.shape
+    n_pad = w2.shape[0]
+    assert a2.dtype == w2.dtype == torch.float16 and w2.shape[1] == K3 and a2.is_contiguous() and w2.is_contiguous()
+    if out is None:
+        if epilogue == N.F32EPI_RESID_DIV:
+            raise ValueError("the residual epilogue updates `out` in place: pass it")
+        out = torch.empty(M, n_pad, dtype=torch.float32, device=a2.device)      # the kernel writes whole padded rows
+    assert out.dtype == torch.float32 and out.stride(1) == 1 and out.stride(0) >= n_pad
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= n_pad
+    N.check(N.lib().esmdiff_gemm_split(_ptr(a2), _ptr(rs), _ptr(w2), float(w_inv), _ptr(out), _ptr(bias), M, n_pad, K3 // 3,
+                                       out.stride(0), float(div), epilogue, _stream()))
+    return out[:, :n_out]
+
+
+def gemm_bf16_timed(A, W, out, epilogue, iters=20, bias=None, alpha=1.0) -> float:
+    """Average milliseconds per launch, HIP events on the launch stream (esmdiff_gemm_bf16_timed; -DED_DEBUG builds only)."""
+    _require_gpu()
+    if not hasattr(N.lib(), "esmdiff_gemm_bf16_timed"):
+        raise RuntimeError("esmdiff_gemm_bf16_timed is a measurement aid of -DED_DEBUG builds: "
+                           "ESMDIFF_EXTRA_CXXFLAGS=-DED_DEBUG python -m esmdiff_amd.build --force")
     M, K = A.shape
     ms = ctypes.c_float(0)
     N.check(N.lib().esmdiff_gemm_bf16_timed(_ptr(A), _ptr(W), _ptr(out), _ptr(bias), M, W.shape[0], K,

@@ -26,7 +26,8 @@ from .weights import load_checkpoint_state_dict, random_init_state_dict
 class MaskedDiffusionLanguageModeling:
     def __init__(self, state_dict: Dict[str, torch.Tensor], cfg: ModelConfig = ESM3_OPEN,
                  noise_schedule: Optional[Noise] = None, max_batch: int = 128, max_len: int = 1026,
-                 device: int = 0, noise_removal: bool = True, precision: str = "bf16", step0_sharing: bool = True):
+                 device: int = 0, noise_removal: bool = True, precision: str = "bf16", step0_sharing: bool = True,
+                 head_precision: Optional[str] = None):
         if noise_schedule is None:
             print("Using default noise schedule: CosineNoise(eps=1e-3)")    # model.py:345-347
             noise_schedule = CosineNoise(eps=1e-3)
@@ -37,7 +38,8 @@ class MaskedDiffusionLanguageModeling:
         self.vocab_size = STRUCTURE_VOCAB
         self.mask_index = STRUCTURE_MASK_TOKEN
         self.neg_infinity = -1000000.0
-        self.net = Engine(cfg, state_dict, max_batch=max_batch, max_len=max_len, device=device, precision=precision)
+        self.net = Engine(cfg, state_dict, max_batch=max_batch, max_len=max_len, device=device, precision=precision,
+                          head_precision=head_precision)
         # exact step-0 sharing (include/esmdiff_hip.h): the CLI repeats ONE sequence per batch, so the first forward of a run has
         # identical rows; the engine checks that on the device and then serves all samples from a sub-batch forward — ids are
         # bit-identical to the unshared loop (tests/test_gpu_fullwidth.py::test_step0_sharing_is_exact).  bench.py's headline
@@ -130,7 +132,8 @@ def config_from_hydra_yaml(path, cfg: ModelConfig = ESM3_OPEN):
 
 
 def load_state_dict_from_lightning_ckpt(ckpt_path, device="cuda", max_batch: int = 128, max_len: int = 1026,
-                                        cfg: ModelConfig = ESM3_OPEN, precision: str = "bf16"):
+                                        cfg: ModelConfig = ESM3_OPEN, precision: str = "bf16",
+                                        head_precision: Optional[str] = None):
     """/root/reference/slm/utils/checkpoint_utils.py:41-74: a `.pt` whose 'module' dict holds `net.*` and
     `sigma_embedder.*`; the model is what the run's `.hydra/config.yaml` says when that file sits where the reference
     looks for it (:45-50), else the mdlm.yaml configuration (LogLinearNoise, time conditioning, 4101-way head);
@@ -146,12 +149,14 @@ def load_state_dict_from_lightning_ckpt(ckpt_path, device="cuda", max_batch: int
     print(f"Loaded experiment config: {exp_cfg_path or 'mdlm.yaml defaults'}...")
     sd = load_checkpoint_state_dict(ckpt_path)
     dev = torch.device(device).index or 0
-    model = MaskedDiffusionLanguageModeling(sd, cfg, noise, max_batch, max_len, dev, noise_removal=True, precision=precision)
+    model = MaskedDiffusionLanguageModeling(sd, cfg, noise, max_batch, max_len, dev, noise_removal=True, precision=precision,
+                                            head_precision=head_precision)
     print(f"Sucessfully loaded model from {ckpt_path}...")
     return model
 
 
-def load_stock_esm3(path, device="cuda", max_batch: int = 128, max_len: int = 1026, precision: str = "bf16"):
+def load_stock_esm3(path, device="cuda", max_batch: int = 128, max_len: int = 1026, precision: str = "bf16",
+                    head_precision: Optional[str] = None):
     """The pre-trained ESM3 the reference uses when --ckpt is absent (`ESM3.from_pretrained("esm3_sm_open_v1")`,
     /root/reference/slm/sample_esmdiff.py:37, :252-255; gibbs mode only): a plain esm state dict (keys without the
     `net.` prefix, 4096-way structure head, no sigma_embedder) saved with torch.save."""
@@ -160,12 +165,12 @@ def load_stock_esm3(path, device="cuda", max_batch: int = 128, max_len: int = 10
     sd = sd.get("state_dict", sd) if isinstance(sd, dict) else sd
     dev = torch.device(device).index or 0
     return MaskedDiffusionLanguageModeling(sd, ESM3_OPEN_STOCK, None, max_batch, max_len, dev, noise_removal=True,
-                                           precision=precision)
+                                           precision=precision, head_precision=head_precision)
 
 
 def random_init_model(cfg: ModelConfig = ESM3_OPEN, seed: int = 0, max_batch: int = 128, max_len: int = 1026,
-                      device: int = 0, precision: str = "bf16"):
+                      device: int = 0, precision: str = "bf16", head_precision: Optional[str] = None):
     """ESM3-open-sized random weights (no checkpoint can be fetched offline): synthetic benchmarking / tests."""
     sd = random_init_state_dict(cfg, seed=seed, device=f"cuda:{device}", with_geom=True)   # real checkpoints carry geom_attn too
     return MaskedDiffusionLanguageModeling(sd, cfg, LogLinearNoise(), max_batch, max_len, device, noise_removal=True,
-                                           precision=precision)
+                                           precision=precision, head_precision=head_precision)

@@ -325,10 +325,13 @@ def get_argparser(argv=None):
     p.add_argument("--synthetic_len", type=int, default=0, help="sample a random sequence of this length")
     p.add_argument("--n_max_residue_square", type=int, default=DEFAULT_NMAX)
     p.add_argument("--parity", action="store_true", help="uniforms from torch's CPU generator, like the reference")
-    p.add_argument("--precision", choices=["bf16", "f32"], default="bf16",
+    p.add_argument("--precision", choices=["bf16", "f32", "f32_split"], default="bf16",
                    help="arithmetic of the sampling network: bf16 = the MFMA throughput path (default); f32 = the strict path, the "
-                        "reference's own float32 arithmetic (ids equal to a float32 run of the same seed; ~1/12 of the throughput)")
-    p.add_argument("--decoder_precision", choices=["f32", "bf16"], default="f32",
+                        "reference's own float32 arithmetic on the f32-input MFMA (ids equal to a float32 run of the same seed; ~1/12 "
+                        "of the throughput); f32_split = float32-grade linears as three f16 MFMA passes over split operands (~1/4)")
+    p.add_argument("--head_precision", choices=["bf16", "f32"], default="bf16",
+                   help="bf16 network only: final LayerNorm + output head in float32 grade (+1 %% time, fewer near-tie flips)")
+    p.add_argument("--decoder_precision", choices=["f32", "f32_split", "bf16"], default="f32",
                    help="arithmetic of the VQ-VAE structure decoder (and encoder): f32 (default, backbone within 1e-4 A of a float32 "
                         "decode, encoder codes equal to a float32 encoder's) or bf16")
     p.add_argument("--no_timestamp", action="store_true")
@@ -385,14 +388,14 @@ def main(argv=None):
     if args.random_init:
         from .config import ESM3_OPEN, TINY
         model = random_init_model(TINY if args.tiny else ESM3_OPEN, seed=args.seed, max_batch=max_b, max_len=max_len,
-                                  device=local_rank, precision=args.precision)
+                                  device=local_rank, precision=args.precision, head_precision=args.head_precision)
     elif args.ckpt is None:
         from .model import load_stock_esm3
         model = load_stock_esm3(args.esm3_ckpt, device=f"cuda:{local_rank}", max_batch=max_b, max_len=max_len,
-                                precision=args.precision)
+                                precision=args.precision, head_precision=args.head_precision)
     else:
         model = load_state_dict_from_lightning_ckpt(args.ckpt, device=f"cuda:{local_rank}", max_batch=max_b,
-                                                    max_len=max_len, precision=args.precision)
+                                                    max_len=max_len, precision=args.precision, head_precision=args.head_precision)
     decoder = None
     if args.decoder_ckpt or args.random_init_decoder:          # one per rank: each rank decodes its own shard
         from .config import STRUCTURE_DECODER_V0, TINY_DECODER
@@ -413,7 +416,8 @@ def main(argv=None):
         ecfg = TINY_ENCODER if args.tiny else STRUCTURE_ENCODER_V0
         esd = (torch.load(args.encoder_ckpt, map_location="cpu", weights_only=True) if args.encoder_ckpt
                else random_init_encoder_state_dict(ecfg, seed=args.seed, device=f"cuda:{local_rank}"))
-        encoder = StructureEncoder(ecfg, esd, device=local_rank, precision=args.decoder_precision)   # same switch as the decoder
+        encoder = StructureEncoder(ecfg, esd, device=local_rank,     # same switch as the decoder (the encoder has no split form)
+                                   precision="f32" if args.decoder_precision == "f32_split" else args.decoder_precision)
     if rank == 0:
         print(f">>> Sampling mode = {args.mode} ...")
     for name, seq in targets:

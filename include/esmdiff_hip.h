@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESMDIFF_ABI_VERSION 4
+#define ESMDIFF_ABI_VERSION 5
 
 /* structure-track vocabulary: esm constants mirrored at model.py:380-381 */
 #define ESMDIFF_VOCAB 4101
@@ -60,8 +60,14 @@ typedef enum { ESMDIFF_F32 = 0, ESMDIFF_BF16 = 1 } esmdiff_dtype;
  *         (checkpoint_utils.py:59-73 loads float32; decode at sample_esmdiff.py:40-61), ~1/12 of the bf16 throughput.
  *         It is what north_star's floating-point bars are stated against (ids equal under a fixed seed, decoded backbone
  *         within 1e-4 A) and the structure decoder's default on the Python side.  A row's result does not depend on the
- *         batch it is computed in.  Coordinate conditioning (esmdiff_set_frames) runs in float32 too. */
-typedef enum { ESMDIFF_PRECISION_BF16 = 0, ESMDIFF_PRECISION_F32 = 1 } esmdiff_precision;
+ *         batch it is computed in.  Coordinate conditioning (esmdiff_set_frames) runs in float32 too.
+ *   F32_SPLIT (ABI 5; csrc/gemm_split.hip)  the F32 path with every large linear computed as THREE passes of the f16 MFMA
+ *         over operands split into two f16 numbers each (x = hi + lo to 2^-22, rows scaled by powers of two so that nothing
+ *         can overflow; f16 x f16 products are exact in f32; the dropped lo.lo term is 2^-22): float32-grade products with
+ *         f32 accumulation at ~1/3 of the bf16 MFMA rate instead of 1/16.  LayerNorm / rotary / softmax / SwiGLU / GELU are
+ *         the F32 path's kernels.  Not bitwise an fmaf chain (F32 is, and stays the referee); a row's result still does not
+ *         depend on the batch it is computed in. */
+typedef enum { ESMDIFF_PRECISION_BF16 = 0, ESMDIFF_PRECISION_F32 = 1, ESMDIFF_PRECISION_F32_SPLIT = 2 } esmdiff_precision;
 
 /* Hyper-parameters of CustomizedESM3 (net.py:322-332) + TimestepEmbedder (net.py:487) +
  * StructureOutputHeads (net.py:299); values for ESM3-open: 1536 / 24 / 48 / 4096 / 4101 / 256. */
@@ -77,6 +83,10 @@ typedef struct {
   float residue_scale;  /* sqrt(n_layers/36) — esm TransformerStack */
   int32_t time_conditioning; /* mdlm.yaml:41 */
   int32_t precision;    /* one of the esmdiff_precision values; new in ABI 4 */
+  int32_t head_precision; /* ABI 5.  0: the head runs in `precision`.  1 (with precision = BF16): the final LayerNorm and the
+                           * output head (net.py:298-308: Linear, GELU, LayerNorm, Linear) run in float32 grade on the
+                           * F32_SPLIT kernels from the f32 residual stream — the logits' own rounding (64 % of the bf16
+                           * engine's logit-error variance, profiles/r04_head_decomposition.json) goes away for +1 % time */
 } esmdiff_config;
 
 /* One state-dict entry.  `name` uses the reference's key layout for the ESMDiff
@@ -125,6 +135,10 @@ const char* esmdiff_last_error(const esmdiff_engine* eng);
 int esmdiff_forward_logits(esmdiff_engine* eng, const int64_t* seq, const int64_t* x,
                            const float* t_freq, float* logits_out, int32_t ld_logits,
                            int32_t B, int32_t L, void* stream);
+
+/* ESMOutput.embeddings of the forward that just ran (net.py:468-469, :312-320: the transformer stack's pre-norm hidden
+ * state, the second value `self.transformer(...)` returns): out f32 [B,L,d_model].  (B, L) must be the last forward's. */
+int esmdiff_get_embeddings(esmdiff_engine* eng, float* out, int32_t B, int32_t L, void* stream);
 
 /* Replaces logits_parameterization + the sampling half of _ddpm_update + _sample_categorical
  * (model.py:527-533, 602-607, 24-28): given RAW network logits, writes x' in place.
@@ -181,11 +195,6 @@ int esmdiff_gibbs_sample(esmdiff_engine* eng, const int64_t* seq, int64_t* x_ino
                          float temperature, float top_p, const int32_t* n_unmask_table, const esmdiff_rng* rng,
                          void* stream);
 
-/* Measurement aid: one forward at (B, L) `n` times as plain launches and as `n` replays of one captured hipGraph of the
- * same launches (engine-owned stream); milliseconds per forward of each [host]. */
-int esmdiff_debug_graph_ab(esmdiff_engine* eng, const int64_t* seq, const int64_t* x, int32_t B, int32_t L, int32_t n,
-                           float* ms_direct, float* ms_graph);
-
 /* Per-kernel entry points (used by the parity tests and the bench's roofline leg). */
 
 /* C[M,N] (+)= A[M,K] · W[N,K]^T, bf16 in, f32 accumulate.  epilogue: see esmdiff_gemm_epilogue. */
@@ -210,17 +219,23 @@ typedef enum {
 int esmdiff_gemm_f32(const float* A, int32_t lda, const float* W, float* out, const float* bias, int32_t M, int32_t N,
                      int32_t K, int32_t ldc, int32_t n_valid, float div, int32_t epilogue, void* stream);
 
+/* The F32_SPLIT path's linear and its operand preparation (csrc/gemm_split.hip, csrc/gemm256w4.hip SPLIT = 1).
+ *   esmdiff_split_rows    src f32 [M,K] (row stride ld) -> a3 f16 [M,3K] = [hi | lo | hi] of src * 2^k(row), rs[M] = 2^-k(row)
+ *   esmdiff_split_weight  src f32 [N,K] -> w3 f16 [N_pad,3K] = [lo | hi | hi] of src * 2^k (rows N..N_pad-1 zero-filled,
+ *                         N_pad a multiple of 256 >= N), *inv_scale_out [host] = 2^-k; synchronous
+ *   esmdiff_gemm_split    out f32 [M,ldc] = epi(rs[m] * w_inv_scale * A . W^T [+ bias[N]]); N (= N_pad) % 256 == 0,
+ *                         K % 128 == 0, ldc >= N: whole padded rows are written (the kernel carries no column bound);
+ *                         epilogue ESMDIFF_F32EPI_STORE (bias optional) or ESMDIFF_F32EPI_RESID_DIV. */
+int esmdiff_split_rows(const float* src, int32_t ld, void* a2, float* rs, int32_t M, int32_t K, void* stream);
+int esmdiff_split_weight(const float* src, void* w2, int32_t N, int32_t N_pad, int32_t K, float* inv_scale_out);
+int esmdiff_gemm_split(const void* a2, const float* rs, const void* w2, float w_inv_scale, float* out, const float* bias,
+                       int32_t M, int32_t N, int32_t K, int32_t ldc, float div, int32_t epilogue, void* stream);
+
 /* The same GEMM as the engine issues it: with the engine's split-K workspace, so the small-M path (M < 1152 rows,
  * K >= 2048: FFN-down) runs as K slices + a fixed-order reduce kernel (csrc/gemm.hip).  Not re-entrant per engine. */
 int esmdiff_gemm_bf16_ws(esmdiff_engine* eng, const void* A, const void* W, void* out, const float* bias, int32_t M,
                          int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue,
                          void* stream);
-
-/* Wall-clock helper for the bench's roofline leg: runs the GEMM `iters` times on `stream` bracketed by
- * HIP events on that stream and returns the average milliseconds per launch in *ms_out [host]. */
-int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float* bias, int32_t M,
-                            int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha,
-                            int32_t epilogue, int32_t iters, float* ms_out, void* stream);
 
 /* The small-batch form of a residual branch (M < 1152 rows; csrc/engine.hip::forward): the branch linear A[M,K] W[N,K]^T
  * is left as S raw f32 K-slice planes in the engine's workspace (S = *splits_out, a function of N and K only) and the
@@ -334,6 +349,22 @@ int esmdiff_metrics_bonding_validity(const double* ca_model, int32_t n_model, co
  * ms_out: [16] floats, launches_out: [16] ints [host].  Synchronises the device. */
 int esmdiff_set_profiling(esmdiff_engine* eng, int32_t on);
 int esmdiff_get_profile(esmdiff_engine* eng, float* ms_out, int32_t* launches_out);
+
+#ifdef ED_DEBUG
+/* ---- measurement aids: exported only by libraries built with -DED_DEBUG (ESMDIFF_EXTRA_CXXFLAGS=-DED_DEBUG python -m
+ * esmdiff_amd.build); the product library carries neither these nor the ESMDIFF_DEBUG_SKIP launch-skipping switch, and
+ * esmdiff_engine_create FAILS when that variable is set.  Used by scratch/ A/B scripts only. ---- */
+/* Measurement aid: one forward at (B, L) `n` times as plain launches and as `n` replays of one captured hipGraph of the
+ * same launches (engine-owned stream); milliseconds per forward of each [host]. */
+int esmdiff_debug_graph_ab(esmdiff_engine* eng, const int64_t* seq, const int64_t* x, int32_t B, int32_t L, int32_t n,
+                           float* ms_direct, float* ms_graph);
+
+/* Wall-clock helper for the bench's roofline leg: runs the GEMM `iters` times on `stream` bracketed by
+ * HIP events on that stream and returns the average milliseconds per launch in *ms_out [host]. */
+int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float* bias, int32_t M,
+                            int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha,
+                            int32_t epilogue, int32_t iters, float* ms_out, void* stream);
+#endif /* ED_DEBUG */
 
 #ifdef __cplusplus
 }

@@ -36,13 +36,17 @@ def test_library_exports_every_declared_symbol():
     lib_path = build()
     assert lib_path.exists()
     header = (ROOT / "include" / "esmdiff_hip.h").read_text()
+    header = re.sub(r"#ifdef ED_DEBUG.*?#endif /\* ED_DEBUG \*/", "", header, flags=re.S)   # measurement aids of debug builds
+    assert "esmdiff_debug_graph_ab" not in header
     declared = set(re.findall(r"\b(esmdiff_[a-z0-9_]+)\s*\(", header))
     declared -= {"esmdiff_gemm_epilogue"}
     assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
     L = ctypes.CDLL(str(lib_path))
     for name in declared:
         assert hasattr(L, name), name
-    assert L.esmdiff_abi_version() == 4
+    # the product library carries no debug exports
+    assert not hasattr(L, "esmdiff_debug_graph_ab") and not hasattr(L, "esmdiff_gemm_bf16_timed")
+    assert L.esmdiff_abi_version() == 5
 
 
 def test_config_dimensions():
