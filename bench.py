@@ -505,12 +505,15 @@ def main():
     prof = eng.get_profile()
     eng.set_profiling(0)
     assert int((ids == 4096).sum()) == 0
-    # Second, LABELLED figure (never `value`): the same workload with exact step-0 sharing — every sample of a step starts
-    # from identical tokens, so the first of the T + 1 forwards runs on a sub-batch and serves all samples; ids are
-    # bit-identical to the run above (tests: test_step0_sharing_is_exact).  FLOP accounting uses the rows really executed.
+    # Second, LABELLED figure (never `value`): the same workload with the exact shortcuts — step-0 sharing (every sample of a
+    # step starts from identical tokens, so the first of the T + 1 forwards runs on a sub-batch and serves all samples) and the
+    # noise-removal skip (forward T + 1 only for samples that still hold a MASK); ids are bit-identical to the run above
+    # (tests: test_step0_sharing_is_exact, test_final_skip_is_exact).  FLOP accounting uses the rows really executed.
     shared_rec = None
     if world == 1 and not stub and not args.no_step0_sharing:
         eng.set_step0_sharing(True)
+        if args.mode == "ddpm":
+            eng.set_final_skip(True)                             # the other exact shortcut (esmdiff_set_final_skip)
         same = bool(torch.equal(one_step(0), ids0)) if ids0 is not None else None   # step 0 again (same seed), shared this time
         sync_local()
         eng.counters(reset=True)
@@ -522,12 +525,15 @@ def main():
         ts1 = time.perf_counter()
         cnt = eng.counters(reset=True)
         eng.set_step0_sharing(False)
+        eng.set_final_skip(False)
         shared_rec = {"value": round(B * ks / (ts1 - ts0), 3), "unit": "samples/s", "steps": ks,
                       "forwards_executed_per_sample": round(cnt["token_rows"] / (B * L * ks), 4),
                       "token_rows_executed_per_step": cnt["token_rows"] // ks,
                       "ids_equal_to_unshared_run": same,
-                      "what": "same workload, esmdiff_set_step0_sharing(1): at step 0 all samples have identical inputs, one "
-                              "sub-batch forward serves them all (exact: ids bit-identical); NOT the headline value"}
+                      "what": "same workload with the two EXACT shortcuts on (ids bit-identical to the plain run, asserted here and in "
+                              "tests/test_gpu_fullwidth.py): esmdiff_set_step0_sharing — at step 0 all samples have identical inputs, "
+                              "one sub-batch forward serves them all; esmdiff_set_final_skip — the noise-removal forward runs only for "
+                              "samples that still hold a MASK (none, almost always).  NOT the headline value"}
 
     # Third, LABELLED figure: the same workload on a bf16 engine whose final LayerNorm + output head run in float32 grade
     # (esmdiff_config.head_precision = 1).  The head is 0.6 % of the FLOP and 64 % of the bf16 logit-error variance
@@ -600,7 +606,7 @@ def main():
             if shared_rec is not None:
                 shared_rec["flop_per_sample_executed"] = flops_forward_per_sample(L, cfg) * shared_rec["forwards_executed_per_sample"]
                 shared_rec["mfma_frac_whole_job"] = round(shared_rec["value"] * shared_rec["flop_per_sample_executed"] / (PEAK_BF16_TFLOPS * 1e12), 4)
-                out["step0_sharing"] = shared_rec
+                out["exact_shortcuts"] = shared_rec
         if world == 1 and not args.no_cpu_baseline and not stub:
             try:
                 out["cpu_baseline"], spots = cpu_baseline(cfg, sd, L, T, {"value": eng, "f32_head": eng_h})

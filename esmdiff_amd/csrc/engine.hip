@@ -122,6 +122,10 @@ struct esmdiff_engine {
   // forward runs on a sub-batch and all samples draw from its logits; counters of the work really executed
   int step0_share = 0;
   int32_t* flag_dev = nullptr;
+  // exact skip of the noise-removal forward (esmdiff_set_final_skip): only samples that still hold a MASK run forward T + 1
+  int final_skip = 0;
+  int32_t *has_dev = nullptr, *idx_dev = nullptr;
+  int64_t *cx = nullptr, *cseq = nullptr;   // compacted token rows of those samples
   // gibbs options (esmdiff_set_gibbs_options): 0 entropy-ordered / 1 random positions; bit v of inv_mask = id v is never drawn
   int g_strategy = 0;
   uint32_t* g_inv_mask = nullptr;
@@ -576,7 +580,10 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
     }
     EACH(S_FFN_UP, launch_gemm_bf16(w.h, ly.w_up, w.mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, w.st, w.gws));
     if (small) EACH(S_FFN_DOWN, launch_gemm_partials(w.mid, ly.w_down, w.gws, M, D, FH, w.st, &PF[pi]));
-    else EACH(S_FFN_DOWN, launch_gemm_bf16(w.mid, ly.w_down, w.dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
+    // (no split-K workspace here: on the regular path a row's K order must not depend on how many rows its sub-batch has —
+    //  with the workspace a part below 1 152 rows next to a larger one, e.g. B = 9 at L_tok = 258 cut 4 + 5, summed its FFN-down
+    //  in 8 slices and the other part in one pass, and step-0 sharing / batch composition changed the last bit: ADVICE r03)
+    else EACH(S_FFN_DOWN, launch_gemm_bf16(w.mid, ly.w_down, w.dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, nullptr));
     pending = true;
   }
   e->last_pending_delta = !small && pending;
@@ -623,6 +630,7 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
 int step0_shared_batch(esmdiff_engine* e, const int64_t* seq, const int64_t* x, int B, int L, hipStream_t st, int* shared) {
   *shared = 0;
   if (!e->step0_share || B < 2) return 0;
+  if (e->frames_B != 0) return 0;   // coordinate conditioning: frames may differ per sample and are not compared below
   const int bs = shared_forward_batch(e, B, L);
   if (bs >= B) return 0;
   HIP_TRY(e, launch_rows_identical(seq, x, B, L, e->flag_dev, st));
@@ -662,6 +670,12 @@ int esmdiff_set_gibbs_options(esmdiff_engine* e, int32_t strategy, const int32_t
 int esmdiff_set_step0_sharing(esmdiff_engine* e, int32_t on) {
   if (!e) return ESMDIFF_E_INVALID;
   e->step0_share = on ? 1 : 0;
+  return 0;
+}
+
+int esmdiff_set_final_skip(esmdiff_engine* e, int32_t on) {
+  if (!e) return ESMDIFF_E_INVALID;
+  e->final_skip = on ? 1 : 0;
   return 0;
 }
 
@@ -974,7 +988,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(dalloc(e, &e->logits, Mx * e->ld_logits));
     if (e->has_plddt) TRY(dalloc(e, &e->pl_logits, Mx * e->ld_plddt));
     if (e->has_pair) {
-      TRY(dalloc(e, &e->pair_qk, Mx * 128));
+      if (!strict) TRY(dalloc(e, &e->pair_qk, Mx * 128));   // (a float32 engine keeps the pair rows in fpair_qk)
       TRY(dalloc(e, &e->tm_rows, Mx));
       TRY(dalloc(e, &e->ptm_dev, (size_t)cfg->max_batch));
     }
@@ -984,6 +998,10 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(dalloc(e, &e->tfreq, (size_t)e->tfreq_rows * F));
     TRY(dalloc(e, &e->g_entropy, Mx));
     TRY(dalloc(e, &e->flag_dev, (size_t)4));
+    TRY(dalloc(e, &e->has_dev, (size_t)cfg->max_batch));
+    TRY(dalloc(e, &e->idx_dev, (size_t)cfg->max_batch));
+    TRY(dalloc(e, &e->cx, Mx));
+    TRY(dalloc(e, &e->cseq, Mx));
     TRY(dalloc(e, &e->g_inv_mask, (size_t)128, true));
     TRY(dalloc(e, &e->g_sampled, Mx));
     TRY(dalloc(e, &e->g_nunmask, (size_t)e->tfreq_rows * cfg->max_batch));
@@ -1176,6 +1194,38 @@ int esmdiff_ddpm_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout,
   if (int r = step0_shared_batch(e, seq, x_inout, B, L, st, &shared)) return r;
   for (int i = 0; i <= T; ++i) {
     const int Bf = (i == 0 && shared) ? shared : B;   // step 0 of an all-identical batch: one sub-batch forward serves all
+    if (i == T && e->final_skip && T > 0) {
+      // Noise removal (model.py:575-579): x = argmax of the re-parameterised logits, which for a row without MASK is the row's own
+      // token (log p = 0 there, -1e6 elsewhere, model.py:530-532) — a sample with no MASK left comes back unchanged whatever the
+      // network says.  After update T the expected number of still-masked rows is mc_s / mc_t of the last step ~ 2.5e-4 of the
+      // masked rows: run forward T + 1 only on the samples that hold one, as a sub-batch that takes the same dispatch path as the
+      // whole batch would (bit-identical logits, shared_forward_batch), padded with the first samples when it is smaller.
+      HIP_TRY(e, launch_samples_with_mask(x_inout, B, L, e->has_dev, st));
+      std::vector<int32_t> has(B);
+      HIP_TRY(e, hipMemcpyAsync(has.data(), e->has_dev, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(e, hipStreamSynchronize(st));
+      std::vector<int32_t> idx;
+      for (int b = 0; b < B; ++b)
+        if (has[b]) idx.push_back(b);
+      const int n_live = (int)idx.size();
+      if (n_live == 0) break;                                   // every sample is complete: forward T + 1 changes nothing
+      const int n_min = shared_forward_batch(e, B, L);           // smallest sub-batch with the whole batch's dispatch path (B: none)
+      if (n_min < B && n_live < B) {
+        for (int b = 0; (int)idx.size() < n_min && b < B; ++b)
+          if (!has[b]) idx.push_back(b);                         // padding: complete samples, their rows come back unchanged
+        const int n_run = (int)idx.size();
+        HIP_TRY(e, hipMemcpyAsync(e->idx_dev, idx.data(), (size_t)n_run * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(e, launch_move_token_rows(x_inout, e->cx, e->idx_dev, n_run, L, 1, st));
+        HIP_TRY(e, launch_move_token_rows(seq, e->cseq, e->idx_dev, n_run, L, 1, st));
+        if (int r = forward(e, e->cseq, e->cx, t_freq ? e->tfreq + (size_t)i * F : nullptr, e->logits, e->ld_logits, n_run, L, st)) return r;
+        p.mark(S_SAMPLER);
+        HIP_TRY(e, launch_ddpm_step(e->cx, e->logits, e->ld_logits, e->cfg.vocab_out, 0.f, 0.f, 1, nullptr, 1, rng->seed, rng->sample_offset, i, n_run, L, st, 0));
+        p.mark(S_SAMPLER);
+        HIP_TRY(e, launch_move_token_rows(e->cx, x_inout, e->idx_dev, n_live, L, 0, st));   // only the live samples go back
+        HIP_TRY(e, hipStreamSynchronize(st));                    // idx (host vector) must outlive the H2D copy
+        break;
+      }
+    }
     if (int r = forward(e, seq, x_inout, t_freq ? e->tfreq + (size_t)i * F : nullptr, e->logits, e->ld_logits, Bf, L, st)) return r;
     const int fin = i == T;
     p.mark(S_SAMPLER);
@@ -1193,7 +1243,7 @@ int esmdiff_gibbs_step(esmdiff_engine* e, int64_t* x_inout, const int64_t* seq, 
   if (!x_inout || !seq || !logits || !n_unmask) return fail(e, ESMDIFF_E_INVALID, "null pointer");
   if (!u && !rng) return fail(e, ESMDIFF_E_INVALID, "need explicit uniforms or an rng");
   if (!(temperature > 0.f)) return fail(e, ESMDIFF_E_INVALID, "temperature must be > 0 (argmax decoding is not built)");
-  if (!(top_p > 0.f)) return fail(e, ESMDIFF_E_INVALID, "top_p must be in (0, 1]");
+  if (!(top_p > 0.f) || top_p > 1.f) return fail(e, ESMDIFF_E_INVALID, "top_p must be in (0, 1]");
   if (ld_logits < 4096 || e->cfg.vocab_out < 4096 || ld_logits < e->cfg.vocab_out) return fail(e, ESMDIFF_E_INVALID, "bad shape");
   if (int r = check_bl(e, B, L)) return r;
   Prof p{e, (hipStream_t)stream};
@@ -1215,12 +1265,11 @@ int esmdiff_gibbs_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout
   if (T <= 0 || T > e->tfreq_rows) return fail(e, ESMDIFF_E_INVALID, "num_steps %d out of range (1..%d)", T, e->tfreq_rows);
   if (int r = check_bl(e, B, L)) return r;
   hipStream_t st = (hipStream_t)stream;
-  HIP_TRY(e, hipMemcpyAsync(e->g_nunmask, n_unmask_table, (size_t)T * B * sizeof(int32_t), hipMemcpyHostToDevice, st));
   if (!(temperature > 0.f)) return fail(e, ESMDIFF_E_INVALID, "temperature must be > 0 (argmax decoding is not built)");
-  if (!(top_p > 0.f)) return fail(e, ESMDIFF_E_INVALID, "top_p must be in (0, 1]");
+  if (!(top_p > 0.f) || top_p > 1.f) return fail(e, ESMDIFF_E_INVALID, "top_p must be in (0, 1]");
+  HIP_TRY(e, hipMemcpyAsync(e->g_nunmask, n_unmask_table, (size_t)T * B * sizeof(int32_t), hipMemcpyHostToDevice, st));
   int shared = 0;
-  if (e->frames_B == 0)              // (with coordinate conditioning the frames may differ per prompt: no sharing)
-    if (int r = step0_shared_batch(e, seq, x_inout, B, L, st, &shared)) return r;
+  if (int r = step0_shared_batch(e, seq, x_inout, B, L, st, &shared)) return r;   // (0 with coordinate conditioning)
   for (int i = 0; i < T; ++i) {
     const int Bf = (i == 0 && shared) ? shared : B;
     if (int r = forward(e, seq, x_inout, nullptr, e->logits, e->ld_logits, Bf, L, st)) return r;

@@ -376,10 +376,9 @@ static hipError_t launch_tiles(const bf16_t* A, const bf16_t* W, void* out, cons
 #define ED_LAUNCH(E, NST, MI)                                                                                       \
   do {                                                                                                              \
     constexpr int lds = NST * (64 * MI * BK * 2 + TILE_BYTES);                                                      \
-    static bool attr_done = false;                                                                                  \
-    if (!attr_done && lds > 65536) {                                                                                \
-      hipFuncSetAttribute((const void*)gemm_bf16_kernel<E, NST, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-      attr_done = true;                                                                                             \
+    if (lds > 65536) {                                                                                              \
+      const hipError_t a_ = ensure_dynamic_lds((const void*)gemm_bf16_kernel<E, NST, MI>, lds);                     \
+      if (a_ != hipSuccess) return a_;                                                                              \
     }                                                                                                               \
     hipLaunchKernelGGL((gemm_bf16_kernel<E, NST, MI>), grid, block, lds, stream, A, W, out, bias, M, N, K, ldc,     \
                        n_valid, alpha, tiles_m, tiles_n, S, partial, pstride, w_rs, w_ks, w_ns, w_nt);              \

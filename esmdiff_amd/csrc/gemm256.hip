@@ -550,10 +550,9 @@ hipError_t launch_gemm256_bf16(const bf16_t* A, const bf16_t* W, void* out, cons
   }();
 #define ED_GEMM(E)                                                                                         \
   do {                                                                                                     \
-    static bool attr_done = false;                                                                         \
-    if (!attr_done) {                                                                                      \
-      hipFuncSetAttribute((const void*)gemm256_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-      attr_done = true;                                                                                    \
+    {                                                                                                      \
+      const hipError_t a_ = ensure_dynamic_lds((const void*)gemm256_kernel<E>, (int)lds);                  \
+      if (a_ != hipSuccess) return a_;                                                                     \
     }                                                                                                      \
     hipLaunchKernelGGL(gemm256_kernel<E>, grid, block, lds, stream, A, W, out, bias, M, N, K, ldc, alpha,   \
                        tiles_m, tiles_n, dbg);                                                             \

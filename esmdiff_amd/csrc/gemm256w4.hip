@@ -478,15 +478,12 @@ hipError_t launch_gemm256w4_split(const uint16_t* A2, const float* rs, const uin
   const int n_tiles = tiles_m * tiles_n;
   dim3 grid(n_tiles < n_cu ? n_tiles : n_cu), block(256);
   const size_t lds = 2 * STAGE_BYTES;
-  static bool attr_done[4][16] = {};
   // (no bias + GELU epilogue here: erff on 256 accumulators spills; the consumer LayerNorm applies the GELU on load)
 #define ED_GEMM_S(E)                                                                                                \
   do {                                                                                                              \
-    if (dev < 16 && !attr_done[E][dev]) {                                                                           \
-      if (hipFuncSetAttribute((const void*)gemm256w4_kernel<E, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-                              (int)lds) != hipSuccess)                                                             \
-        return hipErrorInvalidValue;                                                                                \
-      attr_done[E][dev] = true;                                                                                     \
+    {                                                                                                               \
+      const hipError_t a_ = ensure_dynamic_lds((const void*)gemm256w4_kernel<E, 1>, (int)lds);                      \
+      if (a_ != hipSuccess) return a_;                                                                              \
     }                                                                                                               \
     hipLaunchKernelGGL((gemm256w4_kernel<E, 1>), grid, block, lds, stream, A2, W2, (void*)out, bias, M, N, 3 * K, ldc, \
                        w_scale, tiles_m, tiles_n, rs, div);                                                      \
@@ -519,10 +516,9 @@ hipError_t launch_gemm256w4_bf16(const bf16_t* A, const bf16_t* W, void* out, co
   const size_t lds = 2 * STAGE_BYTES;
 #define ED_GEMM(E)                                                                                                  \
   do {                                                                                                              \
-    static bool attr_done = false;                                                                                  \
-    if (!attr_done) {                                                                                               \
-      hipFuncSetAttribute((const void*)gemm256w4_kernel<E>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-      attr_done = true;                                                                                             \
+    {                                                                                                               \
+      const hipError_t a_ = ensure_dynamic_lds((const void*)gemm256w4_kernel<E>, (int)lds);                         \
+      if (a_ != hipSuccess) return a_;                                                                              \
     }                                                                                                               \
     hipLaunchKernelGGL(gemm256w4_kernel<E>, grid, block, lds, stream, A, W, out, bias, M, N, K, ldc, alpha, tiles_m, \
                        tiles_n);                                                                                    \

@@ -147,11 +147,7 @@ static hipError_t launch_geom_t(const T* P, const float* rot, const float* trans
   if (B <= 0 || L <= 0) return hipSuccess;
   const size_t lds = (size_t)((L + 3) & ~3) * 12 * sizeof(float);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute((const void*)geom_attention_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-    attr_done = true;
-  }
+  if (const hipError_t a_ = ensure_dynamic_lds((const void*)geom_attention_kernel<T>, 150 * 1024); a_ != hipSuccess) return a_;
   hipLaunchKernelGGL(geom_attention_kernel<T>, dim3(VH, B), dim3(64), lds, stream, P, rot, trans, fmask, w_rot, w_dist, out,
                      L, VH);
   return hipGetLastError();

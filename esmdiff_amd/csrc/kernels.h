@@ -7,14 +7,38 @@
 
 #include "../../include/esmdiff_hip.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 
 namespace ed {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: once per (kernel, device), thread-safe,
+// return code checked (a `static bool once` left a second device's launches without the attribute).
+inline hipError_t ensure_dynamic_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> done;
+  int dev = 0;
+  hipError_t s = hipGetDevice(&dev);
+  if (s != hipSuccess) return s;
+  std::lock_guard<std::mutex> g(mu);
+  auto it = done.find({fn, dev});
+  if (it != done.end() && it->second >= bytes) return hipSuccess;
+  s = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (s == hipSuccess) done[{fn, dev}] = bytes;
+  return s;
+}
 
 // ---- sampler.hip -----------------------------------------------------------------------------
 hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, float mc_t, float mc_s, int final_,
                             const float* u, int use_philox, uint64_t seed, uint64_t sample_offset, int step,
                             int B, int L, hipStream_t stream, int logits_period = 0);
+// has[b] = 1 if sample b of x [B, L] still holds a MASK token
+hipError_t launch_samples_with_mask(const int64_t* x, int B, int L, int32_t* has, hipStream_t stream);
+// gather (dst[i] = src[idx[i]]) or scatter (dst[idx[i]] = src[i]) of n token rows of L int64
+hipError_t launch_move_token_rows(const int64_t* src, int64_t* dst, const int32_t* idx, int n, int L, int gather, hipStream_t stream);
 // flag[0] (device int32) = -1 if every row of seq and x [B, L] equals row 0, else 0
 hipError_t launch_rows_identical(const int64_t* seq, const int64_t* x, int B, int L, int32_t* flag, hipStream_t stream);
 

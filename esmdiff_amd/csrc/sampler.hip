@@ -173,6 +173,38 @@ __global__ void rows_identical_kernel(const int64_t* __restrict__ seq, const int
   if (seq[L + i] != seq[l] || x[L + i] != x[l]) flag[0] = 0;
 }
 
+// has[b] = 1 if sample b still holds a MASK token, else 0: one wave per sample
+__global__ __launch_bounds__(64) void samples_with_mask_kernel(const int64_t* __restrict__ x, int L, int32_t* __restrict__ has) {
+  const int b = blockIdx.x;
+  int any = 0;
+  for (int l = threadIdx.x; l < L; l += 64) any |= x[(int64_t)b * L + l] == MASK_ID;
+  any = __any(any);
+  if (threadIdx.x == 0) has[b] = any ? 1 : 0;
+}
+
+hipError_t launch_samples_with_mask(const int64_t* x, int B, int L, int32_t* has, hipStream_t stream) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(samples_with_mask_kernel, dim3(B), dim3(64), 0, stream, x, L, has);
+  return hipGetLastError();
+}
+
+// dst[i, :] = src[idx[i], :] (gather = 1) or dst[idx[i], :] = src[i, :] (gather = 0), rows of L int64; n rows
+__global__ void move_token_rows_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ dst, const int32_t* __restrict__ idx,
+                                       int n, int L, int gather) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n * L) return;
+  const int r = (int)(i / L), l = (int)(i - (int64_t)r * L);
+  const int64_t sidx = gather ? (int64_t)idx[r] * L + l : i, didx = gather ? i : (int64_t)idx[r] * L + l;
+  dst[didx] = src[sidx];
+}
+
+hipError_t launch_move_token_rows(const int64_t* src, int64_t* dst, const int32_t* idx, int n, int L, int gather, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  const int64_t tot = (int64_t)n * L;
+  hipLaunchKernelGGL(move_token_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, src, dst, idx, n, L, gather);
+  return hipGetLastError();
+}
+
 hipError_t launch_rows_identical(const int64_t* seq, const int64_t* x, int B, int L, int32_t* flag, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(flag, 0xff, sizeof(int32_t), stream);   // all ones = true
   if (e != hipSuccess || B <= 1) return e;

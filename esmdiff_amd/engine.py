@@ -289,6 +289,11 @@ class Engine:
         bit-identical to the unshared run.  Off by default."""
         self._chk(self._lib.esmdiff_set_step0_sharing(self._h, int(bool(on))))
 
+    def set_final_skip(self, on: bool) -> None:
+        """Exact skip of the noise-removal forward (esmdiff_set_final_skip): after the last update only the samples that still
+        hold a MASK run forward T + 1 (none, almost always); ids are bit-identical to the full run.  Off by default."""
+        self._chk(self._lib.esmdiff_set_final_skip(self._h, int(bool(on))))
+
     def counters(self, reset: bool = False) -> Dict[str, int]:
         """Network forwards issued and token rows pushed through them since create / the last reset (executed work)."""
         f, r = ctypes.c_int64(0), ctypes.c_int64(0)

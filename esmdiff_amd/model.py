@@ -45,6 +45,7 @@ class MaskedDiffusionLanguageModeling:
         # bit-identical to the unshared loop (tests/test_gpu_fullwidth.py::test_step0_sharing_is_exact).  bench.py's headline
         # run builds its Engine directly and leaves it off.
         self.net.set_step0_sharing(step0_sharing)
+        self.net.set_final_skip(step0_sharing)      # the other exact shortcut: noise-removal forward only for samples with a MASK left
         self.device = self.net.device
         self._parity_gen = None      # noise="torch-cpu": ONE generator stream per run, like the reference's global RNG
         self._parity_seed = None

@@ -56,7 +56,7 @@ typedef enum { ESMDIFF_F32 = 0, ESMDIFF_BF16 = 1 } esmdiff_dtype;
 /* Arithmetic of the network (esmdiff_config.precision).
  *   BF16  the throughput path: bf16 weights and GEMM operands on the bf16 MFMA, f32 accumulation, f32 residual stream.
  *   F32   the "strict" path (csrc/strict.hip): float32 weights and activations end to end, every linear on the f32-input
- *         MFMA (bitwise an fmaf chain), correctly rounded divide / sqrt — the arithmetic the reference itself runs in
+ *         MFMA (one f32 fmaf chain per output element, in a fixed batch-independent K order), correctly rounded divide / sqrt — the arithmetic the reference itself runs in
  *         (checkpoint_utils.py:59-73 loads float32; decode at sample_esmdiff.py:40-61), ~1/12 of the bf16 throughput.
  *         It is what north_star's floating-point bars are stated against (ids equal under a fixed seed, decoded backbone
  *         within 1e-4 A) and the structure decoder's default on the Python side.  A row's result does not depend on the
@@ -169,6 +169,14 @@ int esmdiff_ddpm_sample(esmdiff_engine* eng, const int64_t* seq, int64_t* x_inou
  * esmdiff_get_counters: network forwards issued and token rows pushed through them since create / the last reset — the
  * work actually executed, for FLOP accounting (bench.py reports the shared run as a separate, labelled figure). */
 int esmdiff_set_step0_sharing(esmdiff_engine* eng, int32_t on);
+/* Exact skip of the noise-removal forward (off by default; exact).  The last of the T + 1 forwards of esmdiff_ddpm_sample only
+ * serves `x = argmax(log p)` (model.py:575-579), and for a position that is no longer MASK the re-parameterised log p is 0 at its
+ * own token and -1e6 elsewhere (model.py:530-532): a sample without a MASK comes back unchanged.  With the option on, the
+ * engine counts on the device which samples still hold a MASK after update T (one B x 4-byte read-back), skips the forward
+ * when none does, and otherwise runs it on those samples only — as a sub-batch on the same dispatch path as the whole batch
+ * (padded with complete samples when smaller), so the ids are bit-identical to the full run
+ * (tests/test_gpu_fullwidth.py::test_final_skip_is_exact).  P(a masked row stays masked at the last update) = mc_s / mc_t. */
+int esmdiff_set_final_skip(esmdiff_engine* eng, int32_t on);
 int esmdiff_get_counters(esmdiff_engine* eng, int64_t* forwards, int64_t* token_rows, int32_t reset);
 
 /* Replaces, for ONE step, the per-prompt half of esm.utils.generation.iterative_sampling_raw as the reference calls
@@ -210,7 +218,8 @@ int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias
                       int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream);
 
 /* The strict path's linear (csrc/strict.hip): out f32 [M,ldc] = epi(A f32 [M,K] (row stride lda) . W f32 [N,K]^T), every
- * product and sum in float32 on v_mfma_f32_32x32x2_f32; K % 32 == 0; columns >= n_valid are not written. */
+ * product and sum in float32 on v_mfma_f32_32x32x2_f32 (fixed, batch-independent K order per output element; not ascending k);
+ * K % 32 == 0; columns >= n_valid are not written. */
 typedef enum {
   ESMDIFF_F32EPI_STORE = 0,      /* out = acc (+ bias[N] when bias != NULL)                        */
   ESMDIFF_F32EPI_BIAS_GELU = 1,  /* out = gelu(acc + bias), exact (erf) GELU                        */

@@ -486,7 +486,9 @@ def test_step0_sharing_is_exact():
     g = torch.Generator().manual_seed(4)
     sch = ddpm_schedule(6)
     rec = {}
-    for B, L in ((24, 258), (4, 60)):
+    # (9, 258): two streams cut it 4 + 5 = 1 032 + 1 290 rows, one part on each side of the 1 152-row switch — the case ADVICE r03
+    # found (the smaller part's FFN-down used to run split-K and differ from the shared sub-batch's single pass in the last bit)
+    for B, L in ((24, 258), (9, 258), (4, 60)):
         seq = _seq(B, L, g).cuda()
         eng.set_step0_sharing(False)
         eng.counters(reset=True)
@@ -500,7 +502,8 @@ def test_step0_sharing_is_exact():
         rec[f"B{B}_L{L}"] = {"rows_full": full["token_rows"], "rows_shared": part["token_rows"]}
         if B * L >= 2 * 1152:
             assert part["token_rows"] < full["token_rows"] and (full["token_rows"] - part["token_rows"]) % L == 0
-            assert (full["token_rows"] - part["token_rows"]) // L >= B // 2      # at least half of step 0 saved
+            if B >= 16:
+                assert (full["token_rows"] - part["token_rows"]) // L >= B // 2      # at least half of step 0 saved
         else:
             assert part == full
         # rows that differ: an inpainting prior that is NOT the same for every sample -> the engine must run in full
@@ -530,3 +533,48 @@ def test_step0_sharing_is_exact():
     assert torch.equal(got, want) and eng.counters()["token_rows"] < 5 * B * L
     eng.close()
     _record("step0_sharing_rows", rec)
+
+
+def test_final_skip_is_exact():
+    """Exact skip of the noise-removal forward (esmdiff_set_final_skip): after the last update only samples
+    that still hold a MASK need forward T + 1 (a complete sample is returned unchanged by model.py:575-579).  The ids must be
+    BIT-IDENTICAL to the full run in all three situations: (a) the ordinary schedule (eps = 1e-5: no MASK survives the last
+    update, the forward is skipped entirely), (b) a schedule that leaves masks (eps = 0.3) in a batch where SOME samples are
+    complete from the start (an unmasked prior) and the others keep masks -> sub-batch forward on the same dispatch path,
+    padded, scattered back, (c) every sample keeps a mask -> the full forward runs.  Counters show the rows really executed."""
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ModelConfig(n_layers=3)
+    eng = Engine(cfg, random_init_state_dict(cfg, seed=8), max_batch=24, max_len=258)
+    g = torch.Generator().manual_seed(6)
+    rec = {}
+    for B, L in ((24, 258), (9, 258), (6, 60)):
+        seq = _seq(B, L, g).cuda()
+        full_prior = torch.randint(0, 4096, (B, L), generator=g)
+        for case, eps, n_complete in (("a", 1e-5, 0), ("b", 0.3, B - 2), ("c", 0.3, 0)):
+            sch = ddpm_schedule(4, eps=eps)
+            prior = torch.full((B, L), MASK, dtype=torch.int64)
+            prior[:n_complete] = full_prior[:n_complete]          # these samples hold no MASK at any time
+            eng.set_final_skip(False)
+            eng.counters(reset=True)
+            want = eng.ddpm_sample(seq, sch, seed=5, sample_offset=3, input_prior=prior.cuda()).cpu()
+            full = eng.counters(reset=True)
+            eng.set_final_skip(True)
+            got = eng.ddpm_sample(seq, sch, seed=5, sample_offset=3, input_prior=prior.cuda()).cpu()
+            part = eng.counters(reset=True)
+            eng.set_final_skip(False)
+            assert torch.equal(got, want), (B, L, case)
+            assert full == {"forwards": 5, "token_rows": 5 * B * L}
+            rec[f"B{B}_L{L}_{case}"] = {"rows_full": full["token_rows"], "rows_skip": part["token_rows"],
+                                        "masks_left_before_noise_removal": None}
+            if case == "a":
+                assert part == {"forwards": 4, "token_rows": 4 * B * L}, part          # nothing left to denoise: forward skipped
+                assert int((got == MASK).sum()) == 0
+            elif case == "b" and B * L >= 2 * 1152:
+                assert part["forwards"] == 5 and 4 * B * L < part["token_rows"] < 5 * B * L, part    # a sub-batch ran
+            elif case == "c":
+                assert part == full, part                                                # every sample live: full forward
+    eng.close()
+    _record("final_skip_rows", rec)

@@ -211,3 +211,40 @@ def test_g10_rmsd_after_alignment(golden_dir):
     bb = torch.as_tensor(g["src"]).reshape(5, 16, 3, 3)
     bt = torch.as_tensor(g["tgt"]).reshape(5, 16, 3, 3)
     np.testing.assert_allclose(backbone_rmsd(bb, bt).numpy()[1:], g["rmsd"][1:], rtol=1e-9)
+
+
+def test_g11_rotary_convention_vs_hf_esm(golden_dir):
+    """The oracle network's rotary (oracle/esm3_ref.py::MultiHeadAttentionRef._rope, rotate_half) against Hugging Face's port of
+    the ESM family's rotary (transformers modeling_esm.apply_rotary_pos_emb; fixture by tests/golden/make_goldens_hf.py): the
+    rotate-half pairing (d with d + 32), the sign, inv_freq = 10000^(-2i/64), positions from 0.  Pins the convention, not esm."""
+    from oracle.esm3_ref import MultiHeadAttentionRef, rotate_half
+    g = np.load(golden_dir / "g11_hf_conventions.npz")
+    q, k = torch.as_tensor(g["q"]), torch.as_tensor(g["k"])               # (B, H, L, 64)
+    np.testing.assert_array_equal(rotate_half(q).numpy(), g["rotate_half_q"])
+    B, H, L, d = q.shape
+    mha = MultiHeadAttentionRef(H * d, H)
+    # _rope takes (B, L, H * d) token-major rows and returns (B, L, H, d)
+    qr, kr = mha._rope(q.transpose(1, 2).reshape(B, L, H * d), k.transpose(1, 2).reshape(B, L, H * d))
+    np.testing.assert_allclose(qr.transpose(1, 2).numpy(), g["q_rot"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(kr.transpose(1, 2).numpy(), g["k_rot"], rtol=0, atol=2e-6)
+    # the engine's host-side tables (csrc/engine.hip builds cos / sin of l * 10000^(-2i/64) per position) are the same numbers
+    np.testing.assert_allclose(g["cos"][0, :, :32], np.cos(np.arange(L)[:, None] * (1.0 / 10000.0 ** (np.arange(0, 64, 2) / 64.0))[None]),
+                               atol=1e-6)
+
+
+def test_g11_gram_schmidt_frames_vs_openfold(golden_dir):
+    """Backbone frames (esmdiff_amd/geometry.py, oracle/geom_ref.py) against OpenFold's Rigid.from_3_points(C, CA, N) as shipped in
+    transformers (AlphaFold-2 algorithm 21): first axis CA - C, second in the plane of N, third = first x second (right-handed),
+    axes are the COLUMNS of the rotation, origin CA."""
+    from esmdiff_amd.geometry import build_affine3d_from_coordinates
+    from oracle.geom_ref import frames_from_backbone
+    g = np.load(golden_dir / "g11_hf_conventions.npz")
+    n, ca, c = (torch.as_tensor(g[k]) for k in ("n", "ca", "c"))
+    rot_o, trans_o = frames_from_backbone(n, ca, c)
+    np.testing.assert_allclose(rot_o.numpy(), g["rot"], atol=2e-6)
+    np.testing.assert_allclose(trans_o.numpy(), g["trans"], atol=0)
+    rot, trans, has = build_affine3d_from_coordinates(torch.stack([n, ca, c], dim=-2))
+    assert bool(has.all())
+    np.testing.assert_allclose(rot.numpy(), g["rot"], atol=2e-6)
+    np.testing.assert_allclose(trans.numpy(), g["trans"], atol=0)
+    assert np.allclose(np.linalg.det(g["rot"]), 1.0, atol=1e-5)              # proper rotations
