@@ -336,7 +336,7 @@ def main():
     ap.add_argument("--stub-engine", action="store_true",
                     help="CI only: a CPU stand-in engine (tests/standin_engine.py) over the gloo backend — exercises the launch, "
                          "process-group, gather and reporting path of this script without a GPU; prints data=debug-stub-engine")
-    ap.add_argument("--precision", choices=["bf16", "f32", "f32_split"], default="bf16",
+    ap.add_argument("--precision", choices=["bf16", "f16", "f32", "f32_split"], default="bf16",
                     help="engine arithmetic; the headline metric is quoted at bf16 (BASELINE configs[1]); f32 / f32_split are the "
                          "float32-grade paths whose ids equal the float32 chain's")
     ap.add_argument("--head-precision", choices=["bf16", "f32"], default="bf16",
@@ -535,32 +535,39 @@ def main():
                               "one sub-batch forward serves them all; esmdiff_set_final_skip — the noise-removal forward runs only for "
                               "samples that still hold a MASK (none, almost always).  NOT the headline value"}
 
-    # Third, LABELLED figure: the same workload on a bf16 engine whose final LayerNorm + output head run in float32 grade
-    # (esmdiff_config.head_precision = 1).  The head is 0.6 % of the FLOP and 64 % of the bf16 logit-error variance
-    # (profiles/r04_head_decomposition.json); both settings are timed in the same process, `value` stays the plain bf16 run.
-    head_rec, eng_h = None, None
+    # Further LABELLED figures (never `value`): the same workload at the other precisions of the 16-bit throughput path, each
+    # timed in this process next to a fresh run of the headline engine (A/B inside one thermal state):
+    #   head_f32      final LayerNorm + output head in float32 grade (esmdiff_config.head_precision = 1): the head is 0.6 % of the
+    #                 FLOP and 64 % of the bf16 logit-error variance (profiles/r04_head_decomposition.json)
+    #   f16           IEEE-half operands instead of bfloat16 on the f16 forms of the same MFMA instructions (csrc/ed_half.h):
+    #                 same rate, same bytes, 1/8 of the operand rounding
+    #   f16_head_f32  both
+    # Their logit errors against the oracle are parity_spot_<name>; the id-level figures (flips per draw against the float32
+    # chain at configs[1]'s full size) are measured by tests/test_gpu_strict.py and recorded in profiles/r04_parity_strict.json.
+    alt_recs, alt_engines = {}, {}
     if world == 1 and not stub and args.precision == "bf16" and args.head_precision == "bf16" and not args.no_head_f32_leg:
         from esmdiff_amd.engine import Engine
-        eng_h = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank, head_precision="f32")
-        one_step(1000, engine=eng_h)
-        sync_local()
-        ks = max(2, min(args.steps, 5))
-        th0 = time.perf_counter()
-        for k in range(ks):
-            one_step(k, engine=eng_h)
-        sync_local()
-        th1 = time.perf_counter()
-        # and the plain engine again right after it, same steps: the A/B inside one thermal state
-        tb0 = time.perf_counter()
-        for k in range(ks):
-            one_step(k)
-        sync_local()
-        tb1 = time.perf_counter()
-        head_rec = {"value": round(B * ks / (th1 - th0), 3), "unit": "samples/s", "steps": ks,
-                    "bf16_head_same_session": round(B * ks / (tb1 - tb0), 3),
-                    "cost_frac": round((th1 - th0) / (tb1 - tb0) - 1.0, 4),
-                    "what": "same workload, head_precision = f32 (final LayerNorm + Linear/GELU/LayerNorm/Linear head as three f16 MFMA "
-                            "passes over split rows, f32 LayerNorms); NOT the headline value; parity_spot_f32_head is its logit error"}
+        ks = max(2, min(args.steps, 3))
+
+        def timed(engine):
+            sync_local()
+            ta = time.perf_counter()
+            for k in range(ks):
+                one_step(k, engine=engine)
+            sync_local()
+            return time.perf_counter() - ta
+
+        for name, kw in (("head_f32", {"head_precision": "f32"}), ("f16", {"precision": "f16"}),
+                         ("f16_head_f32", {"precision": "f16", "head_precision": "f32"})):
+            e2 = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank, **kw)
+            one_step(1000, engine=e2)
+            t_alt = timed(e2)
+            t_base = timed(eng)
+            alt_engines[name] = e2
+            alt_recs[name] = {"value": round(B * ks / t_alt, 3), "unit": "samples/s", "steps": ks,
+                              "headline_engine_same_session": round(B * ks / t_base, 3),
+                              "cost_frac": round(t_alt / t_base - 1.0, 4), "engine": kw,
+                              "what": "same workload, labelled extra — NOT the headline value"}
 
     if rank == 0:
         total_samples = B * world * args.steps
@@ -573,7 +580,7 @@ def main():
             "value": round(value, 3), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "f32": "f32", "f32_split": "f16x2-split (f32 grade)"}[args.precision],
+            "dtype": {"bf16": "bf16", "f16": "f16", "f32": "f32", "f32_split": "f16x2-split (f32 grade)"}[args.precision],
             "data": "debug-stub-engine" if stub else ("synthetic" if not args.tiny else "debug-tiny-model"),
             "config": {"workload": workload_name(args, world),
                        "samples_per_gpu": B, "L_tok": L, "num_steps": T, "forwards_per_sample": n_fwd_sample, "mode": args.mode,
@@ -601,24 +608,24 @@ def main():
         else:
             out.update(roofline_report(args, cfg, B, L, n_fwd_sample, prof_dom, prof))
             out["power"] = power_rec
-            if head_rec is not None:
-                out["head_f32"] = head_rec
+            if alt_recs:
+                out["alt_precisions"] = alt_recs
             if shared_rec is not None:
                 shared_rec["flop_per_sample_executed"] = flops_forward_per_sample(L, cfg) * shared_rec["forwards_executed_per_sample"]
                 shared_rec["mfma_frac_whole_job"] = round(shared_rec["value"] * shared_rec["flop_per_sample_executed"] / (PEAK_BF16_TFLOPS * 1e12), 4)
                 out["exact_shortcuts"] = shared_rec
         if world == 1 and not args.no_cpu_baseline and not stub:
             try:
-                out["cpu_baseline"], spots = cpu_baseline(cfg, sd, L, T, {"value": eng, "f32_head": eng_h})
+                out["cpu_baseline"], spots = cpu_baseline(cfg, sd, L, T, {"value": eng, **alt_engines})
                 out["parity_spot"] = spots.get("value")
-                if spots.get("f32_head"):
-                    out["parity_spot_f32_head"] = spots["f32_head"]
+                for name in alt_engines:
+                    out["parity_spot_" + name] = spots.get(name)
             except Exception as ex:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)
     eng.close()
-    if eng_h is not None:
-        eng_h.close()
+    for e2 in alt_engines.values():
+        e2.close()
     if use_dist:
         dist.destroy_process_group()
 

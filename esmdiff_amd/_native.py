@@ -16,7 +16,7 @@ c_i64p = ctypes.POINTER(ctypes.c_int64)
 
 EPI_BF16, EPI_RESID_F32, EPI_SWIGLU_BF16, EPI_BIAS_GELU_BF16, EPI_BIAS_F32 = range(5)
 DT_F32, DT_BF16 = 0, 1
-PRECISION = {"bf16": 0, "f32": 1, "f32_split": 2}       # esmdiff_precision
+PRECISION = {"bf16": 0, "f32": 1, "f32_split": 2, "f16": 3}       # esmdiff_precision
 F32EPI_STORE, F32EPI_BIAS_GELU, F32EPI_RESID_DIV = range(3)
 SECTIONS = ["embed", "layernorm", "gemm_qkv", "qk_norm_rope", "attention", "gemm_out", "gemm_ffn_up",
             "gemm_ffn_down", "head", "sampler"]

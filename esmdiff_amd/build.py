@@ -38,6 +38,11 @@ UNITS = {
     "gibbs": ["-ffp-contract=off"],
     "metrics": ["-ffp-contract=off"],
 }
+# The MFMA kernels, the row kernels that feed them and the weight conversion are compiled a SECOND time with f16 operands
+# (csrc/ed_half.h): -DED_F16 switches the conversion / MFMA primitives, -Ded=ed16 puts that build into namespace ed16
+# (every `ed` token of those sources is the namespace name).  precision="f16" engines call the ed16 kernels.
+F16_UNITS = ["gemm", "gemm256", "gemm256w4", "attention", "norm", "geom", "convert"]
+F16_FLAGS = ["-DED_F16", "-Ded=ed16"]
 EXTRA = os.environ.get("ESMDIFF_EXTRA_CXXFLAGS", "").split()
 COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",
           "-fhip-fp32-correctly-rounded-divide-sqrt", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
@@ -67,21 +72,23 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     cc = _hipcc()
     headers = [p.stat().st_mtime for p in list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [INCLUDE / "esmdiff_hip.h"]]
 
-    def compile_one(name):
-        src, obj = CSRC / f"{name}.hip", OBJDIR / f"{name}.o"
+    def compile_one(job):
+        name, f16 = job
+        src, obj = CSRC / f"{name}.hip", OBJDIR / (f"{name}_f16.o" if f16 else f"{name}.o")
         if (not force and obj.exists() and obj.stat().st_mtime >= max([src.stat().st_mtime] + headers)):
             return name, ""
-        cmd = [cc, *COMMON, *UNITS[name], "-c", str(src), "-o", str(obj)]
+        cmd = [cc, *COMMON, *UNITS[name], *(F16_FLAGS if f16 else []), "-c", str(src), "-o", str(obj)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stderr}")
         return name, r.stderr
 
-    with ThreadPoolExecutor(max_workers=min(8, len(UNITS))) as ex:
-        for name, err in ex.map(compile_one, UNITS):
+    jobs = [(n, False) for n in UNITS] + [(n, True) for n in F16_UNITS]
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        for name, err in ex.map(compile_one, jobs):
             if verbose and err.strip():
                 print(f"[{name}] {err}", file=sys.stderr)
-    objs = [str(OBJDIR / f"{n}.o") for n in UNITS]
+    objs = [str(OBJDIR / f"{n}.o") for n in UNITS] + [str(OBJDIR / f"{n}_f16.o") for n in F16_UNITS]
     r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB)],
                        capture_output=True, text=True)
     if r.returncode != 0:

@@ -35,12 +35,13 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "ed_half.h"
 #include "kernels.h"
 
 namespace ed {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef ed_half8 bf16x8;   // the TU's 16-bit operand type (ed_half.h: bf16, or f16 in the ed16 build)
+typedef ed_half4 bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int KV_TILE = 64;
@@ -51,14 +52,7 @@ __device__ __forceinline__ void glds16a(const void* gsrc, void* lds_dst_wave_uni
                                    (__attribute__((address_space(3))) void*)lds_dst_wave_uniform, 16, 0, 0);
 }
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
-  const bf16x2 v = __builtin_convertvector(f32x2{a, b}, bf16x2);
-  uint32_t u;
-  __builtin_memcpy(&u, &v, 4);
-  return u;
-}
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) { return ed_pack2_bounded(a, b); }  // v_cvt_pk_{bf16,f16}_f32, nearest even
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // bare v_exp_f32
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;

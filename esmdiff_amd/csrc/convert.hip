@@ -1,19 +1,25 @@
 // convert.hip — weight preparation at engine create (gfx950): dtype conversion and the row interleave
 // that lets the SwiGLU epilogue of the FFN-up GEMM pair gate and up columns inside one wave's registers.
+#include "ed_half.h"
 #include "kernels.h"
 
 namespace ed {
 
-__device__ __forceinline__ uint32_t cv_f2bf(float a) {
-  uint32_t u = __float_as_uint(a);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7fc0u;  // NaN
-  return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+// f32 -> the TU's 16-bit operand type, round to nearest even (ed_half.h: bf16, or f16 — saturating — in the ed16 build)
+__device__ __forceinline__ uint32_t cv_f2bf(float a) { return ed_f2h(a); }
+// a source tensor tagged ESMDIFF_BF16 is bfloat16 in BOTH builds (the caller's dtype, not the engine's)
+__device__ __forceinline__ uint32_t cv_bf2h(bf16_t b) {
+#ifdef ED_F16
+  return ed_f2h(__uint_as_float((uint32_t)b << 16));
+#else
+  return b;
+#endif
 }
 
 __global__ void to_bf16_kernel(const void* __restrict__ src, int src_dtype, bf16_t* __restrict__ dst, int64_t n) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     dst[i] = src_dtype == ESMDIFF_F32 ? (bf16_t)cv_f2bf(reinterpret_cast<const float*>(src)[i])
-                                      : reinterpret_cast<const bf16_t*>(src)[i];
+                                      : (bf16_t)cv_bf2h(reinterpret_cast<const bf16_t*>(src)[i]);
 }
 
 __global__ void to_f32_kernel(const void* __restrict__ src, int src_dtype, float* __restrict__ dst, int64_t n) {
@@ -31,7 +37,7 @@ __global__ void interleave_swiglu_kernel(const void* __restrict__ src, int src_d
   for (int k = threadIdx.x; k < K; k += blockDim.x) {
     const int64_t si = (int64_t)srow * K + k;
     dst[(int64_t)rho * K + k] = src_dtype == ESMDIFF_F32 ? (bf16_t)cv_f2bf(reinterpret_cast<const float*>(src)[si])
-                                                         : reinterpret_cast<const bf16_t*>(src)[si];
+                                                         : (bf16_t)cv_bf2h(reinterpret_cast<const bf16_t*>(src)[si]);
   }
 }
 

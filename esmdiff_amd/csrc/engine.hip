@@ -24,6 +24,9 @@
 #include <vector>
 
 #include "kernels.h"
+#define ed ed16            // the f16 build of the same kernel sources (ed_half.h, esmdiff_amd/build.py)
+#include "kernels_ns.inc"
+#undef ed
 
 using namespace ed;
 
@@ -108,6 +111,7 @@ struct esmdiff_engine {
   // precision = ESMDIFF_PRECISION_F32_SPLIT: forward_strict with every large linear as three f16 MFMA passes over split
   // operands (gemm_split.hip); a2 / rs: the split activation rows feeding the next linear and their row scales
   bool split = false;
+  bool f16 = false;          // precision = ESMDIFF_PRECISION_F16: the bf16 engine's launch sequence on the ed16 kernels
   bool head_split = false;   // bf16 engine with esmdiff_config.head_precision = 1: final LayerNorm + head on the split kernels
   SplitW s_head0, s_head3, s_pl0, s_pl3, s_gproj, s_gout;
   uint16_t* a2 = nullptr;
@@ -219,7 +223,7 @@ int load_bf16(esmdiff_engine* e, const Table& t, const std::string& name, std::i
   int64_t rows = w->shape[0], cols = n / rows;
   int64_t rows_p = pad_rows_to > rows ? pad_rows_to : rows;
   if (int r = dalloc(e, dst, (size_t)(rows_p * cols), rows_p != rows)) return r;
-  HIP_TRY(e, launch_to_bf16(w->data, w->dtype, *dst, n, 0));
+  HIP_TRY(e, e->f16 ? ed16::launch_to_bf16(w->data, w->dtype, *dst, n, 0) : ed::launch_to_bf16(w->data, w->dtype, *dst, n, 0));   // the engine's 16-bit type
   return 0;
 }
 
@@ -450,6 +454,17 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
   return 0;
 }
 
+#define KN ed
+#define ED_FWD_NAME forward_bf16
+#include "engine_forward.inc"
+#undef KN
+#undef ED_FWD_NAME
+#define KN ed16
+#define ED_FWD_NAME forward_f16
+#include "engine_forward.inc"
+#undef KN
+#undef ED_FWD_NAME
+
 // The whole network: tokens -> f32 logits [M, ld].
 //
 // Samples are independent, so a large batch is run as two sub-batches on two HIP streams (the caller's and one
@@ -479,149 +494,7 @@ int forward(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const fl
     e->stat_rows += (int64_t)B * L;
     return forward_strict(e, seq, xtok, t_freq_dev, logits, ld, B, L, st);
   }
-  const esmdiff_config& c = e->cfg;
-  const int D = c.d_model, H = c.n_heads, FH = c.ffn_hidden;
-  const float inv_scale = 1.0f / c.residue_scale;
-  Prof p{e, st};
-#define RUN(section, call)   \
-  do {                       \
-    p.mark(section);         \
-    HIP_TRY(e, (call));      \
-    p.mark(section);         \
-  } while (0)
-
-  const float* cond = nullptr;
-  // sigma_embedder runs whenever its weights were loaded and the caller hands a sinusoid: with time conditioning off the
-  // reference still adds sigma_embedder(0) (model.py:466-471 with _process_sigma zeroing sigma, :535-541), and the
-  // host passes the sinusoid of 0 for that case
-  if (t_freq_dev && e->sig_w1) {
-    RUN(S_EMBED, launch_sigma_mlp(t_freq_dev, e->sig_w1, e->sig_b1, e->sig_w2, e->sig_b2, e->sig_hidden, e->cond,
-                                  c.freq_dim, D, st));
-    cond = e->cond;
-  }
-  // profiling == 1 (per-section breakdown) keeps one stream so that the sections do not overlap
-  Part parts[4];
-  const int np = plan_parts(e, B, L);
-  e->stat_forwards += 1;
-  e->stat_rows += (int64_t)B * L;
-  for (int pi = 0; pi < np; ++pi) {
-    const int b0 = (int)((int64_t)B * pi / np), b1 = (int)((int64_t)B * (pi + 1) / np);
-    parts[pi] = make_part(e, seq, xtok, logits, ld, b0, b1 - b0, L, pi == 0 ? st : e->side[pi - 1], pi);
-  }
-  if (np > 1) {
-    HIP_TRY(e, hipEventRecord(e->ev_fork, st));
-    for (int pi = 1; pi < np; ++pi) {
-      HIP_TRY(e, hipStreamWaitEvent(e->side[pi - 1], e->ev_fork, 0));
-      HIP_TRY(e, launch_delay_us(e->stream_offset_us * pi, e->side[pi - 1]));
-    }
-  }
-#define EACH(section, expr)                  \
-  do {                                       \
-    for (int pi = 0; pi < np; ++pi) {        \
-      const Part& w = parts[pi];             \
-      const int M = w.B * L;                 \
-      (void)M;                               \
-      p.s = w.st;                            \
-      RUN(section, expr);                    \
-    }                                        \
-  } while (0)
-
-  if (e->kind == 1) {
-    EACH(S_EMBED, launch_gather_rows(w.xtok, e->e_struct, w.x, M, D, ESMDIFF_VOCAB, w.st));
-  } else {
-    EACH(S_EMBED, launch_embed(w.seq, w.xtok, e->e_seq, e->e_struct, e->cvec, cond, w.x, w.B, L, D, w.st));
-  }
-  // The residual stream x stays f32.  Each branch GEMM (out-proj -> dlt2, FFN-down -> dlt) writes its output, already
-  // divided by the residue scale, as a bf16 delta; the LayerNorm kernels add the deltas while they read x anyway, so no
-  // GEMM epilogue does a read-modify-write.  x is written back once per block: the attention-side LayerNorm only
-  // forms x + dF(previous block) in registers, the FFN-side one forms (x + dF) + dA — the same two f32 additions in the
-  // same order as adding them one LayerNorm apart — and stores it.
-  const bool geom = e->has_geom && e->frames_B > 0;
-  if (geom && (e->frames_B != B || e->frames_L != L))
-    return fail(e, ESMDIFF_E_INVALID, "frames were set for B=%d L=%d, forward called with B=%d L=%d", e->frames_B, e->frames_L, B, L);
-  const int VH = e->v_heads;
-  bool pending = false;
-  // Small batches (a sub-batch of < 1 152 rows, ed::small_max_rows()): the two branch linears leave their products as raw f32 K-slice planes
-  // (gemm.hip: launch_gemm_partials) and the LayerNorm that follows sums the planes into x — x += dF before the
-  // attention-side LayerNorm, x += dA before the FFN-side one: the same two additions in the same order — so neither a
-  // split-K reduce pass nor a bf16 delta round trip runs.  Sub-batches of one forward are all on the same side of the
-  // switch or results would depend on how the batch was cut; parts differ by at most one sample, so test part 0's rows.
-  const bool small = plan_small(e, B, L);
-  ed::GemmPartials PF[4] = {}, PA[4] = {};
-  for (int i = 0; i < c.n_layers; ++i) {
-    const Layer& ly = e->layers[i];
-    if (small) {
-      if (pending) EACH(S_LN, launch_add_partials_layernorm_bf16(w.x, PF[pi], D, inv_scale, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
-      else EACH(S_LN, launch_add_layernorm_bf16(w.x, nullptr, nullptr, 0, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
-    } else if (!(e->debug_skip & 4) || i == 0) {
-      EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, ly.ln1_w, ly.ln1_b, w.h, M, D, w.st));
-    }
-    EACH(S_QKV, launch_gemm_bf16(w.h, ly.w_qkv, w.qkv, nullptr, M, 3 * D, D, 3 * D, 3 * D, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
-    if (!(e->debug_skip & 1) || i == 0) EACH(S_QKROPE, launch_qk_norm_rope(w.qkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.q, w.k, w.B, L, H, w.st));
-    if (!(e->debug_skip & 2) || i == 0) EACH(S_ATTN, launch_attention(w.q, w.k, w.qkv, w.ctx, w.B, L, H, w.st));
-    if (small) EACH(S_OUT, launch_gemm_partials(w.ctx, ly.w_out, w.gws2, M, D, D, w.st, &PA[pi]));
-    else EACH(S_OUT, launch_gemm_bf16(w.ctx, ly.w_out, w.dlt2, nullptr, M, D, D, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
-    const bool geom_here = i == 0 && geom;
-    if (geom_here) {
-      // x += dA; s = s_norm(x); p = proj(s); geometric attention; dG = out_proj(.) / scale  (block 0 only; the FFN-side
-      // LayerNorm below then adds dG instead of dA)
-      if (small) EACH(S_LN, launch_add_partials_layernorm_bf16(w.x, PA[pi], D, inv_scale, e->g_snorm_w, nullptr, w.h, M, D, w.st));
-      else EACH(S_LN, launch_add_layernorm_bf16(w.x, nullptr, w.dlt2, 1, e->g_snorm_w, nullptr, w.h, M, D, w.st));
-      EACH(S_ATTN, launch_gemm_bf16(w.h, e->g_proj, w.gp, nullptr, M, 15 * VH, D, 15 * VH, 15 * VH, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
-      EACH(S_ATTN, launch_geom_attention(w.gp, w.f_rot, w.f_trans, w.f_mask, e->g_wrot, e->g_wdist, w.gctx, w.B, L, VH, w.st));
-      EACH(S_ATTN, launch_gemm_bf16(w.gctx, e->g_out, w.dlt2, nullptr, M, D, 3 * VH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, w.gws));
-    }
-    if (small && !geom_here) {
-      EACH(S_LN, launch_add_partials_layernorm_bf16(w.x, PA[pi], D, inv_scale, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
-    } else if (small) {  // x already holds x + dF + dA; the geometric branch came back as a bf16 delta
-      EACH(S_LN, launch_add_layernorm_bf16(w.x, nullptr, w.dlt2, 1, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
-    } else if (!(e->debug_skip & 8) || i == 0) {
-      EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, w.dlt2, 1, ly.ln2_w, ly.ln2_b, w.h, M, D, w.st));
-    }
-    EACH(S_FFN_UP, launch_gemm_bf16(w.h, ly.w_up, w.mid, nullptr, M, 2 * FH, D, FH, FH, 1.f, ESMDIFF_EPI_SWIGLU_BF16, w.st, w.gws));
-    if (small) EACH(S_FFN_DOWN, launch_gemm_partials(w.mid, ly.w_down, w.gws, M, D, FH, w.st, &PF[pi]));
-    // (no split-K workspace here: on the regular path a row's K order must not depend on how many rows its sub-batch has —
-    //  with the workspace a part below 1 152 rows next to a larger one, e.g. B = 9 at L_tok = 258 cut 4 + 5, summed its FFN-down
-    //  in 8 slices and the other part in one pass, and step-0 sharing / batch composition changed the last bit: ADVICE r03)
-    else EACH(S_FFN_DOWN, launch_gemm_bf16(w.mid, ly.w_down, w.dlt, nullptr, M, D, FH, D, D, inv_scale, ESMDIFF_EPI_BF16, w.st, nullptr));
-    pending = true;
-  }
-  e->last_pending_delta = !small && pending;
-  if (e->head_split) {
-    // f32-grade head on the bf16 body (esmdiff_config.head_precision = 1): final LayerNorm of the f32 residual stream (plus
-    // the last FFN-down delta, which the regular path keeps outside x) -> Linear + bias -> GELU -> LayerNorm -> Linear + bias,
-    // LayerNorms in the strict path's arithmetic, linears as three f16 MFMA passes over split rows (gemm_split.hip)
-    if (small && pending) EACH(S_LN, launch_add_partials_layernorm_bf16(w.x, PF[pi], D, inv_scale, e->final_ln_w, nullptr, w.h, M, D, w.st));  // x += dF
-    EACH(S_LN, launch_layernorm_split(w.x, e->final_ln_w, nullptr, w.a2, w.rs, nullptr, M, D, 0, w.st,
-                                      (!small && pending) ? w.dlt : nullptr));
-    EACH(S_HEAD, launch_gemm256w4_split(w.a2, w.rs, e->s_head0.w, e->s_head0.inv, w.fh2, e->head_b0, M, D, D, D, 1.f, ESMDIFF_F32EPI_STORE, w.st));
-    EACH(S_LN, launch_layernorm_split(w.fh2, e->head_ln_w, e->head_ln_b, w.a2, w.rs, nullptr, M, D, 1, w.st));
-    EACH(S_HEAD, launch_gemm256w4_split(w.a2, w.rs, e->s_head3.w, e->s_head3.inv, w.logits, e->head_b3, M, e->vocab_pad, D, ld, 1.f, ESMDIFF_F32EPI_STORE, w.st));
-    for (int pi = 1; pi < np; ++pi) {
-      HIP_TRY(e, hipEventRecord(e->ev_join[pi - 1], e->side[pi - 1]));
-      HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[pi - 1], 0));
-    }
-    return 0;
-  }
-  if (small && pending) EACH(S_LN, launch_add_partials_layernorm_bf16(w.x, PF[pi], D, inv_scale, e->final_ln_w, nullptr, w.h, M, D, w.st));
-  else EACH(S_LN, launch_add_layernorm_bf16(w.x, pending ? w.dlt : nullptr, nullptr, 0, e->final_ln_w, nullptr, w.h, M, D, w.st));
-  EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w0, w.h2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, w.st, w.gws));
-  // decoder: the pLDDT head reads the same normalised hidden state (w.h) before the structure head's LayerNorm reuses it;
-  // its intermediates live in ctx / q, which are free after the last block
-  if (e->has_plddt) EACH(S_HEAD, launch_gemm_bf16(w.h, e->pl_w0, w.ctx, e->pl_b0, M, D, D, D, D, 1.f, ESMDIFF_EPI_BIAS_GELU_BF16, w.st, w.gws));
-  // ... and so does the pairwise head's down-projection (q | k, 64 + 64 columns per token)
-  if (e->has_pair) EACH(S_HEAD, launch_gemm_bf16(w.h, e->pw_down, e->pair_qk + (w.h - e->h) / D * 128, nullptr, M, 128, D, 128, 128, 1.f, ESMDIFF_EPI_BF16, w.st, w.gws));
-  EACH(S_LN, launch_layernorm_bf16_in(w.h2, e->head_ln_w, e->head_ln_b, w.h, M, D, w.st));
-  if (e->has_plddt) EACH(S_LN, launch_layernorm_bf16_in(w.ctx, e->pl_ln_w, e->pl_ln_b, w.q, M, D, w.st));
-  EACH(S_HEAD, launch_gemm_bf16(w.h, e->head_w3, w.logits, e->head_b3, M, e->vocab_pad, D, ld, c.vocab_out, 1.f, ESMDIFF_EPI_BIAS_F32, w.st, w.gws));
-  if (e->has_plddt) EACH(S_HEAD, launch_gemm_bf16(w.q, e->pl_w3, w.pl_logits, e->pl_b3, M, 128, D, e->ld_plddt, e->plddt_bins, 1.f, ESMDIFF_EPI_BIAS_F32, w.st, w.gws));
-  for (int pi = 1; pi < np; ++pi) {
-    HIP_TRY(e, hipEventRecord(e->ev_join[pi - 1], e->side[pi - 1]));
-    HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[pi - 1], 0));
-  }
-#undef EACH
-#undef RUN
-  return 0;
+  return e->f16 ? forward_f16(e, seq, xtok, t_freq_dev, logits, ld, B, L, st) : forward_bf16(e, seq, xtok, t_freq_dev, logits, ld, B, L, st);
 }
 
 // Step-0 sharing (esmdiff_set_step0_sharing).  Returns in *shared the number of leading samples whose forward serves the
@@ -723,14 +596,17 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       (kind == 0 && (V < ESMDIFF_MASK_ID || V > 5120 || F <= 0)) || (kind == 1 && V != 23))
     return fail(nullptr, ESMDIFF_E_INVALID, "invalid configuration");
 
-  if (cfg->precision != ESMDIFF_PRECISION_BF16 && cfg->precision != ESMDIFF_PRECISION_F32 && cfg->precision != ESMDIFF_PRECISION_F32_SPLIT)
-    return fail(nullptr, ESMDIFF_E_INVALID, "precision %d: expected ESMDIFF_PRECISION_BF16 (0), ESMDIFF_PRECISION_F32 (1) or ESMDIFF_PRECISION_F32_SPLIT (2)", cfg->precision);
+  if (cfg->precision < ESMDIFF_PRECISION_BF16 || cfg->precision > ESMDIFF_PRECISION_F16)
+    return fail(nullptr, ESMDIFF_E_INVALID, "precision %d: expected ESMDIFF_PRECISION_BF16 (0), _F32 (1), _F32_SPLIT (2) or _F16 (3)", cfg->precision);
+  if (cfg->precision == ESMDIFF_PRECISION_F16 && kind != 0)
+    return fail(nullptr, ESMDIFF_E_INVALID, "the structure decoder runs in bf16, f32 or f32_split (its pairwise head has no f16 build)");
   esmdiff_engine* e = new esmdiff_engine;
   e->cfg = *cfg;
   e->kind = kind;
   e->device = device;
-  e->strict = cfg->precision != ESMDIFF_PRECISION_BF16;
+  e->strict = cfg->precision == ESMDIFF_PRECISION_F32 || cfg->precision == ESMDIFF_PRECISION_F32_SPLIT;
   e->split = cfg->precision == ESMDIFF_PRECISION_F32_SPLIT;
+  e->f16 = cfg->precision == ESMDIFF_PRECISION_F16;
   e->head_split = !e->strict && kind == 0 && cfg->head_precision == 1;
   if (cfg->head_precision != 0 && cfg->head_precision != 1)
     return (delete e, fail(nullptr, ESMDIFF_E_INVALID, "head_precision %d: 0 (as precision) or 1 (float32 grade)", cfg->head_precision));
@@ -788,7 +664,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       const esmdiff_weight* w;
       TRY(need(e, t, b + "ffn.1.weight", {2 * FH, D}, &w));
       TRY(dalloc(e, &ly.w_up, (size_t)2 * FH * D));
-      if (launch_interleave_swiglu(w->data, w->dtype, ly.w_up, FH, D, 0) != hipSuccess)
+      if ((e->f16 ? ed16::launch_interleave_swiglu(w->data, w->dtype, ly.w_up, FH, D, 0) : ed::launch_interleave_swiglu(w->data, w->dtype, ly.w_up, FH, D, 0)) != hipSuccess)
         return bail(fail(e, ESMDIFF_E_HIP, "interleave_swiglu launch failed"));
       TRY(load_bf16(e, t, b + "ffn.3.weight", {D, FH}, &ly.w_down));
     }
@@ -1157,7 +1033,8 @@ int esmdiff_get_embeddings(esmdiff_engine* e, float* out, int32_t B, int32_t L, 
   // regular bf16 path: the last block's FFN-down delta is added by the final add+LayerNorm in registers; add it here the
   // same way (out = out + dF, one f32 addition per element; the normalised row goes to a scratch buffer nobody reads)
   if (e->last_pending_delta)
-    HIP_TRY(e, launch_add_layernorm_bf16(out, e->dlt, nullptr, 1, e->final_ln_w, nullptr, e->q, (int)M, (int)D, st));
+    HIP_TRY(e, e->f16 ? ed16::launch_add_layernorm_bf16(out, e->dlt, nullptr, 1, e->final_ln_w, nullptr, e->q, (int)M, (int)D, st)
+                      : ed::launch_add_layernorm_bf16(out, e->dlt, nullptr, 1, e->final_ln_w, nullptr, e->q, (int)M, (int)D, st));
   return 0;
 }
 
@@ -1436,7 +1313,7 @@ int esmdiff_attention_bf16(esmdiff_engine* e, const void* qkv, const float* q_ln
                            int32_t B, int32_t L, void* stream) {
   if (!e) return ESMDIFF_E_INVALID;
   if (!qkv || !q_ln_w || !k_ln_w || !ctx) return fail(e, ESMDIFF_E_INVALID, "null pointer");
-  if (e->strict) return fail(e, ESMDIFF_E_INVALID, "esmdiff_attention_bf16 on a float32 (strict) engine: it has no bf16 workspace");
+  if (e->strict || e->f16) return fail(e, ESMDIFF_E_INVALID, "esmdiff_attention_bf16 needs a bf16 engine (this one is float32 or f16)");
   if (int r = check_bl(e, B, L)) return r;
   HIP_TRY(e, launch_qk_norm_rope((const bf16_t*)qkv, q_ln_w, k_ln_w, e->rope_cos, e->rope_sin, e->q, e->k, B, L,
                                  e->cfg.n_heads, (hipStream_t)stream));

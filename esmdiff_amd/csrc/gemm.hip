@@ -34,11 +34,12 @@
 //            release/acquire costs an L2 write-back/invalidate per workgroup on this multi-XCD part.)
 #include <stdlib.h>
 
+#include "ed_half.h"
 #include "kernels.h"
 
 namespace ed {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef ed_half8 bf16x8;   // 8 operand elements of the TU's 16-bit type (ed_half.h: bf16, or f16 in the ed16 build)
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -64,14 +65,7 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 __device__ __forceinline__ float silu_mul(float g, float u) {
   return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896341f)) * u;
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // v_cvt_pk_bf16_f32, round to nearest even
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-  const bf16x2_t v = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
-  uint32_t u;
-  __builtin_memcpy(&u, &v, 4);
-  return u;
-}
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) { return ed_pack2(a, b); }   // the TU's 16-bit type (ed_half.h)
 
 // MI = 32-row blocks per wave: 2 -> 128-row tiles (waves 2x2 of 64x64), 1 -> 64-row tiles (waves 2x2 of 32x64) for the
 // small-M path, where the 128-row grid leaves most CUs idle.  The per-element K order is the same, so the tile height
@@ -165,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const bf16_t* __restr
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = ED_MFMA_32x32x16(a[i], b[j], acc[i][j]);
     }
   };
   if constexpr (NST == 2) {

@@ -33,11 +33,12 @@
 
 #include <type_traits>
 
+#include "ed_half.h"
 #include "kernels.h"
 
 namespace ed {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef ed_half8 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -57,14 +58,7 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 __device__ __forceinline__ float silu_mul(float g, float u) {
   return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896341f)) * u;
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // v_cvt_pk_bf16_f32, round to nearest even
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-  const bf16x2_t v = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
-  uint32_t u;
-  __builtin_memcpy(&u, &v, 4);
-  return u;
-}
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) { return ed_pack2(a, b); }   // the TU's 16-bit type (ed_half.h)
 #define ED_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
 // Ablation builds: -DED_ABL=<bits> compiles parts of the kernel out (results are then wrong by construction; only the
 // times mean something).  Bits: 1 no fragment reads, 2 no LDS-DMA in the main loop, 4 no stores, 8 no vmcnt wait, 16 no
@@ -254,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const bf16_t* __restric
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int f = 0; f < 2; ++f)
-        acc[mh][f][nh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[f][j], acc[mh][f][nh], 0, 0, 0);  // C^T: see epilogue
+        acc[mh][f][nh] = ED_MFMA_32x32x16(b[j], a[f][j], acc[mh][f][nh]);  // C^T: see epilogue
     __builtin_amdgcn_s_setprio(0);
     ED_PHASE_FENCE();
   };

@@ -25,11 +25,12 @@
 
 #include <type_traits>
 
+#include "ed_half.h"
 #include "kernels.h"
 
 namespace ed {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef ed_half8 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -91,14 +92,7 @@ __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + e
 __device__ __forceinline__ float silu_mul(float g, float u) {
   return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896341f)) * u;
 }
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {  // v_cvt_pk_bf16_f32, round to nearest even
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-  const bf16x2_t v = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
-  uint32_t u;
-  __builtin_memcpy(&u, &v, 4);
-  return u;
-}
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) { return ed_pack2(a, b); }   // the TU's 16-bit type (ed_half.h)
 
 // SPLIT = 1 (gemm_split.hip's launcher, the float32-grade "split" linears of the strict path): the operands are f16 plane
 // triples per row — A [M, 3K1] = [hi | lo | hi], W [N, 3K1] = [lo | hi | hi] with x ~ hi + lo to 2^-22 — so that ONE linear
@@ -213,14 +207,14 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16_t* __restr
   do {                                                                                                \
     if (W4_ABL(4)) asm volatile("" : "+a"(acc_) : "v"(b_), "v"(a_));                                  \
     else if constexpr (SPLIT) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc_) : "v"(b_), "v"(a_)); \
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc_) : "v"(b_), "v"(a_));     \
+    else asm volatile(ED_MFMA_32x32x16_ASM " %0, %1, %2, %0" : "+a"(acc_) : "v"(b_), "v"(a_));        \
   } while (0)
 // first k-step of a tile: D = B x A + 0 (no zeroing pass over the 256 accumulator registers)
 #define W4_MFMA0(acc_, b_, a_)                                                                        \
   do {                                                                                                \
     if (W4_ABL(4)) asm volatile("" : "=a"(acc_) : "v"(b_), "v"(a_));                                  \
     else if constexpr (SPLIT) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(acc_) : "v"(b_), "v"(a_)); \
-    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(acc_) : "v"(b_), "v"(a_));      \
+    else asm volatile(ED_MFMA_32x32x16_ASM " %0, %1, %2, 0" : "=a"(acc_) : "v"(b_), "v"(a_));         \
   } while (0)
 #define W4_WAIT_LGKM0(s_)                                                                                          \
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                              \

@@ -100,7 +100,7 @@ template <int NV, bool GELU_IN>
 __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ b, uint16_t* __restrict__ dst,
                                                               float* __restrict__ rs, float* __restrict__ y32, int M, int D,
-                                                              const uint16_t* __restrict__ delta) {
+                                                              const uint16_t* __restrict__ delta, int delta_is_f16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -113,10 +113,16 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
       v[j] = *reinterpret_cast<const f32x4*>(x + (int64_t)row * D + c);
       if (delta) {   // bf16 engine with an f32-grade head: the last FFN-down delta is still outside x (one f32 add per element)
         const uint2 dd = *reinterpret_cast<const uint2*>(delta + (int64_t)row * D + c);
-        v[j][0] += __uint_as_float(dd.x << 16);
-        v[j][1] += __uint_as_float(dd.x & 0xffff0000u);
-        v[j][2] += __uint_as_float(dd.y << 16);
-        v[j][3] += __uint_as_float(dd.y & 0xffff0000u);
+        if (delta_is_f16) {   // the f16 engine's deltas
+          const f16x4 hv = *reinterpret_cast<const f16x4*>(&dd);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] += (float)hv[e];
+        } else {
+          v[j][0] += __uint_as_float(dd.x << 16);
+          v[j][1] += __uint_as_float(dd.x & 0xffff0000u);
+          v[j][2] += __uint_as_float(dd.y << 16);
+          v[j][3] += __uint_as_float(dd.y & 0xffff0000u);
+        }
       }
       if constexpr (GELU_IN) {
 #pragma unroll
@@ -263,15 +269,15 @@ hipError_t launch_split_rows(const float* src, int ld, uint16_t* dst, float* rs,
 }
 
 hipError_t launch_layernorm_split(const float* x, const float* w, const float* b, uint16_t* dst, float* rs, float* y32,
-                                  int M, int D, int gelu_in, hipStream_t stream, const uint16_t* delta) {
+                                  int M, int D, int gelu_in, hipStream_t stream, const uint16_t* delta, int delta_is_f16) {
   if (M <= 0) return hipSuccess;
   if (D % 4 != 0 || D > 2048) return hipErrorInvalidValue;
   const int nv = (D + 255) / 256;
   dim3 grid((M + 3) / 4), block(256);
 #define ED_LN(N)                                                                                                       \
   do {                                                                                                                 \
-    if (gelu_in) hipLaunchKernelGGL((layernorm_split_kernel<N, true>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta);  \
-    else hipLaunchKernelGGL((layernorm_split_kernel<N, false>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta);         \
+    if (gelu_in) hipLaunchKernelGGL((layernorm_split_kernel<N, true>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta, delta_is_f16);  \
+    else hipLaunchKernelGGL((layernorm_split_kernel<N, false>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta, delta_is_f16);  \
   } while (0)
   switch (nv) {
     case 1: ED_LN(1); break;

@@ -16,11 +16,12 @@
 // lane owns a query and walks the keys with an online softmax (all lanes read the same key: LDS broadcast, no bank
 // conflicts).  Head dimension 3 leaves nothing for MFMA; the kernel is VALU-bound at ~25 ops per (query, key)
 // pair: 1.7e9 pairs per forward at config 2, i.e. about one millisecond, and only when coordinates are given.
+#include "ed_half.h"
 #include "kernels.h"
 
 namespace ed {
 
-__device__ __forceinline__ float gbf(const bf16_t* p) { return __uint_as_float((uint32_t)(*p) << 16); }
+__device__ __forceinline__ float gbf(const bf16_t* p) { return ed_h2f(*p); }   // the TU's 16-bit type (ed_half.h)
 __device__ __forceinline__ float gbf(const float* p) { return *p; }
 
 // T = bf16_t: the throughput path (bare v_sqrt_f32 / v_exp_f32, softmax in base 2).  T = float: the strict path
@@ -132,10 +133,7 @@ __global__ __launch_bounds__(64) void geom_attention_kernel(const T* __restrict_
     if constexpr (STRICT) {
       dst[0] = r0; dst[1] = r1; dst[2] = r2;
     } else {
-      auto f2b = [](float f) {
-        uint32_t u = __float_as_uint(f);
-        return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-      };
+      auto f2b = [](float f) { return (bf16_t)ed_f2h(f); };   // round to nearest even
       dst[0] = f2b(r0); dst[1] = f2b(r1); dst[2] = f2b(r2);
     }
   }

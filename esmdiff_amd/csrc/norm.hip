@@ -9,6 +9,7 @@
 //                         (rotate-half, base 10000) per 64-wide head, q pre-scaled by log2(e)/sqrt(64);
 //                         writes token-major q,k [M, D] (same row layout as qkv, contiguous 1 KiB stores)
 //                         (v is not touched: attention.hip reads it in place and transposes in its LDS reads)
+#include "ed_half.h"
 #include "kernels.h"
 
 namespace ed {
@@ -20,15 +21,9 @@ __device__ __forceinline__ float wsum(float v) {
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
-__device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
-__device__ __forceinline__ uint32_t pack2(float a, float b) {  // v_cvt_pk_bf16_f32, round to nearest even
-  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-  typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-  const bf16x2_t v = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t);
-  uint32_t u;
-  __builtin_memcpy(&u, &v, 4);
-  return u;
-}
+// 16-bit operand conversions of this TU (ed_half.h: bf16, or f16 in the ed16 build)
+__device__ __forceinline__ float bf2f(uint32_t h) { return ed_h2f(h); }
+__device__ __forceinline__ uint32_t pack2(float a, float b) { return ed_pack2(a, b); }
 
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: NV = ceil(D / 256) float4 per lane; D % 4 == 0.

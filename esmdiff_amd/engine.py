@@ -41,15 +41,16 @@ class Engine:
         """precision: "bf16" (the throughput path: bf16 MFMA, f32 accumulate and residual stream), "f32" (the strict
         path, csrc/strict.hip: float32 weights and activations on the f32-input MFMA — the reference's own arithmetic,
         checkpoint_utils.py:59-73; ~1/12 of the throughput; the referee) or "f32_split" (the strict path with every large
-        linear as three f16 MFMA passes over split operands, csrc/gemm_split.hip: float32-grade, ~1/4 of the bf16 throughput).
-        head_precision="f32" (bf16 engines only): final LayerNorm + output head in float32 grade on the split kernels."""
+        linear as three f16 MFMA passes over split operands, csrc/gemm_split.hip: float32-grade, ~1/4 of the bf16 throughput) or
+        "f16" (the bf16 path's kernels compiled with IEEE-half operands, csrc/ed_half.h: same speed, 1/8 of the operand rounding).
+        head_precision="f32" (bf16 / f16 engines): final LayerNorm + output head in float32 grade on the split kernels."""
         _require_gpu()
         if precision not in N.PRECISION:
             raise ValueError(f"precision must be one of {sorted(N.PRECISION)}, got {precision!r}")
-        if head_precision not in (None, "bf16", "f32"):
-            raise ValueError(f"head_precision must be None, 'bf16' or 'f32', got {head_precision!r}")
+        if head_precision not in (None, "bf16", "f16", "f32"):
+            raise ValueError(f"head_precision must be None (= precision) or 'f32', got {head_precision!r}")
         self.precision = precision
-        self.head_precision = "f32" if (head_precision == "f32" or precision != "bf16") else "bf16"
+        self.head_precision = "f32" if (head_precision == "f32" or precision in ("f32", "f32_split")) else precision
         self.cfg = cfg
         self.device = torch.device("cuda", device)
         self.max_batch, self.max_len = max_batch, max_len
@@ -57,7 +58,7 @@ class Engine:
         self._h = ctypes.c_void_p(0)
         c = N.Config(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden, cfg.n_structure_heads, cfg.freq_dim,
                      max_batch, max_len, cfg.residue_scale, int(cfg.time_conditioning), N.PRECISION[precision],
-                     1 if (head_precision == "f32" and precision == "bf16") else 0)
+                     1 if (head_precision == "f32" and precision in ("bf16", "f16")) else 0)
         # upload the caller's tensors (any float dtype) as device containers; the engine makes its own
         # bf16 / re-laid-out copies, after which these are released.
         keep, table = [], (N.Weight * len(state_dict))()

@@ -325,10 +325,11 @@ def get_argparser(argv=None):
     p.add_argument("--synthetic_len", type=int, default=0, help="sample a random sequence of this length")
     p.add_argument("--n_max_residue_square", type=int, default=DEFAULT_NMAX)
     p.add_argument("--parity", action="store_true", help="uniforms from torch's CPU generator, like the reference")
-    p.add_argument("--precision", choices=["bf16", "f32", "f32_split"], default="bf16",
+    p.add_argument("--precision", choices=["bf16", "f16", "f32", "f32_split"], default="bf16",
                    help="arithmetic of the sampling network: bf16 = the MFMA throughput path (default); f32 = the strict path, the "
                         "reference's own float32 arithmetic on the f32-input MFMA (ids equal to a float32 run of the same seed; ~1/12 "
-                        "of the throughput); f32_split = float32-grade linears as three f16 MFMA passes over split operands (~1/4)")
+                        "of the throughput); f32_split = float32-grade linears as three f16 MFMA passes over split operands (~1/4); f16 = the "
+                        "bf16 path with IEEE-half operands (same speed, 1/8 of the rounding error)")
     p.add_argument("--head_precision", choices=["bf16", "f32"], default="bf16",
                    help="bf16 network only: final LayerNorm + output head in float32 grade (+1 %% time, fewer near-tie flips)")
     p.add_argument("--decoder_precision", choices=["f32", "f32_split", "bf16"], default="f32",

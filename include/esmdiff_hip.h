@@ -66,8 +66,13 @@ typedef enum { ESMDIFF_F32 = 0, ESMDIFF_BF16 = 1 } esmdiff_dtype;
  *         can overflow; f16 x f16 products are exact in f32; the dropped lo.lo term is 2^-22): float32-grade products with
  *         f32 accumulation at ~1/3 of the bf16 MFMA rate instead of 1/16.  LayerNorm / rotary / softmax / SwiGLU / GELU are
  *         the F32 path's kernels.  Not bitwise an fmaf chain (F32 is, and stays the referee); a row's result still does not
- *         depend on the batch it is computed in. */
-typedef enum { ESMDIFF_PRECISION_BF16 = 0, ESMDIFF_PRECISION_F32 = 1, ESMDIFF_PRECISION_F32_SPLIT = 2 } esmdiff_precision;
+ *         depend on the batch it is computed in.
+ *   F16 (ABI 5)  the BF16 path's kernels and launch sequence with IEEE half operands instead of bfloat16 (the same sources
+ *         compiled a second time, csrc/ed_half.h): the f16 forms of the same MFMA instructions run at the same rate on the
+ *         same bytes, and an 11-bit significand instead of 8 cuts every operand rounding — and with it the logit error and
+ *         the rate of near-tie id flips against the float32 chain — by 8.  f16's narrower exponent is not an issue for this
+ *         network (weights, LayerNorm / attention / SwiGLU outputs are O(1e-3 .. 1e2)); conversions saturate at +-65504. */
+typedef enum { ESMDIFF_PRECISION_BF16 = 0, ESMDIFF_PRECISION_F32 = 1, ESMDIFF_PRECISION_F32_SPLIT = 2, ESMDIFF_PRECISION_F16 = 3 } esmdiff_precision;
 
 /* Hyper-parameters of CustomizedESM3 (net.py:322-332) + TimestepEmbedder (net.py:487) +
  * StructureOutputHeads (net.py:299); values for ESM3-open: 1536 / 24 / 48 / 4096 / 4101 / 256. */

@@ -92,10 +92,18 @@ def test_forward_production_width_vs_oracle(wide, B, L):
     got = eng.forward_logits(x.cuda(), seq.cuda(), sch.t_freq[i]).float().cpu()
     s = _stats(got, ref)
     _record(f"wide3_B{B}_L{L}", s)
-    # the bars of the TINY forward test (bf16 GEMM operands, f32 accumulation and residual stream)
-    assert s["cos"] > 0.999, s
-    assert s["max_err"] < 0.12 and s["mean_err"] < 1.2e-2, s
-    assert s["argmax_agree"] > 0.9, s
+    # bf16 GEMM operands, f32 accumulation and residual stream; bars 2x the measured 0.0149 / 0.0022 (profiles/r0*_parity_fullwidth.json)
+    assert s["cos"] > 0.9999, s
+    assert s["max_err"] < 0.03 and s["mean_err"] < 4.5e-3, s
+    assert s["argmax_agree"] > 0.97, s
+    # the same forward with IEEE-half operands (precision="f16", csrc/ed_half.h): 1/8 of the operand rounding
+    from esmdiff_amd.engine import Engine
+    e16 = Engine(cfg, sd, max_batch=B, max_len=L, precision="f16")
+    got16 = e16.forward_logits(x.cuda(), seq.cuda(), sch.t_freq[i]).float().cpu()
+    e16.close()
+    s16 = _stats(got16, ref)
+    _record(f"wide3_f16_B{B}_L{L}", s16)
+    assert s16["max_err"] < 4e-3 and s16["mean_err"] < 6e-4 and s16["argmax_agree"] > 0.995, s16
 
 
 def test_forward_production_width_long_chain(wide):

@@ -392,10 +392,38 @@ def test_forward_logits_vs_oracle(tiny, B, L):
     assert got.shape == ref.shape
     err = (got - ref).abs()
     cos = torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0)
-    # bf16 GEMM operands through 2 blocks + head: logits (std ~0.6) agree to ~1e-2 absolute
-    assert float(cos) > 0.999, float(cos)
-    assert float(err.max()) < 0.12 and float(err.mean()) < 1.2e-2, (float(err.max()), float(err.mean()))
-    assert float((got.argmax(-1) == ref.argmax(-1)).float().mean()) > 0.9
+    # bf16 GEMM operands through 2 blocks + head: logits (std ~0.6).  Bars = 2x the measured 0.015 / 0.0022 / 0.99
+    assert float(cos) > 0.9999, float(cos)
+    assert float(err.max()) < 0.03 and float(err.mean()) < 4.5e-3, (float(err.max()), float(err.mean()))
+    assert float((got.argmax(-1) == ref.argmax(-1)).float().mean()) > 0.98
+
+
+def test_forward_logits_f16_vs_oracle(tiny):
+    """precision="f16" (the same kernel sources compiled with IEEE-half operands, csrc/ed_half.h) over the engine's stream / path
+    switches: every operand rounding is 2^-12 instead of 2^-9, so the logit error is 1/8 of the bf16 engine's — measured
+    0.0017 max / 0.00026 mean at production width; bars 2x that.  Sampling loop runs, a sample alone equals itself in a batch
+    on the same dispatch path."""
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    cfg, sd, _, net, emb = tiny
+    eng = Engine(cfg, sd, max_batch=8, max_len=300, precision="f16")
+    sch = ddpm_schedule(25)
+    i = 6
+    for B, L in [(2, 60), (3, 258), (8, 110), (8, 290), (5, 258)]:
+        g = torch.Generator().manual_seed(L)
+        seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1)
+        x = torch.full((B, L), MASK, dtype=torch.int64)
+        x[:, 5:20] = torch.randint(0, 4096, (B, 15), generator=g)
+        with torch.no_grad():
+            cond = torch.tile(emb(sch.sigma_t[i] * torch.ones(B))[:, None, :], (1, L, 1))
+            ref = net(structure_tokens=x, sequence_tokens=seq, auxiliary_embeddings=cond).structure_logits
+        got = eng.forward_logits(x.cuda(), seq.cuda(), sch.t_freq[i]).float().cpu()
+        err = (got - ref).abs()
+        assert float(err.max()) < 4e-3 and float(err.mean()) < 6e-4, (B, L, float(err.max()), float(err.mean()))
+        assert float((got.argmax(-1) == ref.argmax(-1)).float().mean()) > 0.995
+    out = eng.ddpm_sample(seq.cuda(), ddpm_schedule(3), seed=1).cpu()
+    assert int((out == MASK).sum()) == 0
+    eng.close()
 
 
 def test_forward_with_coordinates_vs_oracle(monkeypatch):
@@ -607,7 +635,7 @@ def test_ddpm_sample_end_to_end_vs_oracle(tiny):
     got = eng.ddpm_step(x0.clone().cuda(), lg, sch.mc_t[0].item(), sch.mc_s[0].item(), seed=42, sample_offset=10,
                         step=0).cpu().numpy()
     agree = float((got == want).mean())
-    assert agree > 0.9, agree
+    assert agree > 0.98, agree          # 120 draws: at most 2 near-tie flips (measured 1.0)
     # and the sampler alone on the ENGINE's logits is bit-exact against the C oracle
     want2 = c_oracle.ddpm_step(x0.numpy(), lg.float().cpu().numpy(), sch.mc_t[0].item(), sch.mc_s[0].item(), seed=42,
                                sample_offset=10, step=0)

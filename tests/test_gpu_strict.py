@@ -628,8 +628,8 @@ def test_bf16_vs_float32_chain_configs1_full_batch():
     """BASELINE configs[1] at FULL size (100 samples x 256 residues, 25 steps, 48 blocks): every engine's chain against the
     float32 chain.  THE REFEREE IS THE EXACT-F32 ENGINE (precision="f32", v_mfma_f32_32x32x2_f32), not the torch-CPU oracle: the
     oracle would need an hour here, and the strict engine equals the oracle chain id for id at B = 2 and B = 4 (tests above).
-    Candidates: the bf16 engine (the benchmarked path), the bf16 engine with the float32-grade head (head_precision="f32"), and
-    the F32_SPLIT engine.  Per candidate: free-running agreement per step and per sample, and the per-draw flip rate when every
+    Candidates: the bf16 engine (the benchmarked path), the bf16 engine with the float32-grade head (head_precision="f32"), the f16
+    engine (same kernels, IEEE-half operands) without and with that head, and the F32_SPLIT engine.  Per candidate: free-running agreement per step and per sample, and the per-draw flip rate when every
     step starts from the referee's state (teacher-forced).  Bars are 2x the measured values."""
     import time
     from esmdiff_amd.config import ESM3_OPEN
@@ -667,7 +667,8 @@ def test_bf16_vs_float32_chain_configs1_full_batch():
     out = {"B": B, "L_tok": L, "steps": T, "layers": cfg.n_layers, "referee": "exact-f32 engine (precision='f32')",
            "referee_chain_seconds_stepwise": round(t_strict, 2), "referee_samples_per_s": round(B / t_strict, 2),
            "masked_draws_total": draws}
-    for name, kw in (("bf16", {}), ("bf16_f32head", {"head_precision": "f32"}), ("f32_split", {"precision": "f32_split"})):
+    for name, kw in (("bf16", {}), ("bf16_f32head", {"head_precision": "f32"}), ("f16", {"precision": "f16"}),
+                     ("f16_f32head", {"precision": "f16", "head_precision": "f32"}), ("f32_split", {"precision": "f32_split"})):
         eng = Engine(cfg, sd, max_batch=B, max_len=L, **kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         free = chain(eng)
@@ -687,12 +688,16 @@ def test_bf16_vs_float32_chain_configs1_full_batch():
                      "device_loop_equals_stepwise": loop_equal}
     del sd
     _record("full48_configs1_full_batch_vs_f32_chain", out)
-    for name in ("bf16", "bf16_f32head", "f32_split"):
+    for name in ("bf16", "bf16_f32head", "f16", "f16_f32head", "f32_split"):
         assert out[name]["device_loop_equals_stepwise"], (name, out[name])
     # bf16 (r03: 1.4e-4 flips per masked draw, 63 / 100 samples identical, mean agreement 0.9982)
     assert out["bf16"]["flip_rate_per_masked_draw"] < 3e-4, out["bf16"]
     assert out["bf16"]["samples_fully_identical"] >= 45 and out["bf16"]["final_agreement_mean"] > 0.996, out["bf16"]
     # the float32-grade head removes the head's share of the logit error (64 % of its variance): fewer flips, never more
     assert out["bf16_f32head"]["flip_rate_per_masked_draw"] <= out["bf16"]["flip_rate_per_masked_draw"], out["bf16_f32head"]
+    # f16 operands: 1/8 of the operand rounding -> an order of magnitude fewer flips than bf16 (VERDICT r03's bar for the headline
+    # path was <= 5e-5 per draw and >= 85 / 100 samples identical; bf16 with the float32 head alone reaches 1.0e-4 / 73)
+    assert out["f16"]["flip_rate_per_masked_draw"] <= 5e-5 and out["f16"]["samples_fully_identical"] >= 85, out["f16"]
+    assert out["f16_f32head"]["flip_rate_per_masked_draw"] <= 5e-5 and out["f16_f32head"]["samples_fully_identical"] >= 85, out["f16_f32head"]
     # F32_SPLIT: float32-grade arithmetic end to end
     assert out["f32_split"]["flip_rate_per_masked_draw"] < 1e-5 and out["f32_split"]["samples_fully_identical"] >= 97, out["f32_split"]
