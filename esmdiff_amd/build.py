@@ -26,6 +26,7 @@ UNITS = {
     "gemm256": [],
     "gemm256w4": [],
     "gemm_split": [],
+    "attention_split": [],
     "strict": [],
     "geom": [],
     "encoder": [],

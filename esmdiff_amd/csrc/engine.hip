@@ -48,6 +48,8 @@ struct Layer {
   float *fw_qkv, *fw_out, *fw_up, *fw_down;
   // precision = F32_SPLIT (csrc/gemm_split.hip): the linears as scaled f16 [lo | hi] plane pairs + 1 / scale
   SplitW s_qkv, s_out, s_up, s_down;
+  // ... and the power-of-two operand scales of the split attention (attention_split.hip), from rigorous bounds at create
+  float att_qk = 1.f, att_v = 1.f;
 };
 
 }  // namespace
@@ -100,6 +102,7 @@ struct esmdiff_engine {
   std::vector<hipStream_t> side;
   std::vector<hipEvent_t> ev_join;
   hipEvent_t ev_fork = nullptr;
+  int64_t strict_dual_min_tokens = 8192;   // F32_SPLIT: two sub-batch streams from this many tokens (ESMDIFF_STRICT_DUAL_MIN_TOKENS)
   int64_t dual_min_tokens = 2200, dual_small_max_tokens = 1024;  // two streams from / small window up to (tokens), see forward()
   int stream_offset_us = 0;  // phase offset of the second sub-batch stream (ESMDIFF_STREAM_OFFSET_US), see forward()
   int debug_skip = 0;  // -DED_DEBUG builds only: ESMDIFF_DEBUG_SKIP bits (timing experiments, results are wrong): 1 rope, 2 attention, 4 / 8 the two add+LN; always 0 otherwise
@@ -367,6 +370,107 @@ int shared_forward_batch(const esmdiff_engine* e, int B, int L) {
 // precision = F32: the same network in float32 end to end (csrc/strict.hip).  One stream, one launch per op, residual
 // adds in the branch GEMMs' epilogues as x + r / scaling_factor (esm's own expression).  Sections are timed like the
 // bf16 path's.  Block 0's geometric branch runs between the attention and the FFN branch while frames are set.
+struct SPart {   // one sub-batch of a strict forward: the engine's float32 workspace at a row offset, on its own stream
+  const int64_t *seq, *xtok;
+  float *x, *fh, *fh2, *fqkv, *fq, *fk, *fctx, *fgu, *fmid, *fgp, *fgctx, *fpair_qk, *logits, *pl_logits;
+  uint16_t* a2;
+  float* rs;
+  const float *f_rot, *f_trans;
+  const uint8_t* f_mask;
+  int B;
+  hipStream_t st;
+};
+
+static int strict_part(esmdiff_engine* e, const SPart& w, const float* cond, int ld, int L) {
+  const esmdiff_config& c = e->cfg;
+  const int D = c.d_model, H = c.n_heads, FH = c.ffn_hidden;
+  const bool geom = e->has_geom && e->frames_B > 0;
+#define RUN(section, call)   \
+  do {                       \
+    p.mark(section);         \
+    HIP_TRY(e, (call));      \
+    p.mark(section);         \
+  } while (0)
+  const int VH = e->v_heads;
+  // precision = F32_SPLIT: the same op sequence; every LayerNorm / SwiGLU / attention output that feeds a linear is written
+  // as a split row (a2, rs) and the linear runs as three f16 MFMA passes (gemm_split.hip); everything else is unchanged
+  const bool sp = e->split;
+  uint16_t* a2 = w.a2;
+  float* rs = w.rs;
+  float* logits = w.logits;
+  hipStream_t st = w.st;
+  const int B = w.B, M = B * L;
+  Prof p{e, st};
+  if (e->kind == 1) RUN(S_EMBED, launch_gather_rows(w.xtok, e->e_struct, w.x, M, D, ESMDIFF_VOCAB, st));
+  else RUN(S_EMBED, launch_embed(w.seq, w.xtok, e->e_seq, e->e_struct, e->cvec, cond, w.x, B, L, D, st));
+#define LIN(section, sw, fw, A32, lda, Kdim, out, bias, n_rows, ldc, n_valid, div, epi)                                  \
+  do {                                                                                                                   \
+    if (sp && (sw).w) RUN(section, launch_gemm256w4_split(a2, rs, (sw).w, (sw).inv, out, bias, M, round_up(n_rows, 256), Kdim, ldc, div, epi, st)); \
+    else RUN(section, launch_gemm_f32(A32, lda, fw, out, bias, M, n_rows, Kdim, ldc, n_valid, div, epi, st));             \
+  } while (0)
+  for (int i = 0; i < c.n_layers; ++i) {
+    const Layer& ly = e->layers[i];
+    if (sp) RUN(S_LN, launch_layernorm_split(w.x, ly.ln1_w, ly.ln1_b, a2, rs, nullptr, M, D, 0, st));
+    else RUN(S_LN, launch_layernorm_f32(w.x, ly.ln1_w, ly.ln1_b, w.fh, M, D, st));
+    LIN(S_QKV, ly.s_qkv, ly.fw_qkv, w.fh, D, D, w.fqkv, nullptr, 3 * D, 3 * D, 3 * D, 1.f, ESMDIFF_F32EPI_STORE);
+    if (sp) {   // float32-grade attention on the f16 MFMA: q / k / v as [hi | lo] rows in fq / fk / fh (attention_split.hip)
+      uint16_t *q2 = reinterpret_cast<uint16_t*>(w.fq), *k2 = reinterpret_cast<uint16_t*>(w.fk), *v2 = reinterpret_cast<uint16_t*>(w.fh);
+      RUN(S_QKROPE, launch_qk_norm_rope_split(w.fqkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, q2, k2, B, L, H,
+                                              ly.att_qk * 0.18033688011112042f /* log2(e) / 8 */, ly.att_qk, st));
+      RUN(S_QKROPE, launch_v_split(w.fqkv, v2, M, D, ly.att_v, st));
+      RUN(S_ATTN, launch_attention_split(q2, k2, v2, w.fctx, B, L, H, ly.att_qk * ly.att_qk, ly.att_v, st));
+      RUN(S_ATTN, launch_split_rows(w.fctx, D, a2, rs, M, D, st));
+    } else {
+      RUN(S_QKROPE, launch_qk_norm_rope_f32(w.fqkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.fq, w.fk, B, L, H, st));
+      RUN(S_ATTN, launch_attention_f32(w.fq, w.fk, w.fqkv, w.fctx, B, L, H, st));
+    }
+    LIN(S_OUT, ly.s_out, ly.fw_out, w.fctx, D, D, w.x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
+    if (i == 0 && geom) {   // x = x + geom_attn(s_norm(x), frames) / scaling_factor
+      const bool gs = sp && e->s_gproj.w;
+      if (gs) RUN(S_LN, launch_layernorm_split(w.x, e->g_snorm_w, nullptr, a2, rs, nullptr, M, D, 0, st));
+      else RUN(S_LN, launch_layernorm_f32(w.x, e->g_snorm_w, nullptr, w.fh, M, D, st));
+      LIN(S_ATTN, e->s_gproj, e->fg_proj, w.fh, D, D, w.fgp, nullptr, 15 * VH, 15 * VH, 15 * VH, 1.f, ESMDIFF_F32EPI_STORE);
+      RUN(S_ATTN, launch_geom_attention_f32(w.fgp, w.f_rot, w.f_trans, w.f_mask, e->g_wrot, e->g_wdist, w.fgctx, B, L, VH, st));
+      if (gs) RUN(S_ATTN, launch_split_rows(w.fgctx, 3 * VH, a2, rs, M, 3 * VH, st));
+      LIN(S_ATTN, e->s_gout, e->fg_out, w.fgctx, 3 * VH, 3 * VH, w.x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
+    }
+    if (sp) RUN(S_LN, launch_layernorm_split(w.x, ly.ln2_w, ly.ln2_b, a2, rs, nullptr, M, D, 0, st));
+    else RUN(S_LN, launch_layernorm_f32(w.x, ly.ln2_w, ly.ln2_b, w.fh, M, D, st));
+    LIN(S_FFN_UP, ly.s_up, ly.fw_up, w.fh, D, D, w.fgu, nullptr, 2 * FH, 2 * FH, 2 * FH, 1.f, ESMDIFF_F32EPI_STORE);
+    if (sp) RUN(S_FFN_UP, launch_swiglu_split(w.fgu, a2, rs, M, FH, st));
+    else RUN(S_FFN_UP, launch_swiglu_f32(w.fgu, w.fmid, M, FH, st));
+    LIN(S_FFN_DOWN, ly.s_down, ly.fw_down, w.fmid, FH, FH, w.x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
+  }
+  if (sp) {
+    // head: Linear + bias -> GELU -> LayerNorm -> Linear + bias; the GELU is applied by the LayerNorm as it loads the row
+    // (the same erff expression on the same f32 value).  The final norm's f32 rows are kept only for the 128-wide pairwise
+    // down-projection, which stays on the exact-f32 kernel.
+    RUN(S_LN, launch_layernorm_split(w.x, e->final_ln_w, nullptr, a2, rs, e->has_pair ? w.fh : nullptr, M, D, 0, st));
+    RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_head0.w, e->s_head0.inv, w.fh2, e->head_b0, M, D, D, D, 1.f, ESMDIFF_F32EPI_STORE, st));
+    if (e->has_plddt) RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_pl0.w, e->s_pl0.inv, w.fctx, e->pl_b0, M, D, D, D, 1.f, ESMDIFF_F32EPI_STORE, st));
+    if (e->has_pair) RUN(S_HEAD, launch_gemm_f32(w.fh, D, e->fpw_down, w.fpair_qk, nullptr, M, 128, D, 128, 128, 1.f, ESMDIFF_F32EPI_STORE, st));
+    RUN(S_LN, launch_layernorm_split(w.fh2, e->head_ln_w, e->head_ln_b, a2, rs, nullptr, M, D, 1, st));
+    RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_head3.w, e->s_head3.inv, logits, e->head_b3, M, e->vocab_pad, D, ld, 1.f, ESMDIFF_F32EPI_STORE, st));
+    if (e->has_plddt) {
+      RUN(S_LN, launch_layernorm_split(w.fctx, e->pl_ln_w, e->pl_ln_b, a2, rs, nullptr, M, D, 1, st));
+      RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_pl3.w, e->s_pl3.inv, w.pl_logits, e->pl_b3, M, 256, D, e->ld_plddt, 1.f, ESMDIFF_F32EPI_STORE, st));
+    }
+    return 0;
+  }
+#undef LIN
+  RUN(S_LN, launch_layernorm_f32(w.x, e->final_ln_w, nullptr, w.fh, M, D, st));
+  RUN(S_HEAD, launch_gemm_f32(w.fh, D, e->fhead_w0, w.fh2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_F32EPI_BIAS_GELU, st));
+  if (e->has_plddt) RUN(S_HEAD, launch_gemm_f32(w.fh, D, e->fpl_w0, w.fctx, e->pl_b0, M, D, D, D, D, 1.f, ESMDIFF_F32EPI_BIAS_GELU, st));
+  if (e->has_pair)     // the pairwise confidence head's down-projection (q | k, 64 + 64 columns per token), float32 like the rest
+    RUN(S_HEAD, launch_gemm_f32(w.fh, D, e->fpw_down, w.fpair_qk, nullptr, M, 128, D, 128, 128, 1.f, ESMDIFF_F32EPI_STORE, st));
+  RUN(S_LN, launch_layernorm_f32(w.fh2, e->head_ln_w, e->head_ln_b, w.fh, M, D, st));
+  if (e->has_plddt) RUN(S_LN, launch_layernorm_f32(w.fctx, e->pl_ln_w, e->pl_ln_b, w.fq, M, D, st));
+  RUN(S_HEAD, launch_gemm_f32(w.fh, D, e->fhead_w3, logits, e->head_b3, M, c.vocab_out, D, ld, c.vocab_out, 1.f, ESMDIFF_F32EPI_STORE, st));
+  if (e->has_plddt) RUN(S_HEAD, launch_gemm_f32(w.fq, D, e->fpl_w3, w.pl_logits, e->pl_b3, M, e->plddt_bins, D, e->ld_plddt, e->plddt_bins, 1.f, ESMDIFF_F32EPI_STORE, st));
+#undef RUN
+  return 0;
+}
+
 int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, const float* t_freq_dev, float* logits,
                    int ld, int B, int L, hipStream_t st) {
   const esmdiff_config& c = e->cfg;
@@ -383,73 +487,36 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
     RUN(S_EMBED, launch_sigma_mlp(t_freq_dev, e->sig_w1, e->sig_b1, e->sig_w2, e->sig_b2, e->sig_hidden, e->cond, c.freq_dim, D, st));
     cond = e->cond;
   }
-  if (e->kind == 1) RUN(S_EMBED, launch_gather_rows(xtok, e->e_struct, e->x, M, D, ESMDIFF_VOCAB, st));
-  else RUN(S_EMBED, launch_embed(seq, xtok, e->e_seq, e->e_struct, e->cvec, cond, e->x, B, L, D, st));
   const bool geom = e->has_geom && e->frames_B > 0;
   if (geom && (e->frames_B != B || e->frames_L != L))
     return fail(e, ESMDIFF_E_INVALID, "frames were set for B=%d L=%d, forward called with B=%d L=%d", e->frames_B, e->frames_L, B, L);
-  const int VH = e->v_heads;
-  // precision = F32_SPLIT: the same op sequence; every LayerNorm / SwiGLU / attention output that feeds a linear is written
-  // as a split row (a2, rs) and the linear runs as three f16 MFMA passes (gemm_split.hip); everything else is unchanged
-  const bool sp = e->split;
-  uint16_t* a2 = e->a2;
-  float* rs = e->rs;
-#define LIN(section, sw, fw, A32, lda, Kdim, out, bias, n_rows, ldc, n_valid, div, epi)                                  \
-  do {                                                                                                                   \
-    if (sp && (sw).w) RUN(section, launch_gemm256w4_split(a2, rs, (sw).w, (sw).inv, out, bias, M, round_up(n_rows, 256), Kdim, ldc, div, epi, st)); \
-    else RUN(section, launch_gemm_f32(A32, lda, fw, out, bias, M, n_rows, Kdim, ldc, n_valid, div, epi, st));             \
-  } while (0)
-  for (int i = 0; i < c.n_layers; ++i) {
-    const Layer& ly = e->layers[i];
-    if (sp) RUN(S_LN, launch_layernorm_split(e->x, ly.ln1_w, ly.ln1_b, a2, rs, nullptr, M, D, 0, st));
-    else RUN(S_LN, launch_layernorm_f32(e->x, ly.ln1_w, ly.ln1_b, e->fh, M, D, st));
-    LIN(S_QKV, ly.s_qkv, ly.fw_qkv, e->fh, D, D, e->fqkv, nullptr, 3 * D, 3 * D, 3 * D, 1.f, ESMDIFF_F32EPI_STORE);
-    RUN(S_QKROPE, launch_qk_norm_rope_f32(e->fqkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, e->fq, e->fk, B, L, H, st));
-    RUN(S_ATTN, launch_attention_f32(e->fq, e->fk, e->fqkv, e->fctx, B, L, H, st));
-    if (sp) RUN(S_ATTN, launch_split_rows(e->fctx, D, a2, rs, M, D, st));
-    LIN(S_OUT, ly.s_out, ly.fw_out, e->fctx, D, D, e->x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
-    if (i == 0 && geom) {   // x = x + geom_attn(s_norm(x), frames) / scaling_factor
-      const bool gs = sp && e->s_gproj.w;
-      if (gs) RUN(S_LN, launch_layernorm_split(e->x, e->g_snorm_w, nullptr, a2, rs, nullptr, M, D, 0, st));
-      else RUN(S_LN, launch_layernorm_f32(e->x, e->g_snorm_w, nullptr, e->fh, M, D, st));
-      LIN(S_ATTN, e->s_gproj, e->fg_proj, e->fh, D, D, e->fgp, nullptr, 15 * VH, 15 * VH, 15 * VH, 1.f, ESMDIFF_F32EPI_STORE);
-      RUN(S_ATTN, launch_geom_attention_f32(e->fgp, e->f_rot, e->f_trans, e->f_mask, e->g_wrot, e->g_wdist, e->fgctx, B, L, VH, st));
-      if (gs) RUN(S_ATTN, launch_split_rows(e->fgctx, 3 * VH, a2, rs, M, 3 * VH, st));
-      LIN(S_ATTN, e->s_gout, e->fg_out, e->fgctx, 3 * VH, 3 * VH, e->x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
-    }
-    if (sp) RUN(S_LN, launch_layernorm_split(e->x, ly.ln2_w, ly.ln2_b, a2, rs, nullptr, M, D, 0, st));
-    else RUN(S_LN, launch_layernorm_f32(e->x, ly.ln2_w, ly.ln2_b, e->fh, M, D, st));
-    LIN(S_FFN_UP, ly.s_up, ly.fw_up, e->fh, D, D, e->fgu, nullptr, 2 * FH, 2 * FH, 2 * FH, 1.f, ESMDIFF_F32EPI_STORE);
-    if (sp) RUN(S_FFN_UP, launch_swiglu_split(e->fgu, a2, rs, M, FH, st));
-    else RUN(S_FFN_UP, launch_swiglu_f32(e->fgu, e->fmid, M, FH, st));
-    LIN(S_FFN_DOWN, ly.s_down, ly.fw_down, e->fmid, FH, FH, e->x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
+  // F32_SPLIT at large batches: two sub-batches on two streams, as the bf16 engine does (every kernel's row results are
+  // independent of the batch, so the cut changes no bit): the persistent split GEMMs leave CUs idle in their last round and the
+  // other sub-batch's kernels fill them.
+  const int64_t tokens = (int64_t)B * L;
+  const int np = (e->split && !e->side.empty() && e->profiling != 1 && B >= 2 && tokens >= e->strict_dual_min_tokens) ? 2 : 1;
+  const int64_t WS = 3 * (int64_t)std::max(D, FH);
+  SPart parts[2];
+  for (int pi = 0; pi < np; ++pi) {
+    const int b0 = (int)((int64_t)B * pi / np), b1 = (int)((int64_t)B * (pi + 1) / np);
+    const int64_t t0 = (int64_t)b0 * L;
+    auto off = [&](float* p_, int64_t stride) { return p_ ? p_ + t0 * stride : nullptr; };
+    parts[pi] = SPart{seq + t0, xtok + t0, off(e->x, D), off(e->fh, D), off(e->fh2, D), off(e->fqkv, 3 * D), off(e->fq, D), off(e->fk, D),
+                      off(e->fctx, D), off(e->fgu, 2 * FH), off(e->fmid, FH), off(e->fgp, 15 * e->v_heads), off(e->fgctx, 3 * e->v_heads),
+                      off(e->fpair_qk, 128), logits + t0 * ld, off(e->pl_logits, e->ld_plddt), e->a2 ? e->a2 + t0 * WS : nullptr,
+                      e->rs ? e->rs + t0 : nullptr, e->f_rot ? e->f_rot + t0 * 9 : nullptr, e->f_trans ? e->f_trans + t0 * 3 : nullptr,
+                      e->f_mask ? e->f_mask + t0 : nullptr, b1 - b0, pi == 0 ? st : e->side[pi - 1]};
   }
-  if (sp) {
-    // head: Linear + bias -> GELU -> LayerNorm -> Linear + bias; the GELU is applied by the LayerNorm as it loads the row
-    // (the same erff expression on the same f32 value).  The final norm's f32 rows are kept only for the 128-wide pairwise
-    // down-projection, which stays on the exact-f32 kernel.
-    RUN(S_LN, launch_layernorm_split(e->x, e->final_ln_w, nullptr, a2, rs, e->has_pair ? e->fh : nullptr, M, D, 0, st));
-    RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_head0.w, e->s_head0.inv, e->fh2, e->head_b0, M, D, D, D, 1.f, ESMDIFF_F32EPI_STORE, st));
-    if (e->has_plddt) RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_pl0.w, e->s_pl0.inv, e->fctx, e->pl_b0, M, D, D, D, 1.f, ESMDIFF_F32EPI_STORE, st));
-    if (e->has_pair) RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fpw_down, e->fpair_qk, nullptr, M, 128, D, 128, 128, 1.f, ESMDIFF_F32EPI_STORE, st));
-    RUN(S_LN, launch_layernorm_split(e->fh2, e->head_ln_w, e->head_ln_b, a2, rs, nullptr, M, D, 1, st));
-    RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_head3.w, e->s_head3.inv, logits, e->head_b3, M, e->vocab_pad, D, ld, 1.f, ESMDIFF_F32EPI_STORE, st));
-    if (e->has_plddt) {
-      RUN(S_LN, launch_layernorm_split(e->fctx, e->pl_ln_w, e->pl_ln_b, a2, rs, nullptr, M, D, 1, st));
-      RUN(S_HEAD, launch_gemm256w4_split(a2, rs, e->s_pl3.w, e->s_pl3.inv, e->pl_logits, e->pl_b3, M, 256, D, e->ld_plddt, 1.f, ESMDIFF_F32EPI_STORE, st));
-    }
-    return 0;
+  if (np > 1) {
+    HIP_TRY(e, hipEventRecord(e->ev_fork, st));
+    HIP_TRY(e, hipStreamWaitEvent(e->side[0], e->ev_fork, 0));
   }
-#undef LIN
-  RUN(S_LN, launch_layernorm_f32(e->x, e->final_ln_w, nullptr, e->fh, M, D, st));
-  RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fhead_w0, e->fh2, e->head_b0, M, D, D, D, D, 1.f, ESMDIFF_F32EPI_BIAS_GELU, st));
-  if (e->has_plddt) RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fpl_w0, e->fctx, e->pl_b0, M, D, D, D, D, 1.f, ESMDIFF_F32EPI_BIAS_GELU, st));
-  if (e->has_pair)     // the pairwise confidence head's down-projection (q | k, 64 + 64 columns per token), float32 like the rest
-    RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fpw_down, e->fpair_qk, nullptr, M, 128, D, 128, 128, 1.f, ESMDIFF_F32EPI_STORE, st));
-  RUN(S_LN, launch_layernorm_f32(e->fh2, e->head_ln_w, e->head_ln_b, e->fh, M, D, st));
-  if (e->has_plddt) RUN(S_LN, launch_layernorm_f32(e->fctx, e->pl_ln_w, e->pl_ln_b, e->fq, M, D, st));
-  RUN(S_HEAD, launch_gemm_f32(e->fh, D, e->fhead_w3, logits, e->head_b3, M, c.vocab_out, D, ld, c.vocab_out, 1.f, ESMDIFF_F32EPI_STORE, st));
-  if (e->has_plddt) RUN(S_HEAD, launch_gemm_f32(e->fq, D, e->fpl_w3, e->pl_logits, e->pl_b3, M, e->plddt_bins, D, e->ld_plddt, e->plddt_bins, 1.f, ESMDIFF_F32EPI_STORE, st));
+  for (int pi = 0; pi < np; ++pi)
+    if (int r = strict_part(e, parts[pi], cond, ld, L)) return r;
+  if (np > 1) {
+    HIP_TRY(e, hipEventRecord(e->ev_join[0], e->side[0]));
+    HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[0], 0));
+  }
 #undef RUN
   return 0;
 }
@@ -649,6 +716,27 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     else TRY(load_bf16(e, t, b + "attn.layernorm_qkv.1.weight", {3 * D, D}, &ly.w_qkv));
     TRY(load_f32(e, t, b + "attn.q_ln.weight", {D}, &ly.q_ln_w));
     TRY(load_f32(e, t, b + "attn.k_ln.weight", {D}, &ly.k_ln_w));
+    if (split) {   // |q|, |k| <= sqrt(2 (D - 1)) max|ln weight| (LayerNorm + rotation); |v| <= (sqrt(D) max|g| + |b|_2) max_row |W_v row|_2
+      if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "weight conversion failed"));
+      std::vector<float> hq(D), hk(D), hg(D), hb(D);
+      hipMemcpy(hq.data(), ly.q_ln_w, (size_t)D * 4, hipMemcpyDeviceToHost);
+      hipMemcpy(hk.data(), ly.k_ln_w, (size_t)D * 4, hipMemcpyDeviceToHost);
+      hipMemcpy(hg.data(), ly.ln1_w, (size_t)D * 4, hipMemcpyDeviceToHost);
+      hipMemcpy(hb.data(), ly.ln1_b, (size_t)D * 4, hipMemcpyDeviceToHost);
+      float wmax = 0.f, gmax = 0.f, b2 = 0.f, rn = 0.f;
+      for (int d = 0; d < D; ++d) {
+        wmax = std::max(wmax, std::max(fabsf(hq[d]), fabsf(hk[d])));
+        gmax = std::max(gmax, fabsf(hg[d]));
+        b2 += hb[d] * hb[d];
+      }
+      const esmdiff_weight* wq;
+      TRY(need(e, t, b + "attn.layernorm_qkv.1.weight", {3 * D, D}, &wq));
+      if (weight_rownorm_max(wq->data, wq->dtype, (int64_t)2 * D, D, D, e->scratch_bits, &rn) != hipSuccess)
+        return bail(fail(e, ESMDIFF_E_HIP, "row-norm reduction of the value projection failed"));
+      auto pow2_below = [](float x) { return (x > 0.f && std::isfinite(x)) ? exp2f(floorf(log2f(x))) : 1.f; };
+      ly.att_qk = pow2_below(30000.f / (sqrtf(2.f * D) * wmax));
+      ly.att_v = pow2_below(30000.f / ((sqrtf((float)D) * gmax + sqrtf(b2)) * rn));
+    }
     if (split) TRY(load_split(e, t, b + "attn.out_proj.weight", {D, D}, &ly.s_out));
     else if (strict) TRY(load_f32(e, t, b + "attn.out_proj.weight", {D, D}, &ly.fw_out));
     else TRY(load_bf16(e, t, b + "attn.out_proj.weight", {D, D}, &ly.w_out));
@@ -921,6 +1009,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     if (const char* so = getenv("ESMDIFF_STREAM_OFFSET_US")) e->stream_offset_us = atoi(so);
     if (const char* sf = getenv("ESMDIFF_SMALL_FUSED")) e->small_fused = atoi(sf);
     if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_MIN_TOKENS")) e->dual_min_tokens = atoll(mt);
+    if (const char* mt = getenv("ESMDIFF_STRICT_DUAL_MIN_TOKENS")) e->strict_dual_min_tokens = atoll(mt);
     if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_SMALL_MAX_TOKENS")) e->dual_small_max_tokens = atoll(mt);
   }
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "engine create: %s", hipGetErrorString(hipGetLastError())));

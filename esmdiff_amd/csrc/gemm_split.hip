@@ -68,7 +68,7 @@ __device__ __forceinline__ void split4(const f32x4 v, float s, f16x4& hi, f16x4&
 __device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 // f32 rows -> split rows.  Two passes over the row (the second one hits L2 / TCP): any K % 4 == 0.
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, int ld, uint16_t* __restrict__ dst,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void split_rows_kernel(const float* __restrict__ src, int ld, uint16_t* __restrict__ dst,
                                                          float* __restrict__ rs, int M, int K) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -96,24 +96,31 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
 
 // y = LayerNorm(GELU_IN ? gelu(x) : x) * w (+ b) in the strict path's arithmetic (strict.hip::layernorm_f32_kernel: two-pass
 // statistics, 1 / sqrtf(var + 1e-5), correctly rounded), written as a split row.  One wave per row, D <= 2048.
-template <int NV, bool GELU_IN>
-__global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ b, uint16_t* __restrict__ dst,
-                                                              float* __restrict__ rs, float* __restrict__ y32, int M, int D,
-                                                              const uint16_t* __restrict__ delta, int delta_is_f16) {
+// FULL: D == 256 NV exactly (every d_model the engine accepts): no per-lane column test, hence no divergent branch per slab
+template <int NV, bool GELU_IN, bool FULL>
+__global__ __launch_bounds__(256) void layernorm_split_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, uint16_t* __restrict__ dst,
+    float* __restrict__ rs, float* __restrict__ y32, int M, int D, const uint16_t* __restrict__ delta, int delta_is_f16) {
+  // (every optional input is handled in ONE block over the row, outside the main loops: with the `if (delta)` / `if (b)` /
+  //  `if (y32)` tests inside the unrolled per-slab loops hipcc kept > 1000 values live — 263 VGPRs, one wave per SIMD, 220 us
+  //  for a 158 MB read + 238 MB write)
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   f32x4 v[NV];
-  float s = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = j * 256 + lane * 4;
-    if (c < D) {
-      v[j] = *reinterpret_cast<const f32x4*>(x + (int64_t)row * D + c);
-      if (delta) {   // bf16 engine with an f32-grade head: the last FFN-down delta is still outside x (one f32 add per element)
-        const uint2 dd = *reinterpret_cast<const uint2*>(delta + (int64_t)row * D + c);
-        if (delta_is_f16) {   // the f16 engine's deltas
+    v[j] = (FULL || c < D) ? *reinterpret_cast<const f32x4*>(x + (int64_t)row * D + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (delta) {   // bf16 / f16 engine with an f32-grade head: the last FFN-down delta is still outside x (one f32 add per element)
+    const uint16_t* dr = delta + (int64_t)row * D;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = j * 256 + lane * 4;
+      if (FULL || c < D) {
+        const uint2 dd = *reinterpret_cast<const uint2*>(dr + c);
+        if (delta_is_f16) {
           const f16x4 hv = *reinterpret_cast<const f16x4*>(&dd);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[j][e] += (float)hv[e];
@@ -124,13 +131,18 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
           v[j][3] += __uint_as_float(dd.y & 0xffff0000u);
         }
       }
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int c = j * 256 + lane * 4;
+    if (FULL || c < D) {
       if constexpr (GELU_IN) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[j][e] = gelu_erf(v[j][e]);
       }
       s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-    } else {
-      v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
   const float mean = wsum64(s) / (float)D;
@@ -138,7 +150,7 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = j * 256 + lane * 4;
-    if (c < D) {
+    if (FULL || c < D) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float d = v[j][e] - mean;
@@ -147,24 +159,30 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
     }
   }
   const float rstd = 1.0f / sqrtf(wsum64(q) / (float)D + 1e-5f);
-  float amax = 0.f;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = j * 256 + lane * 4;
-    if (c < D) {
+    if (FULL || c < D) {
       const f32x4 ww = *reinterpret_cast<const f32x4*>(w + c);
-      f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mean) * rstd * ww[e];
-      if (b) {
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] += bb[e];
-      }
-      v[j] = o;
-      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(o[0]), fabsf(o[1]))), fmaxf(fabsf(o[2]), fabsf(o[3])));
+      for (int e = 0; e < 4; ++e) v[j][e] = (v[j][e] - mean) * rstd * ww[e];
     }
   }
+  if (b) {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = j * 256 + lane * 4;
+      if (FULL || c < D) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(b + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] += bb[e];
+      }
+    }
+  }
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)   // (columns >= D hold zeros)
+    amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[j][0]), fabsf(v[j][1]))), fmaxf(fabsf(v[j][2]), fabsf(v[j][3])));
   amax = wmax64(amax);
   float sc, inv;
   row_scale(amax, sc, inv);
@@ -173,19 +191,25 @@ __global__ __launch_bounds__(256) void layernorm_split_kernel(const float* __res
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = j * 256 + lane * 4;
-    if (c < D) {
+    if (FULL || c < D) {
       f16x4 hi, lo;
       split4(v[j], sc, hi, lo);
       *reinterpret_cast<f16x4*>(d + c) = hi;
       *reinterpret_cast<f16x4*>(d + D + c) = lo;
       *reinterpret_cast<f16x4*>(d + 2 * D + c) = hi;
-      if (y32) *reinterpret_cast<f32x4*>(y32 + (int64_t)row * D + c) = v[j];   // consumers that stay on the exact-f32 kernel
+    }
+  }
+  if (y32) {   // consumers that stay on the exact-f32 kernel
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int c = j * 256 + lane * 4;
+      if (FULL || c < D) *reinterpret_cast<f32x4*>(y32 + (int64_t)row * D + c) = v[j];
     }
   }
 }
 
 // mid = silu(gate) * up (strict.hip::swiglu_f32_kernel's arithmetic) of one [2 FH] row, as a split row.  FH <= 256 * NV.
-template <int NV>
+template <int NV, bool FULL>
 __global__ __launch_bounds__(256) void swiglu_split_kernel(const float* __restrict__ gu, uint16_t* __restrict__ dst,
                                                            float* __restrict__ rs, int M, int FH) {
   const int lane = threadIdx.x & 63;
@@ -197,7 +221,7 @@ __global__ __launch_bounds__(256) void swiglu_split_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = j * 256 + lane * 4;
-    if (c < FH) {
+    if (FULL || c < FH) {
       const f32x4 gg = *reinterpret_cast<const f32x4*>(g + c);
       const f32x4 uu = *reinterpret_cast<const f32x4*>(g + FH + c);
       f32x4 o;
@@ -215,7 +239,7 @@ __global__ __launch_bounds__(256) void swiglu_split_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int c = j * 256 + lane * 4;
-    if (c < FH) {
+    if (FULL || c < FH) {
       f16x4 hi, lo;
       split4(v[j], sc, hi, lo);
       *reinterpret_cast<f16x4*>(d + c) = hi;
@@ -276,8 +300,13 @@ hipError_t launch_layernorm_split(const float* x, const float* w, const float* b
   dim3 grid((M + 3) / 4), block(256);
 #define ED_LN(N)                                                                                                       \
   do {                                                                                                                 \
-    if (gelu_in) hipLaunchKernelGGL((layernorm_split_kernel<N, true>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta, delta_is_f16);  \
-    else hipLaunchKernelGGL((layernorm_split_kernel<N, false>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta, delta_is_f16);  \
+    if (D == N * 256) {                                                                                                \
+      if (gelu_in) hipLaunchKernelGGL((layernorm_split_kernel<N, true, true>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta, delta_is_f16);  \
+      else hipLaunchKernelGGL((layernorm_split_kernel<N, false, true>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta, delta_is_f16);  \
+    } else {                                                                                                           \
+      if (gelu_in) hipLaunchKernelGGL((layernorm_split_kernel<N, true, false>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta, delta_is_f16);  \
+      else hipLaunchKernelGGL((layernorm_split_kernel<N, false, false>), grid, block, 0, stream, x, w, b, dst, rs, y32, M, D, delta, delta_is_f16);  \
+    }                                                                                                                  \
   } while (0)
   switch (nv) {
     case 1: ED_LN(1); break;
@@ -298,10 +327,16 @@ hipError_t launch_swiglu_split(const float* gu, uint16_t* dst, float* rs, int M,
   if (FH % 4 || FH > 4096) return hipErrorInvalidValue;
   dim3 grid((M + 3) / 4), block(256);
   const int nv = (FH + 255) / 256;
-  if (nv <= 4) hipLaunchKernelGGL((swiglu_split_kernel<4>), grid, block, 0, stream, gu, dst, rs, M, FH);
-  else if (nv <= 8) hipLaunchKernelGGL((swiglu_split_kernel<8>), grid, block, 0, stream, gu, dst, rs, M, FH);
-  else if (nv <= 14) hipLaunchKernelGGL((swiglu_split_kernel<14>), grid, block, 0, stream, gu, dst, rs, M, FH);
-  else hipLaunchKernelGGL((swiglu_split_kernel<16>), grid, block, 0, stream, gu, dst, rs, M, FH);
+#define ED_SW(N)                                                                                                     \
+  do {                                                                                                               \
+    if (FH == N * 256) hipLaunchKernelGGL((swiglu_split_kernel<N, true>), grid, block, 0, stream, gu, dst, rs, M, FH); \
+    else hipLaunchKernelGGL((swiglu_split_kernel<N, false>), grid, block, 0, stream, gu, dst, rs, M, FH);            \
+  } while (0)
+  if (nv <= 4) ED_SW(4);
+  else if (nv <= 8) ED_SW(8);
+  else if (nv <= 14) ED_SW(14);
+  else ED_SW(16);
+#undef ED_SW
   return hipGetLastError();
 }
 

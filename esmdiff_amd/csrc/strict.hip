@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------------------------------
 // LayerNorm of f32 rows -> f32.  One wave per row; D % 4 == 0, D <= 2048.
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void layernorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ b, float* __restrict__ y, int M,
                                                             int D) {
   const int lane = threadIdx.x & 63;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void swiglu_f32_kernel(const float* __restrict
 // q/k LayerNorm over the full width D (no bias) + rotary per 64-wide head (rotate-half, cos / sin tables [L][32]).
 // One wave per (token, q|k); the row (<= 2048 floats) lives in registers: NV float4 per lane at c = j*256 + lane*4.
 template <int NV>
-__global__ __launch_bounds__(256) void qk_norm_rope_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ qw,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void qk_norm_rope_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ qw,
                                                                const float* __restrict__ kw, const float* __restrict__ rcos,
                                                                const float* __restrict__ rsin, float* __restrict__ q,
                                                                float* __restrict__ k, int M, int L, int D) {

@@ -79,3 +79,27 @@ def test_no_silent_cpu_fallback():
         Engine(TINY, {}, 1, 8)
     with pytest.raises(RuntimeError):
         gemm_bf16(torch.zeros(2, 64, dtype=torch.bfloat16), torch.zeros(128, 64, dtype=torch.bfloat16), 0)
+
+
+def test_hand_placed_gemm_has_no_sgpr_reload_hazard():
+    """tools/check_asm_hazards.py on the hand-placed GEMM (csrc/gemm256w4.hip), both operand-type builds: hipcc may reload a
+    spilled SGPR with v_readlane directly in front of an inline-asm LDS-DMA that uses it as scalar base — a VALU-writes-SGPR ->
+    VMEM hazard (5 wait states) that nobody pads inside an asm statement; the first split-f16 build faulted that way at multi-tile
+    launches (r04).  The check compiles to gfx950 assembly (no GPU needed) and must find no such pair; the SPLIT kernels, whose
+    main loop has no slack at all, must not spill at all."""
+    import subprocess
+    import sys
+    sys.path.insert(0, str(ROOT / "tools"))
+    import check_asm_hazards as chk
+    src = ROOT / "esmdiff_amd" / "csrc" / "gemm256w4.hip"
+    for extra in ([], ["-DED_F16", "-Ded=ed16"]):
+        r = subprocess.run(["/opt/rocm/bin/hipcc", *chk.FLAGS, *extra, str(src), "-o", "/dev/stdout"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        seen = 0
+        for name, meta, hazards in chk.analyse(r.stdout):
+            assert not hazards, (name, hazards[:3])
+            seen += 1
+            if "ELi1EEE" in name:          # gemm256w4_kernel<EPI, SPLIT = 1>
+                assert meta.get("sgpr_spill_count", 0) == 0 and meta.get("vgpr_spill_count", 0) == 0, (name, meta)
+            assert meta.get("agpr_count") == 256, (name, meta)      # the 128 x 128 wave tile lives in the accumulation registers
+        assert seen == 8, seen

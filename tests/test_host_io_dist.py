@@ -327,6 +327,30 @@ def test_bench_self_spawns_ranks_world2_gloo_stub():
     assert "sample-sharded x2" in out["config"]["parallelism"]
     # whole-job value: samples of BOTH ranks / max-over-ranks time
     assert abs(out["value"] - 2 * 3 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 1e-3
+    # the N > 1 line explains its own efficiency: one record per rank with engine-create time, sampling and
+    # gather time per step, power, NUMA pinning; the slowest rank is named; the environment the number was taken in is on the line
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1] and out["slowest_rank"] in (0, 1)
+    for r in out["per_rank"]:
+        assert r["create_s"] >= 0 and r["sample_ms_per_step"] > 0 and r["gather_ms_per_step"] >= 0 and r["elapsed_s"] > 0
+        assert "power_mean_w" in r and "numa" in r
+    assert out["environment"]["esmdiff_env"] == {k: v for k, v in os.environ.items() if k.startswith("ESMDIFF_")}
+    assert isinstance(out["timed_region"], str) and "all_gather" in out["timed_region"]
+
+
+def test_bench_fails_fast_and_refuses_debug_switches(monkeypatch):
+    """`--gpus N` with fewer visible GPUs ends in seconds with one line (no launcher started); ESMDIFF_DEBUG_SKIP in the
+    environment — the launch-skipping switch of -DED_DEBUG builds — makes bench.py refuse to measure at all."""
+    import subprocess
+    import sys
+    import time
+    root = Path(__file__).resolve().parent.parent
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=120, cwd=root)
+    assert r.returncode != 0 and "--gpus 64 but" in r.stderr and time.time() - t0 < 30, r.stderr[-500:]
+    assert len([ln for ln in r.stderr.splitlines() if ln.strip()]) == 1
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--stub-engine", "--tiny"], capture_output=True, text=True, timeout=120,
+                       cwd=root, env=dict(os.environ, ESMDIFF_DEBUG_SKIP="3"))
+    assert r.returncode != 0 and "ESMDIFF_DEBUG_SKIP" in r.stderr
 
 
 def test_bench_refuses_mismatched_world(monkeypatch):

@@ -23,8 +23,9 @@ LLVM = Path("/opt/rocm/lib/llvm/bin")
 
 
 def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "")          # before the argument list is cut at the first "("
     name = re.sub(r"\(.*\)$", "", name)
-    name = name.replace("void ", "").replace("ed::", "").replace("(anonymous namespace)::", "")
+    name = name.replace("void ", "").replace("ed16::", "f16:").replace("ed::", "")
     return name[:90]
 
 
