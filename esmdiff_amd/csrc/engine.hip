@@ -50,6 +50,8 @@ struct Layer {
   SplitW s_qkv, s_out, s_up, s_down;
   // ... and the power-of-two operand scales of the split attention (attention_split.hip), from rigorous bounds at create
   float att_qk = 1.f, att_v = 1.f;
+  // ... and of the FFN mid row written by the fused SwiGLU epilogue of the split FFN-up (0: unfused, per-row scales)
+  float mid_scale = 0.f;
 };
 
 }  // namespace
@@ -232,14 +234,14 @@ int load_bf16(esmdiff_engine* e, const Table& t, const std::string& name, std::i
 
 // precision = F32_SPLIT: a linear's weight as split f16 planes [rows padded to pad_rows_to, 2K] + its inverse scale
 int load_split(esmdiff_engine* e, const Table& t, const std::string& name, std::initializer_list<int64_t> shape, SplitW* dst,
-               int64_t pad_rows_to = 0) {
+               int64_t pad_rows_to = 0, int interleave_h = 0) {
   const esmdiff_weight* w;
   if (int r = need(e, t, name, shape, &w)) return r;
   const int64_t rows = w->shape[0], K = numel(w) / rows;
   const int64_t rows_p = pad_rows_to > rows ? pad_rows_to : rows;
   if (K % 128 || rows_p % 256) return fail(e, ESMDIFF_E_SHAPE, "weight '%s': [%lld, %lld] does not fit the split GEMM (rows %% 256, K %% 128)", name.c_str(), (long long)rows_p, (long long)K);
   if (int r = dalloc(e, &dst->w, (size_t)(rows_p * 3 * K), rows_p != rows)) return r;
-  HIP_TRY(e, split_weight(w->data, w->dtype, dst->w, rows, (int)K, e->scratch_bits, &dst->inv));
+  HIP_TRY(e, split_weight(w->data, w->dtype, dst->w, rows, (int)K, e->scratch_bits, &dst->inv, interleave_h));
   return 0;
 }
 
@@ -373,7 +375,7 @@ int shared_forward_batch(const esmdiff_engine* e, int B, int L) {
 struct SPart {   // one sub-batch of a strict forward: the engine's float32 workspace at a row offset, on its own stream
   const int64_t *seq, *xtok;
   float *x, *fh, *fh2, *fqkv, *fq, *fk, *fctx, *fgu, *fmid, *fgp, *fgctx, *fpair_qk, *logits, *pl_logits;
-  uint16_t* a2;
+  uint16_t *a2, *a2b;   // split rows feeding the next linear; a2b: the FFN mid rows written by the fused SwiGLU epilogue
   float* rs;
   const float *f_rot, *f_trans;
   const uint8_t* f_mask;
@@ -436,10 +438,19 @@ static int strict_part(esmdiff_engine* e, const SPart& w, const float* cond, int
     }
     if (sp) RUN(S_LN, launch_layernorm_split(w.x, ly.ln2_w, ly.ln2_b, a2, rs, nullptr, M, D, 0, st));
     else RUN(S_LN, launch_layernorm_f32(w.x, ly.ln2_w, ly.ln2_b, w.fh, M, D, st));
-    LIN(S_FFN_UP, ly.s_up, ly.fw_up, w.fh, D, D, w.fgu, nullptr, 2 * FH, 2 * FH, 2 * FH, 1.f, ESMDIFF_F32EPI_STORE);
-    if (sp) RUN(S_FFN_UP, launch_swiglu_split(w.fgu, a2, rs, M, FH, st));
-    else RUN(S_FFN_UP, launch_swiglu_f32(w.fgu, w.fmid, M, FH, st));
-    LIN(S_FFN_DOWN, ly.s_down, ly.fw_down, w.fmid, FH, FH, w.x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
+    if (sp && ly.mid_scale > 0.f) {
+      // split FFN-up with the SwiGLU in its epilogue: reads the LayerNorm's split row (a2: [M, 3 D]) and writes the mid row as
+      // the next split row (w.a2b: [M, 3 FH], one scale per layer) — then FFN-down with that constant folded into its weight scale
+      RUN(S_FFN_UP, launch_gemm256w4_split(a2, rs, ly.s_up.w, ly.s_up.inv, reinterpret_cast<float*>(w.a2b), nullptr, M, 2 * FH, D, 3 * FH,
+                                           ly.mid_scale, 4, st));
+      RUN(S_FFN_DOWN, launch_gemm256w4_split(w.a2b, nullptr, ly.s_down.w, ly.s_down.inv / ly.mid_scale, w.x, nullptr, M, D, FH, D,
+                                             c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
+    } else {
+      LIN(S_FFN_UP, ly.s_up, ly.fw_up, w.fh, D, D, w.fgu, nullptr, 2 * FH, 2 * FH, 2 * FH, 1.f, ESMDIFF_F32EPI_STORE);
+      if (sp) RUN(S_FFN_UP, launch_swiglu_split(w.fgu, a2, rs, M, FH, st));
+      else RUN(S_FFN_UP, launch_swiglu_f32(w.fgu, w.fmid, M, FH, st));
+      LIN(S_FFN_DOWN, ly.s_down, ly.fw_down, w.fmid, FH, FH, w.x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
+    }
   }
   if (sp) {
     // head: Linear + bias -> GELU -> LayerNorm -> Linear + bias; the GELU is applied by the LayerNorm as it loads the row
@@ -504,7 +515,7 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
     parts[pi] = SPart{seq + t0, xtok + t0, off(e->x, D), off(e->fh, D), off(e->fh2, D), off(e->fqkv, 3 * D), off(e->fq, D), off(e->fk, D),
                       off(e->fctx, D), off(e->fgu, 2 * FH), off(e->fmid, FH), off(e->fgp, 15 * e->v_heads), off(e->fgctx, 3 * e->v_heads),
                       off(e->fpair_qk, 128), logits + t0 * ld, off(e->pl_logits, e->ld_plddt), e->a2 ? e->a2 + t0 * WS : nullptr,
-                      e->rs ? e->rs + t0 : nullptr, e->f_rot ? e->f_rot + t0 * 9 : nullptr, e->f_trans ? e->f_trans + t0 * 3 : nullptr,
+                      reinterpret_cast<uint16_t*>(e->fgu) + t0 * 3 * FH, e->rs ? e->rs + t0 : nullptr, e->f_rot ? e->f_rot + t0 * 9 : nullptr, e->f_trans ? e->f_trans + t0 * 3 : nullptr,
                       e->f_mask ? e->f_mask + t0 : nullptr, b1 - b0, pi == 0 ? st : e->side[pi - 1]};
   }
   if (np > 1) {
@@ -743,8 +754,28 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(load_f32(e, t, b + "ffn.0.weight", {D}, &ly.ln2_w));
     TRY(load_f32(e, t, b + "ffn.0.bias", {D}, &ly.ln2_b));
     if (split) {
-      TRY(load_split(e, t, b + "ffn.1.weight", {2 * FH, D}, &ly.s_up));
+      // FFN-up with the SwiGLU fused into the split GEMM's epilogue (rows interleaved gate / up): the mid row is written with ONE
+      // power-of-two scale per layer, from |mid| = |silu(g) u| <= |g| |u| <= B^2, B = (sqrt(D) max|ln2 g| + |ln2 b|_2) max_row |W row|_2
+      const bool fuse = FH % 32 == 0 && !getenv("ESMDIFF_SPLIT_UNFUSED_SWIGLU");
+      TRY(load_split(e, t, b + "ffn.1.weight", {2 * FH, D}, &ly.s_up, 0, fuse ? FH : 0));
       TRY(load_split(e, t, b + "ffn.3.weight", {D, FH}, &ly.s_down));
+      if (fuse) {
+        if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "weight conversion failed"));
+        std::vector<float> hg(D), hb(D);
+        hipMemcpy(hg.data(), ly.ln2_w, (size_t)D * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(hb.data(), ly.ln2_b, (size_t)D * 4, hipMemcpyDeviceToHost);
+        float gmax = 0.f, b2 = 0.f, rn = 0.f;
+        for (int d = 0; d < D; ++d) {
+          gmax = std::max(gmax, fabsf(hg[d]));
+          b2 += hb[d] * hb[d];
+        }
+        const esmdiff_weight* wu;
+        TRY(need(e, t, b + "ffn.1.weight", {2 * FH, D}, &wu));
+        if (weight_rownorm_max(wu->data, wu->dtype, 0, 2 * FH, D, e->scratch_bits, &rn) != hipSuccess)
+          return bail(fail(e, ESMDIFF_E_HIP, "row-norm reduction of the FFN-up weight failed"));
+        const float Bg = (sqrtf((float)D) * gmax + sqrtf(b2)) * rn, B2 = Bg * Bg;
+        ly.mid_scale = (B2 > 0.f && std::isfinite(B2)) ? exp2f(floorf(log2f(30000.f / B2))) : 1.f;
+      }
     } else if (strict) {
       TRY(load_f32(e, t, b + "ffn.1.weight", {2 * FH, D}, &ly.fw_up));
       TRY(load_f32(e, t, b + "ffn.3.weight", {D, FH}, &ly.fw_down));

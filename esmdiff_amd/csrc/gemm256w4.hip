@@ -339,7 +339,48 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16_t* __restr
       }
       const int m = m0 + wm * 128 + i * 32 + lrow;
       const bool live = m < M && !(W4_ABL(8) && alpha != 12345.f);
-      if constexpr (SPLIT) {   // f32 outputs of the split linears: acc * (row scale * weight scale), both powers of two
+      if constexpr (SPLIT && EPI == 4) {
+        // F32_SPLIT FFN-up with the SwiGLU fused (W rows interleaved gate / up in blocks of 32, as in the bf16 path): mid =
+        // silu(g) * u in f32, then mid * s_mid (`div`: a power of two from the per-layer bound |mid| <= |g| |u| <= B^2, engine.hip)
+        // written straight as the split row [hi | lo | hi] (row stride ldc = 3 FH) that the FFN-down GEMM reads — no f32
+        // [M, 2 FH] round trip, no separate SwiGLU pass.  exp and the reciprocal are the hardware's (1 ulp each).
+        const float sc = (rs && m < M) ? rs[m] * alpha : alpha;
+        const int FHc = N >> 1;   // (ldc = 3 FH; a division by 3 here costs the SGPRs that make the kernel spill)
+#pragma unroll
+        for (int jp = 0; jp < 2; ++jp) {
+          uint16_t* orow = reinterpret_cast<uint16_t*>(out) + (int64_t)m * ldc + (n0 + wn * 128 + jp * 64) / 2 + lhi * 8;
+#pragma unroll
+          for (int gp = 0; gp < 2; ++gp) {
+            uint32_t hw[4], lw[4];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+              float a[2];
+#pragma unroll
+              for (int t = 0; t < 2; ++t) {
+                const float g = acc[i][2 * jp][gp * 8 + 2 * e2 + t] * sc, u = acc[i][2 * jp + 1][gp * 8 + 2 * e2 + t] * sc;
+                a[t] = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.44269504088896341f)) * u * div;
+              }
+              typedef __attribute__((ext_vector_type(2))) _Float16 h2_t;
+              typedef __attribute__((ext_vector_type(2))) float f2_t;
+              const h2_t h = __builtin_convertvector(f2_t{a[0], a[1]}, h2_t);
+              const f2_t hf = __builtin_convertvector(h, f2_t);
+              const h2_t l = __builtin_convertvector(f2_t{a[0] - hf[0], a[1] - hf[1]}, h2_t);
+              __builtin_memcpy(&hw[e2], &h, 4);
+              __builtin_memcpy(&lw[e2], &l, 4);
+            }
+            swap_halves(hw[0], hw[2]);
+            swap_halves(hw[1], hw[3]);
+            swap_halves(lw[0], lw[2]);
+            swap_halves(lw[1], lw[3]);
+            if (live) {
+              const uint4 hv = make_uint4(hw[0], hw[1], hw[2], hw[3]), lv = make_uint4(lw[0], lw[1], lw[2], lw[3]);
+              *reinterpret_cast<uint4*>(orow + gp * 16) = hv;
+              *reinterpret_cast<uint4*>(orow + FHc + gp * 16) = lv;
+              *reinterpret_cast<uint4*>(orow + 2 * FHc + gp * 16) = hv;
+            }
+          }
+        }
+      } else if constexpr (SPLIT) {   // f32 outputs of the split linears: acc * (row scale * weight scale), both powers of two
         const float sc = (rs && m < M) ? rs[m] * alpha : alpha;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -464,7 +505,7 @@ hipError_t launch_gemm256w4_split(const uint16_t* A2, const float* rs, const uin
                                   const float* bias, int M, int N, int K, int ldc, float div, int epi, hipStream_t stream) {
   using namespace g4;
   if (M <= 0) return hipSuccess;
-  if (N % BN != 0 || K % (2 * BK) != 0 || (ldc & 3) || ldc < N) return hipErrorInvalidValue;
+  if (N % BN != 0 || K % (2 * BK) != 0 || (ldc & 3) || (epi != 4 && ldc < N) || (epi == 4 && ldc != 3 * (N / 2))) return hipErrorInvalidValue;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
   int dev = 0, n_cu = 256;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
@@ -488,6 +529,7 @@ hipError_t launch_gemm256w4_split(const uint16_t* A2, const float* rs, const uin
       else ED_GEMM_S(ESMDIFF_F32EPI_STORE);
       break;
     case ESMDIFF_F32EPI_RESID_DIV: ED_GEMM_S(ESMDIFF_F32EPI_RESID_DIV); break;
+    case 4: ED_GEMM_S(4); break;   // fused SwiGLU -> split row (out: uint16_t [M, ldc = 3 N / 2]; div = the mid scale)
     default: return hipErrorInvalidValue;
   }
 #undef ED_GEMM_S

@@ -266,13 +266,21 @@ __global__ __launch_bounds__(256) void weight_absmax_kernel(const void* __restri
   if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order like their bits
 }
 
+// interleave_h > 0: dst row rho takes source row (blk / 2) * 32 + rho % 32 (+ interleave_h for odd blk), blk = rho / 32 — gate and
+// up rows of the FFN-up weight [2 H, K] alternate in blocks of 32, so a wave's accumulator pair (2 jp, 2 jp + 1) holds the gate
+// and the up value of the same hidden unit (the bf16 path's convert.hip::interleave_swiglu_kernel, for the fused SwiGLU epilogue)
 __global__ __launch_bounds__(256) void split_weight_kernel(const void* __restrict__ src, int dt, uint16_t* __restrict__ dst,
-                                                           int64_t n, int K, float s) {
+                                                           int64_t n, int K, float s, int interleave_h) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int64_t r = i / K;
   const int c = (int)(i - r * K);
-  const float a = load_w(src, dt, i) * s;
+  int64_t sr = r;
+  if (interleave_h > 0) {
+    const int64_t blk = r >> 5;
+    sr = (blk >> 1) * 32 + (r & 31) + ((blk & 1) ? interleave_h : 0);
+  }
+  const float a = load_w(src, dt, sr * K + c) * s;
   const _Float16 h = (_Float16)a;
   const _Float16 l = (_Float16)(a - (float)h);
   uint16_t hb, lb;
@@ -343,7 +351,7 @@ hipError_t launch_swiglu_split(const float* gu, uint16_t* dst, float* rs, int M,
 // dst f16 [rows_pad >= rows, 3K] (zero-filled by the caller beyond `rows`) = [lo | hi | hi] of src * 2^k, k chosen so that the
 // matrix maximum lands in [2^14, 2^15); *inv_scale_out = 2^-k for the GEMM epilogue.  Synchronous (create time).
 hipError_t split_weight(const void* src, int src_dtype, uint16_t* dst, int64_t rows, int K, uint32_t* scratch_bits,
-                        float* inv_scale_out) {
+                        float* inv_scale_out, int interleave_h) {
   const int64_t n = rows * K;
   hipError_t s = hipMemset(scratch_bits, 0, 4);
   if (s != hipSuccess) return s;
@@ -358,7 +366,7 @@ hipError_t split_weight(const void* src, int src_dtype, uint16_t* dst, int64_t r
   float sc, inv;
   memcpy(&sc, &sb, 4);
   memcpy(&inv, &ib, 4);
-  hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, src, src_dtype, dst, n, K, sc);
+  hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, src, src_dtype, dst, n, K, sc, interleave_h);
   *inv_scale_out = inv;
   return hipGetLastError();
 }

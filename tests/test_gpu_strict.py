@@ -402,7 +402,7 @@ def test_strict_engine_refuses_what_it_does_not_build():
     with pytest.raises(ValueError):
         Engine(TINY, sd, max_batch=2, max_len=16, precision="fp8")
     eng = Engine(TINY, sd, max_batch=2, max_len=16, precision="f32")
-    with pytest.raises(RuntimeError, match="strict"):
+    with pytest.raises(RuntimeError, match="needs a bf16 engine"):
         eng.attention(torch.zeros(32, 3 * TINY.d_model, dtype=torch.bfloat16, device="cuda"),
                       torch.ones(TINY.d_model), torch.ones(TINY.d_model), 2, 16)
     eng.close()
