@@ -269,8 +269,12 @@ def roofline_report(args, cfg, B, L, n_fwd_sample, prof_dom, prof):
                 traffic_note = f"profiles/{name}: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, fabric-level" + (
                     "; " + rec["note"] if "note" in rec else "")
                 break
-    return {
-        "roofline": {"bound": "mfma", "kernel": "g4::gemm256w4_kernel<SWIGLU> (FFN-up, M=%d N=%d K=%d)" % (M // parts, 2 * cfg.ffn_hidden, cfg.d_model),
+    passes = 3 if args.precision == "f32_split" else 1      # f32_split: three f16 MFMA products per split operand pair
+    kname = {"bf16": "g4::gemm256w4_kernel<SWIGLU, 0>", "f16": "ed16::g4::gemm256w4_kernel<SWIGLU, 0>",
+             "f32_split": "g4::gemm256w4_kernel<4, SPLIT> (fused SwiGLU, 3 f16 MFMA passes)", "f32": "gemm_f32_kernel<STORE>"}[args.precision]
+    rep = {
+        "roofline": {"bound": "mfma", "kernel": "%s (FFN-up, M=%d N=%d K=%d)" % (kname, M // parts, 2 * cfg.ffn_hidden, cfg.d_model),
+                     "mfma_passes": passes,
                      # top level = the contract's figure: algorithmic FLOP of ONE launch / its mean duration in the timed
                      # configuration (HIP events on the launch stream); it is the number profiles/*_kernel_stats.txt
                      # (rocprofv3 --kernel-trace --stats of the same command) shows as the kernel's average
@@ -295,6 +299,9 @@ def roofline_report(args, cfg, B, L, n_fwd_sample, prof_dom, prof):
         "sections_note": "per-launch HIP events of one extra untimed single-stream step; roofline.* is from the timed region",
         "device_ms_per_forward": round(tot_ms / n_fwd, 3),
     }
+    if passes > 1:   # the figure above counts the ALGORITHMIC product once; the matrix pipes do `passes` times that
+        rep["roofline"]["mfma_work_frac"] = round(passes * ach_launch / PEAK_BF16_TFLOPS, 4)
+    return rep
 
 
 def spawn_ranks(n: int) -> int:
@@ -325,6 +332,10 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="small model (debug only; prints data=debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="debug: timed region without the in-stream HIP events")
+    ap.add_argument("--no-breakdown", action="store_true",
+                    help="skip the extra UNTIMED single-stream step that produces sections_ms_per_forward and roofline.exclusive: under "
+                         "rocprofv3 every launch of the dominant kernel is then a launch of the timed configuration, so the trace's "
+                         "average for it is directly the figure roofline.frac is computed from")
     ap.add_argument("--no-step0-sharing", action="store_true", help="skip the second, labelled run with exact step-0 sharing")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--mode", choices=["ddpm", "gibbs"], default="ddpm",
@@ -498,11 +509,14 @@ def main():
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
     prof_dom = eng.get_profile()
-    eng.set_profiling(1)                                         # one extra, UNTIMED pass for the per-section breakdown
-    one_step(2000)
     sync_local = (lambda: None) if stub else (lambda: torch.cuda.synchronize(dev))
-    sync_local()
-    prof = eng.get_profile()
+    if args.no_breakdown:
+        prof = {k: {"ms": 0.0, "launches": 0} for k in prof_dom}
+    else:
+        eng.set_profiling(1)                                     # one extra, UNTIMED pass for the per-section breakdown
+        one_step(2000)
+        sync_local()
+        prof = eng.get_profile()
     eng.set_profiling(0)
     assert int((ids == 4096).sum()) == 0
     # Second, LABELLED figure (never `value`): the same workload with the exact shortcuts — step-0 sharing (every sample of a

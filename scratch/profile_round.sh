@@ -17,10 +17,10 @@ prof() {  # name, bench args...
   python $R/tools/rocprof_summary.py $db $out/${tag}_${name}_kernel_stats.txt --lib $R/esmdiff_amd/lib/libesmdiff_hip.so --union "gemm256w4_kernel<2, 0>" > /dev/null
 }
 # (the profiled runs skip the labelled extra legs: one engine, the headline workload only)
-prof cfg1 --no-head-f32-leg --no-step0-sharing
+prof cfg1 --no-head-f32-leg --no-step0-sharing --no-breakdown
 prof cfg3 --residues 1024 --samples-per-gpu 32 --no-head-f32-leg --no-step0-sharing
 prof cfg4 --num-steps 50 --inpaint 96:160 --no-head-f32-leg --no-step0-sharing
-prof cfg1_f16 --precision f16 --no-head-f32-leg --no-step0-sharing
+prof cfg1_f16 --precision f16 --no-head-f32-leg --no-step0-sharing --no-breakdown
 prof cfg1_f32split --precision f32_split --steps 1 --warmup 1 --no-step0-sharing
 for mm in 25800 12900; do
   for grp in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
