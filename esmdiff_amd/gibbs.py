@@ -67,12 +67,17 @@ def encode_structure_prior(protein: ESMProtein, n_tokens: int) -> torch.Tensor:
 
 @torch.no_grad()
 def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequence[GenerationConfig], *,
-                           seed: int = 0, sample_offset: int = 0, decoder=None) -> List[ESMProtein]:
-    """client: an esmdiff_amd Engine, or an object with a `.net` Engine (the model wrapper); `decoder` defaults to the
-    client's own `.decoder` attribute when it has one."""
+                           seed: int = 0, sample_offset: int = 0, decoder=None, encoder=None) -> List[ESMProtein]:
+    """client: an esmdiff_amd Engine, or an object with a `.net` Engine (the model wrapper); `decoder` / `encoder` default to
+    the client's own `.decoder` / `.encoder` attributes when it has them.  `GenerationConfig.condition_on_coordinates_only =
+    False` [ESM-RECALL: esm then also feeds the structure TOKENS its VQ-VAE encoder derives from the coordinates]: proteins
+    that carry coordinates but no structure tokens get them from `encoder` (an esmdiff_amd.engine.StructureEncoder) for every
+    residue with finite coordinates; those positions are then known tokens, not MASK, and are not sampled."""
     eng = getattr(client, "net", client)
     if decoder is None:
         decoder = getattr(client, "decoder", None)
+    if encoder is None:
+        encoder = getattr(client, "encoder", None)
     assert len(proteins) == len(configs) and len(proteins) > 0
     cfg0 = configs[0]
     for c in configs:
@@ -91,6 +96,15 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
     seq = torch.stack(seqs)
     x0 = torch.stack([encode_structure_prior(p, L) for p in proteins])
     has_xyz = [p.coordinates is not None for p in proteins]
+    for b, (p, c) in enumerate(zip(proteins, configs)):
+        if not getattr(c, "condition_on_coordinates_only", True) and p.coordinates is not None and p.structure_tokens is None:
+            if encoder is None:
+                raise RuntimeError("condition_on_coordinates_only=False needs the VQ-VAE structure encoder: pass encoder= "
+                                   "(esmdiff_amd.engine.StructureEncoder; CLI: --encoder_ckpt)")
+            cb = torch.as_tensor(p.coordinates, dtype=torch.float32)
+            if cb.shape[0] != L - 2:
+                raise ValueError(f"coordinates cover {cb.shape[0]} residues, sequence has {L - 2}")
+            x0[b, 1:-1] = encoder.encode(cb[None]).reshape(-1).to(x0.device)     # MASK where a residue has no coordinates
     if any(has_xyz):
         from .geometry import build_affine3d_from_coordinates
         if not getattr(eng, "has_geom", False):

@@ -67,6 +67,46 @@ class MaskedDiffusionLanguageModeling:
     def _sample_prior(self, *batch_dims):
         return self.mask_index * torch.ones(*batch_dims, dtype=torch.int64)
 
+    sequence_prediction = False      # the reference's flag (model.py:487-490); this engine builds the structure head only
+
+    def logits_parameterization(self, logits: torch.Tensor, xt: torch.Tensor) -> torch.Tensor:
+        """model.py:527-533 on the device, in the reference's operation order (torch ops on the logits tensor: the loops use the
+        fused sampler kernel instead; this is the standalone form `_model_wrapper` returns)."""
+        logits = logits.clone()
+        logits[:, :, self.mask_index] += self.neg_infinity
+        logits = logits - torch.logsumexp(logits, dim=-1, keepdim=True)
+        unmasked = xt != self.mask_index
+        logits[unmasked] = self.neg_infinity
+        logits[unmasked, xt[unmasked]] = 0
+        return logits
+
+    @torch.no_grad()
+    def _model_wrapper(self, xt, sequence_tokens=None, sigma=None, shield_special_tokens: bool = False):
+        """The reference's `_model_wrapper` (model.py:464-492): log-probabilities (B, L, 4101) of the SUBS parameterisation at
+        noise level `sigma` ((B,) or (B, 1); every row must carry the same value, as in the sampling loop — the engine embeds one
+        sigma per forward; None = no time conditioning at all), optionally with the five special ids shielded (:484-486).
+        Returns (logits, None) like the reference with sequence_prediction off; sequence_prediction is not built."""
+        from .schedule import timestep_embedding
+        if self.sequence_prediction:
+            raise NotImplementedError("sequence_prediction: the engine has no sequence head (the reference's sampler never uses it)")
+        xt = xt.to(self.device)
+        B, L = xt.shape
+        if sequence_tokens is None:     # net.py:412-416: the sequence track defaults to all-mask
+            from .constants import SEQUENCE_MASK_TOKEN
+            sequence_tokens = torch.full((B, L), SEQUENCE_MASK_TOKEN, dtype=torch.int64)
+        tf = None
+        if sigma is not None:
+            sg = torch.as_tensor(sigma, dtype=torch.float32).reshape(-1)          # _process_sigma: squeeze
+            if sg.numel() not in (1, B) or bool((sg != sg[0]).any()):
+                raise ValueError("_model_wrapper: one sigma per call (all rows equal), as ddpm_sample passes it")
+            tf = self.net.conditioning_rows(timestep_embedding(sg[:1], self.cfg.freq_dim))
+            tf = None if tf is None else tf[0]
+        raw = self.net.forward_logits(xt, sequence_tokens.to(self.device), tf)
+        logits = self.logits_parameterization(raw.float(), xt)
+        if shield_special_tokens:
+            logits[..., STRUCTURE_MASK_TOKEN:STRUCTURE_MASK_TOKEN + 5] += self.neg_infinity
+        return logits, None
+
     @torch.no_grad()
     def ddpm_sample(self, sequence_tokens, num_steps=None, eps=1e-5, input_prior=None, sample_max_t=1.0, *,
                     seed: int = 0, sample_offset: int = 0, noise: str = "philox"):

@@ -713,3 +713,45 @@ def test_bf16_vs_float32_chain_configs1_full_batch():
     assert out["f16_f32head"]["flip_rate_per_masked_draw"] <= 5e-5 and out["f16_f32head"]["samples_fully_identical"] >= 85, out["f16_f32head"]
     # F32_SPLIT: float32-grade arithmetic end to end
     assert out["f32_split"]["flip_rate_per_masked_draw"] < 1e-5 and out["f32_split"]["samples_fully_identical"] >= 97, out["f32_split"]
+
+
+def test_model_wrapper_semantics_vs_reference_parameterization():
+    """`MaskedDiffusionLanguageModeling._model_wrapper` (model.py:464-492) as a standalone call: network at sigma -> SUBS
+    log-probabilities -> optional shield of the five special ids; (logits, None) with sequence_prediction off.  Checked on a
+    float32-grade engine against the oracle network + the restated logits_parameterization (pinned to golden g3): masked rows within
+    float32 round-off, carried rows exactly (-1e6 everywhere, 0 at the own token), mask column pushed to -1e6 before the logsumexp."""
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.model import MaskedDiffusionLanguageModeling
+    from esmdiff_amd.schedule import LogLinearNoise
+    from esmdiff_amd.weights import random_init_state_dict
+    from oracle.esm3_ref import build_from_state_dict
+    from oracle.sampler_ref import logits_parameterization_ref
+    sd = random_init_state_dict(TINY, seed=4)
+    model = MaskedDiffusionLanguageModeling(sd, TINY, LogLinearNoise(), max_batch=3, max_len=40, device=0, precision="f32_split")
+    net, emb = build_from_state_dict(TINY, sd)
+    B, L = 3, 40
+    g = torch.Generator().manual_seed(3)
+    seq = _seq(B, L, g)
+    xt = torch.full((B, L), MASK, dtype=torch.int64)
+    xt[:, 3:17] = torch.randint(0, 4096, (B, 14), generator=g)
+    sigma = torch.full((B, 1), 1.7)
+    with torch.no_grad():
+        cond = torch.tile(emb(sigma.squeeze(-1))[:, None, :], (1, L, 1))
+        raw = net(structure_tokens=xt, sequence_tokens=seq, auxiliary_embeddings=cond).structure_logits
+    want = logits_parameterization_ref(raw.clone(), xt)
+    got, none = model._model_wrapper(xt, seq, sigma)
+    assert none is None and got.shape == (B, L, V)
+    got = got.cpu()
+    masked = xt == MASK
+    assert float((got[masked] - want[masked])[..., :4096].abs().max()) < 5e-5
+    assert bool((got[masked][..., 4096] < -9e5).all())                              # the mask id can never be predicted
+    assert torch.equal(got[~masked], want[~masked])                                 # carry-over rows: exactly -1e6 / 0
+    assert abs(float(torch.logsumexp(got[masked][..., :4096], -1).abs().max())) < 1e-4
+    sh, _ = model._model_wrapper(xt, seq, sigma, shield_special_tokens=True)
+    assert torch.equal(sh.cpu()[..., :4096], got[..., :4096])
+    assert float((sh.cpu()[..., 4096:] - (got[..., 4096:] - 1e6)).abs().max()) < 1.0    # (-1e6 + -1e6 in float32)
+    with pytest.raises(ValueError):
+        model._model_wrapper(xt, seq, torch.tensor([0.1, 0.2, 0.3]))
+    model.sequence_prediction = True
+    with pytest.raises(NotImplementedError):
+        model._model_wrapper(xt, seq, sigma)
