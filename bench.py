@@ -565,22 +565,28 @@ def main():
 
         def timed(engine):
             sync_local()
+            ps = PowerSampler(local_rank)
+            ps.start()
             ta = time.perf_counter()
             for k in range(ks):
                 one_step(k, engine=engine)
             sync_local()
-            return time.perf_counter() - ta
+            dt = time.perf_counter() - ta
+            pw = ps.stop()
+            return dt, pw
 
         for name, kw in (("head_f32", {"head_precision": "f32"}), ("f16", {"precision": "f16"}),
                          ("f16_head_f32", {"precision": "f16", "head_precision": "f32"})):
             e2 = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank, **kw)
             one_step(1000, engine=e2)
-            t_alt = timed(e2)
-            t_base = timed(eng)
+            t_alt, pw_alt = timed(e2)
+            t_base, pw_base = timed(eng)
             alt_engines[name] = e2
+            pw = lambda r: None if not r else {"mean_w": r["mean_w"], "mean_sclk_mhz": r["mean_sclk_mhz"]}  # noqa: E731
             alt_recs[name] = {"value": round(B * ks / t_alt, 3), "unit": "samples/s", "steps": ks,
                               "headline_engine_same_session": round(B * ks / t_base, 3),
                               "cost_frac": round(t_alt / t_base - 1.0, 4), "engine": kw,
+                              "power": pw(pw_alt), "headline_engine_power": pw(pw_base),
                               "what": "same workload, labelled extra — NOT the headline value"}
 
     if rank == 0:

@@ -64,9 +64,11 @@ typedef enum { ESMDIFF_F32 = 0, ESMDIFF_BF16 = 1 } esmdiff_dtype;
  *   F32_SPLIT (ABI 5; csrc/gemm_split.hip)  the F32 path with every large linear computed as THREE passes of the f16 MFMA
  *         over operands split into two f16 numbers each (x = hi + lo to 2^-22, rows scaled by powers of two so that nothing
  *         can overflow; f16 x f16 products are exact in f32; the dropped lo.lo term is 2^-22): float32-grade products with
- *         f32 accumulation at ~1/3 of the bf16 MFMA rate instead of 1/16.  LayerNorm / rotary / softmax / SwiGLU / GELU are
- *         the F32 path's kernels.  Not bitwise an fmaf chain (F32 is, and stays the referee); a row's result still does not
- *         depend on the batch it is computed in.
+ *         f32 accumulation at ~1/3 of the bf16 MFMA rate instead of 1/16.  Attention runs the same way (attention_split.hip).
+ *         LayerNorm, rotary and GELU are the F32 path's arithmetic; the softmax exponentials and the SwiGLU (fused into the
+ *         FFN-up epilogue) use the hardware's exp2 / reciprocal (1 ulp each) where F32 calls expf and divides.  Logits agree
+ *         with the F32 engine to 7e-6 and the id chains are equal at BASELINE configs[1]'s full size; F32 stays the referee.  A
+ *         row's result does not depend on the batch it is computed in.
  *   F16 (ABI 5)  the BF16 path's kernels and launch sequence with IEEE half operands instead of bfloat16 (the same sources
  *         compiled a second time, csrc/ed_half.h): the f16 forms of the same MFMA instructions run at the same rate on the
  *         same bytes, and an 11-bit significand instead of 8 cuts every operand rounding — and with it the logit error and

@@ -44,6 +44,11 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(str(lib_path))
     for name in declared:
         assert hasattr(L, name), name
+    # both operand-type builds of the kernels are linked in (csrc/ed_half.h: namespace ed = bf16, ed16 = f16)
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", str(lib_path)], capture_output=True, text=True).stdout
+    for fn in ("launch_gemm_bf16", "launch_attention", "launch_add_layernorm_bf16", "launch_qk_norm_rope", "launch_to_bf16"):
+        assert f"_ZN2ed{len(fn)}{fn}" in syms and f"_ZN4ed16{len(fn)}{fn}" in syms, fn
     # the product library carries no debug exports
     assert not hasattr(L, "esmdiff_debug_graph_ab") and not hasattr(L, "esmdiff_gemm_bf16_timed")
     assert L.esmdiff_abi_version() == 5
