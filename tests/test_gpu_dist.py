@@ -94,3 +94,58 @@ def test_engine_rccl_world2_equals_single_process(tmp_path):
     want = eng.ddpm_sample(seq[None].repeat(N, 1).cuda(), ddpm_schedule(5, freq_dim=TINY.freq_dim), seed=9).cpu().numpy()
     eng.close()
     assert np.array_equal(got, want)
+
+
+def _worker_shared_gpu(rank, world, port, tmp):
+    """Two ranks, ONE GPU (both on device 0), the real Engine, gloo for the exchange (RCCL refuses two ranks on one device)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.dist import gather_ids, shard_samples
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N, L = 7, 40
+    g = torch.Generator().manual_seed(1)
+    seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])
+    off, cnt = shard_samples(N, world, rank)
+    out = {}
+    for prec in ("bf16", "f16", "f32_split"):
+        eng = Engine(TINY, random_init_state_dict(TINY, seed=3), max_batch=N, max_len=L, device=0, precision=prec)
+        eng.set_step0_sharing(True)
+        eng.set_final_skip(True)
+        ids = eng.ddpm_sample(seq[None].repeat(cnt, 1).cuda(0), ddpm_schedule(5, freq_dim=TINY.freq_dim), seed=9, sample_offset=off)
+        out[prec] = gather_ids(ids.cpu(), N).numpy()          # the exchange itself over gloo (CPU tensors)
+        eng.close()
+    if rank == 0:
+        np.savez(Path(tmp) / "gathered_shared.npz", **out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_engine_two_ranks_one_gpu_equal_single_process(tmp_path):
+    """The multi-rank path with the REAL engine on a one-GPU box: two processes share device 0, each samples its shard (4 + 3 of 7
+    samples, Philox keyed by the global sample index, exact shortcuts on), gloo gathers the int16 ids — the ensemble must equal the
+    one a single process draws, for the bf16, f16 and f32_split engines.  (What this cannot cover is RCCL itself at world > 1:
+    test_engine_rccl_world2_equals_single_process does, on a node with two GPUs.)"""
+    import torch.multiprocessing as mp
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_shared_gpu, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "gathered_shared.npz")
+    N, L = 7, 40
+    g = torch.Generator().manual_seed(1)
+    seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])
+    for prec in ("bf16", "f16", "f32_split"):
+        eng = Engine(TINY, random_init_state_dict(TINY, seed=3), max_batch=N, max_len=L, precision=prec)
+        want = eng.ddpm_sample(seq[None].repeat(N, 1).cuda(), ddpm_schedule(5, freq_dim=TINY.freq_dim), seed=9).cpu().numpy()
+        eng.close()
+        assert np.array_equal(got[prec], want), prec

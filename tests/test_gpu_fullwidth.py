@@ -151,8 +151,9 @@ def test_attention_production_heads(wide):
         assert float(per_head.max()) < 6e-2, per_head
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16"])
 @pytest.mark.parametrize("B,L", [(2, 60), (2, 258)])
-def test_forward_with_coordinates_production_width(B, L):
+def test_forward_with_coordinates_production_width(B, L, precision):
     """Coordinate conditioning as the inpainting path uses it (sample_esmdiff.py:88-96), at the shipped geometry: 256
     vector heads (projection 3840 wide, 768-wide output), d 1536, 3 blocks — engine (esmdiff_set_frames + geom.hip) vs
     oracle/geom_ref.py inside the whole network, partly masked (Inf) coordinates, NaN at BOS / EOS."""
@@ -176,15 +177,17 @@ def test_forward_with_coordinates_production_width(B, L):
     with torch.no_grad():
         ref = net(structure_tokens=x, sequence_tokens=seq, structure_coords=xyz).structure_logits
         ref0 = net(structure_tokens=x, sequence_tokens=seq).structure_logits
-    eng = Engine(cfg, sd, max_batch=B, max_len=L)
+    eng = Engine(cfg, sd, max_batch=B, max_len=L, precision=precision)
     eng.set_frames(*build_affine3d_from_coordinates(xyz))
     got = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu()
     eng.close()
     s = _stats(got, ref)
     s["conditioning_effect_max"] = float((ref - ref0).abs().max())
-    _record(f"wide3_coords_B{B}_L{L}", s)
+    _record(f"wide3_coords_{precision}_B{B}_L{L}", s)
     assert s["conditioning_effect_max"] > 5e-2                           # the coordinates matter in the oracle itself
-    assert s["cos"] > 0.999 and s["max_err"] < 0.12 and s["mean_err"] < 1.2e-2, s
+    # bars 2x the measured 0.0142 / 0.0022 (bf16); the f16 build of the same kernels (geom.hip included): 1/8 of that
+    k = 1.0 if precision == "bf16" else 0.125
+    assert s["cos"] > 0.9999 and s["max_err"] < 0.03 * k + 1e-3 and s["mean_err"] < 4.5e-3 * k + 1e-4, s
     assert s["max_err"] < 0.5 * s["conditioning_effect_max"], s
 
 

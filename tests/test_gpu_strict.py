@@ -439,10 +439,24 @@ def test_cli_precision_flags(tmp_path):
     main([a if a != str(tmp_path) else str(out2) for a in common[:-2]] + ["--mode", "ddpm"])
     meta2 = json.loads((out2 / "step4_eps1e-05_N3" / "synthetic30.json").read_text())
     assert meta2["precision"] == "bf16" and meta2["decoder_precision"] == "f32"
+    # r04: float32 grade on the f16 MFMA (sampler AND decoder) must give the exact-f32 run's ids on the same seed; the f16 engine
+    # with the float32-grade head runs through the same CLI
+    out3 = tmp_path / "split"
+    main([a if a != str(tmp_path) else str(out3) for a in common[:-2]] + ["--precision", "f32_split", "--decoder_precision", "f32_split",
+                                                                          "--mode", "ddpm"])
+    d3 = out3 / "step4_eps1e-05_N3"
+    meta3 = json.loads((d3 / "synthetic30.json").read_text())
+    assert meta3["precision"] == "f32_split" and meta3["decoder_precision"] == "f32_split"
+    assert np.array_equal(np.load(d3 / "synthetic30.tokens.npy"), ids_f32)
+    out4 = tmp_path / "f16"
+    main([a if a != str(tmp_path) else str(out4) for a in common[:-2]] + ["--precision", "f16", "--head_precision", "f32", "--mode", "ddpm"])
+    assert json.loads((out4 / "step4_eps1e-05_N3" / "synthetic30.json").read_text())["precision"] == "f16"
+    assert np.load(out4 / "step4_eps1e-05_N3" / "synthetic30.tokens.npy").shape == (3, 30)
 
 
+@pytest.mark.parametrize("precision", ["f32", "f32_split"])
 @pytest.mark.parametrize("B,L", [(2, 60), (2, 258)])
-def test_strict_forward_with_coordinates(B, L):
+def test_strict_forward_with_coordinates(B, L, precision):
     """Coordinate conditioning (block 0's geometric attention, the gibbs-mode inpainting path: sample_esmdiff.py:88-96) on the
     strict engine at the shipped geometry (256 vector heads, d 1536, 3 blocks): float32 projection / geometric attention /
     output projection against oracle/geom_ref.py inside the whole network — partly masked (Inf) coordinates, NaN at BOS / EOS."""
@@ -465,7 +479,7 @@ def test_strict_forward_with_coordinates(B, L):
     with torch.no_grad():
         ref = net(structure_tokens=x, sequence_tokens=seq, structure_coords=xyz).structure_logits
         ref0 = net(structure_tokens=x, sequence_tokens=seq).structure_logits
-    eng = Engine(cfg, sd, max_batch=B, max_len=L, precision="f32")
+    eng = Engine(cfg, sd, max_batch=B, max_len=L, precision=precision)
     off = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu().clone()
     eng.set_frames(*build_affine3d_from_coordinates(xyz))
     got = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu().clone()
@@ -475,7 +489,7 @@ def test_strict_forward_with_coordinates(B, L):
     s = _stats(got, ref)
     s["conditioning_effect_max"] = float((ref - ref0).abs().max())
     s["unconditioned_max_err"] = float((off - ref0).abs().max())
-    _record(f"strict_wide3_coords_B{B}_L{L}", s)
+    _record(f"{precision}_wide3_coords_B{B}_L{L}", s)
     assert s["conditioning_effect_max"] > 5e-2
     assert s["max_err"] < 5e-5 and s["unconditioned_max_err"] < 2e-5, s
     assert torch.equal(nan, off)                         # all-unknown coordinates: the branch contributes exactly zero
@@ -572,8 +586,9 @@ def test_strict_model_wrapper_replays_reference_rng_stream():
     assert torch.equal(got1, want1) and torch.equal(got2, want2), rec
 
 
-def test_strict_gibbs_chain_equals_oracle_chain():
-    """The default ("gibbs") mode on the strict engine: the whole entropy-ordered unmasking loop (esmdiff_gibbs_sample) against
+@pytest.mark.parametrize("precision", ["f32", "f32_split"])
+def test_strict_gibbs_chain_equals_oracle_chain(precision):
+    """The default ("gibbs") mode on the strict engine (exact f32 and float32 grade on the f16 MFMA): the whole entropy-ordered unmasking loop (esmdiff_gibbs_sample) against
     the chain oracle forward (f32, no time conditioning) -> C-oracle gibbs step with the same Philox noise — production width,
     3 blocks, the stock 4096-way head shape is covered in test_gpu_kernels; here the ESMDiff 4101-way head."""
     from esmdiff_amd.config import ModelConfig
@@ -585,7 +600,7 @@ def test_strict_gibbs_chain_equals_oracle_chain():
     cfg = ModelConfig(n_layers=3)
     sd = random_init_state_dict(cfg, seed=13)
     net, _ = build_from_state_dict(cfg, sd)
-    eng = Engine(cfg, sd, max_batch=2, max_len=60, precision="f32")
+    eng = Engine(cfg, sd, max_batch=2, max_len=60, precision=precision)
     B, L, T = 2, 60, 8
     g = torch.Generator().manual_seed(6)
     seq = _seq(B, L, g)
@@ -601,7 +616,7 @@ def test_strict_gibbs_chain_equals_oracle_chain():
     got = eng.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=5, sample_offset=3).cpu().numpy()
     eng.close()
     rec = {"agree": float((got == x).mean()), "masked_left": int((got == MASK).sum())}
-    _record("strict_wide3_gibbs_chain_B2_L60_T8", rec)
+    _record(f"{precision}_wide3_gibbs_chain_B2_L60_T8", rec)
     assert rec["masked_left"] == 0 and np.array_equal(got, x), rec
 
 
