@@ -48,7 +48,7 @@ EXPORTS = [
     "esmdiff_metrics_bonding_validity", "esmdiff_metrics_pwd", "esmdiff_metrics_js_columns", "esmdiff_encoder_create", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error",
     "esmdiff_encoder_encode", "esmdiff_gemm_f32", "esmdiff_set_step0_sharing", "esmdiff_get_counters",
     "esmdiff_set_gibbs_options", "esmdiff_split_rows", "esmdiff_split_weight", "esmdiff_gemm_split",
-    "esmdiff_get_embeddings", "esmdiff_set_final_skip",
+    "esmdiff_get_embeddings", "esmdiff_set_final_skip", "esmdiff_gemm_f16",
 ]
 
 
@@ -86,6 +86,7 @@ def lib():
     L.esmdiff_gibbs_step.argtypes = [vp, vp, vp, vp, i32, f32, f32, vp, vp, ctypes.POINTER(Rng), i32, i32, i32, vp]
     L.esmdiff_gibbs_sample.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, ctypes.POINTER(i32), ctypes.POINTER(Rng), vp]
     L.esmdiff_gemm_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
+    L.esmdiff_gemm_f16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     if hasattr(L, "esmdiff_gemm_bf16_timed"):      # -DED_DEBUG builds only (scratch/ A-B scripts)
         L.esmdiff_gemm_bf16_timed.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, i32, c_f32p, vp]
         L.esmdiff_gemm_bf16_timed.restype = ctypes.c_int

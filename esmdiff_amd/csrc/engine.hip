@@ -1340,6 +1340,15 @@ int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias
   return 0;
 }
 
+int esmdiff_gemm_f16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N, int32_t K,
+                     int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream) {
+  if (!A || !W || !out) return ESMDIFF_E_INVALID;
+  hipError_t s = ed16::launch_gemm_bf16((const bf16_t*)A, (const bf16_t*)W, out, bias, M, N, K, ldc, n_valid, alpha, epilogue,
+                                        (hipStream_t)stream);
+  if (s != hipSuccess) return fail(nullptr, s == hipErrorInvalidValue ? ESMDIFF_E_INVALID : ESMDIFF_E_HIP, "gemm_f16: %s", hipGetErrorString(s));
+  return 0;
+}
+
 int esmdiff_gemm_f32(const float* A, int32_t lda, const float* W, float* out, const float* bias, int32_t M, int32_t N,
                      int32_t K, int32_t ldc, int32_t n_valid, float div, int32_t epilogue, void* stream) {
   if (!A || !W || !out) return ESMDIFF_E_INVALID;

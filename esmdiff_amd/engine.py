@@ -481,6 +481,25 @@ def gemm_bf16(A: torch.Tensor, W: torch.Tensor, epilogue: int, *, out: Optional[
     return out
 
 
+def gemm_f16(A: torch.Tensor, W: torch.Tensor, epilogue: int, *, out: Optional[torch.Tensor] = None,
+             bias: Optional[torch.Tensor] = None, alpha: float = 1.0, n_valid: Optional[int] = None) -> torch.Tensor:
+    """gemm_bf16's contract on the f16 build of the kernels (esmdiff_gemm_f16): A, W and 16-bit outputs are torch.float16."""
+    _require_gpu()
+    M, K = A.shape
+    Nn = W.shape[0]
+    assert A.dtype == W.dtype == torch.float16 and A.is_contiguous() and W.is_contiguous() and W.shape[1] == K
+    if out is None:
+        if epilogue in (N.EPI_BF16, N.EPI_BIAS_GELU_BF16):
+            out = torch.empty(M, Nn, dtype=torch.float16, device=A.device)
+        elif epilogue == N.EPI_SWIGLU_BF16:
+            out = torch.empty(M, Nn // 2, dtype=torch.float16, device=A.device)
+        else:
+            raise ValueError("f32 epilogues need an explicit `out`")
+    N.check(N.lib().esmdiff_gemm_f16(_ptr(A), _ptr(W), _ptr(out), _ptr(bias), M, Nn, K, out.stride(0),
+                                     Nn if n_valid is None else n_valid, float(alpha), epilogue, _stream()))
+    return out
+
+
 def gemm_f32(A: torch.Tensor, W: torch.Tensor, epilogue: int = 0, *, out: Optional[torch.Tensor] = None,
              bias: Optional[torch.Tensor] = None, div: float = 1.0) -> torch.Tensor:
     """The strict path's linear (esmdiff_gemm_f32): out f32 [M,N] = epi(A f32 [M,K] @ W f32 [N,K]^T); K % 32 == 0.

@@ -224,6 +224,11 @@ typedef enum {
 int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N,
                       int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream);
 
+/* The same kernels in their f16 build (csrc/ed_half.h, namespace ed16; what precision = ESMDIFF_PRECISION_F16 engines run): A, W and
+ * the 16-bit outputs are IEEE half instead of bfloat16, conversions saturate at +-65504; everything else as esmdiff_gemm_bf16. */
+int esmdiff_gemm_f16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N,
+                     int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream);
+
 /* The strict path's linear (csrc/strict.hip): out f32 [M,ldc] = epi(A f32 [M,K] (row stride lda) . W f32 [N,K]^T), every
  * product and sum in float32 on v_mfma_f32_32x32x2_f32 (fixed, batch-independent K order per output element; not ascending k);
  * K % 32 == 0; columns >= n_valid are not written. */

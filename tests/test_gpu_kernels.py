@@ -243,6 +243,48 @@ def test_gemm_epilogues():
     assert float((o[:, :nv] - ref[:, :nv]).abs().max()) < 2e-4
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(200, 256, 192, "store"), (777, 384, 512, "store"), (12900, 4608, 1536, "store"),
+                                       (12900, 8192, 1536, "swiglu"), (8229, 1536, 768, "gelu"), (3000, 4352, 1536, "bias_f32")])
+def test_gemm_f16_build(M, N, K, epi):
+    """The f16 build of the GEMM kernels (esmdiff_gemm_f16: the same sources compiled with IEEE-half operands, csrc/ed_half.h;
+    128x128 and four-wave 256x256 kernels, every 16-bit epilogue): exact f16 products accumulated in f32, outputs rounded to f16 —
+    |err| <= 2^-11 |ref| + accumulation noise, 1/8 of the bf16 bars; asymmetric-identity layout check; saturation instead of inf."""
+    from esmdiff_amd import _native as Nn
+    from esmdiff_amd.engine import gemm_f16
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g, device="cuda").half()
+    W = (torch.randn(N, K, generator=g, device="cuda") / K ** 0.5).half()
+    ref = A.float() @ W.float().t()
+    if epi == "store":
+        out = gemm_f16(A, W, Nn.EPI_BF16, alpha=0.866)
+        assert out.dtype == torch.float16
+        err = (out.float() - ref * 0.866).abs()
+        assert float((err - ref.abs() * 2 ** -11).max()) < 5e-4, float(err.max())
+    elif epi == "swiglu":
+        out = gemm_f16(A, W, Nn.EPI_SWIGLU_BF16)
+        r = ref.view(M, N // 64, 2, 32)
+        want = (torch.nn.functional.silu(r[:, :, 0]) * r[:, :, 1]).reshape(M, N // 2)
+        err = (out.float() - want).abs()
+        assert float((err - want.abs() * 2 ** -10).max()) < 1.5e-3, float(err.max())
+    elif epi == "gelu":
+        bias = torch.randn(N, generator=g, device="cuda")
+        out = gemm_f16(A, W, Nn.EPI_BIAS_GELU_BF16, bias=bias)
+        want = torch.nn.functional.gelu(ref + bias)
+        assert float((out.float() - want).abs().max()) < 4e-3 and float((out.float() - want).abs().mean()) < 3e-4
+    else:
+        nv, ld = 4101, 4104
+        bias = torch.randn(N, generator=g, device="cuda")
+        o = torch.full((M, ld), -7.0, device="cuda")
+        gemm_f16(A, W, Nn.EPI_BIAS_F32, out=o, bias=bias, n_valid=nv)
+        assert float((o[:, :nv] - (ref + bias)[:, :nv]).abs().max()) < 2e-4
+    if (M, N, K) == (200, 256, 192):
+        eye = torch.eye(256, device="cuda").half()
+        Wa = (torch.arange(256 * 256, dtype=torch.float32, device="cuda").reshape(256, 256) % 251 - 125).half()
+        assert torch.equal(gemm_f16(eye, Wa, Nn.EPI_BF16).float(), Wa.float().t())
+        big = gemm_f16(torch.full((128, 64), 60000.0, device="cuda").half(), torch.full((128, 64), 2.0, device="cuda").half(), Nn.EPI_BF16)
+        assert bool(torch.isfinite(big.float()).all()) and float(big.float().max()) == 65504.0      # saturates, never inf
+
+
 @pytest.mark.parametrize("K", [768, 1536])
 def test_gemm256w4_epilogues_large_m(K):
     """Every epilogue of the four-wave 256x256 kernel (the large-M default: >= 128 tiles) against f32 torch, ragged last
