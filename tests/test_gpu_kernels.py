@@ -1173,3 +1173,28 @@ def test_bench_line_contract(tmp_path):
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and isinstance(cb["sample"], str)
     assert "power" in d                                                     # hwmon sample or null, never missing
+
+
+def test_f16_engine_saturates_instead_of_overflowing(tiny):
+    """f16 has 5 exponent bits: every f32 -> f16 conversion of the ed16 kernels clamps to +-65504 (csrc/ed_half.h), so an outlier
+    activation costs accuracy, never an inf / NaN that would poison the residual stream.  One block's FFN-up weight is scaled by 400
+    (SwiGLU products far beyond 65504): the f16 engine's logits stay finite and the sampling loop still completes; the bf16 engine,
+    which has the range, is the reference for 'finite'."""
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    cfg, sd, _, _, _ = tiny
+    sd2 = dict(sd)
+    key = next(k for k in sd2 if k.endswith("blocks.1.ffn.1.weight"))
+    sd2[key] = sd2[key] * 400.0
+    B, L = 2, 40
+    g = torch.Generator().manual_seed(2)
+    seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1)
+    x = torch.full((B, L), MASK, dtype=torch.int64)
+    sch = ddpm_schedule(3)
+    for prec in ("bf16", "f16"):
+        eng = Engine(cfg, sd2, max_batch=B, max_len=L, precision=prec)
+        lg = eng.forward_logits(x.cuda(), seq.cuda(), sch.t_freq[0]).float()
+        assert bool(torch.isfinite(lg).all()), prec
+        out = eng.ddpm_sample(seq.cuda(), sch, seed=1).cpu()
+        assert int((out == MASK).sum()) == 0, prec
+        eng.close()
