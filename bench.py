@@ -531,7 +531,7 @@ def main():
         same = bool(torch.equal(one_step(0), ids0)) if ids0 is not None else None   # step 0 again (same seed), shared this time
         sync_local()
         eng.counters(reset=True)
-        ks = max(2, min(args.steps, 5))
+        ks = max(2, min(args.steps, 3))
         ts0 = time.perf_counter()
         for k in range(ks):
             one_step(k)
@@ -561,7 +561,7 @@ def main():
     alt_recs, alt_engines = {}, {}
     if world == 1 and not stub and args.precision == "bf16" and args.head_precision == "bf16" and not args.no_head_f32_leg:
         from esmdiff_amd.engine import Engine
-        ks = max(2, min(args.steps, 3))
+        ks = 2
 
         def timed(engine):
             sync_local()

@@ -550,7 +550,8 @@ def test_strict_inpainting_trajectory_and_long_chain(full48):
     assert s["max_err"] < 3e-5 and s["argmax_agree"] == 1.0, s
 
 
-def test_strict_model_wrapper_replays_reference_rng_stream():
+@pytest.mark.parametrize("precision", ["f32", "f32_split"])
+def test_strict_model_wrapper_replays_reference_rng_stream(precision):
     """north_star's sentence taken literally — "ids match the reference CPU/PyTorch path bit-exact under a fixed RNG seed":
     the reference's OWN noise source (torch.manual_seed + torch.rand_like, model.py:24-28) drives (a) the oracle's restatement
     of the reference sampler (pinned to goldens g3-g6 made by the reference's model.py) around the float32 oracle network and
@@ -565,8 +566,8 @@ def test_strict_model_wrapper_replays_reference_rng_stream():
     cfg = ModelConfig(n_layers=6)
     sd = random_init_state_dict(cfg, seed=21)
     net, emb = build_from_state_dict(cfg, sd)
-    model = MaskedDiffusionLanguageModeling(sd, cfg, LogLinearNoise(), max_batch=3, max_len=60, device=0, precision="f32")
-    assert model.net.precision == "f32"
+    model = MaskedDiffusionLanguageModeling(sd, cfg, LogLinearNoise(), max_batch=3, max_len=60, device=0, precision=precision)
+    assert model.net.precision == precision
     B, L, T = 3, 60, 25
     g = torch.Generator().manual_seed(2)
     seq = _seq(B, L, g)
@@ -582,7 +583,7 @@ def test_strict_model_wrapper_replays_reference_rng_stream():
     got2 = model.ddpm_sample(seq, num_steps=T, seed=123, noise="torch-cpu", input_prior=prior, sample_offset=B).cpu()
     model.net.close()
     rec = {"agree_all_masked": float((got1 == want1).float().mean()), "agree_inpainting": float((got2 == want2).float().mean())}
-    _record("strict_wide6_reference_rng_stream_B3_L60_T25", rec)
+    _record(f"{precision}_wide6_reference_rng_stream_B3_L60_T25", rec)
     assert torch.equal(got1, want1) and torch.equal(got2, want2), rec
 
 
