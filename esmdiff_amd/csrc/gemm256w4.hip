@@ -507,9 +507,11 @@ hipError_t launch_gemm256w4_split(const uint16_t* A2, const float* rs, const uin
   if (M <= 0) return hipSuccess;
   if (N % BN != 0 || K % (2 * BK) != 0 || (ldc & 3) || (epi != 4 && ldc < N) || (epi == 4 && ldc != 3 * (N / 2))) return hipErrorInvalidValue;
   const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
-  int dev = 0, n_cu = 256;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-  n_cu = n_cu >= 8 ? (n_cu / 8) * 8 : 8;
+  static const int n_cu = [] {   // (one device model per process: every gfx950 in a node has the same CU count)
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n >= 8 ? (n / 8) * 8 : 8;
+  }();
   const int n_tiles = tiles_m * tiles_n;
   dim3 grid(n_tiles < n_cu ? n_tiles : n_cu), block(256);
   const size_t lds = 2 * STAGE_BYTES;
