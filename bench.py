@@ -589,6 +589,43 @@ def main():
                               "power": pw(pw_alt), "headline_engine_power": pw(pw_base),
                               "what": "same workload, labelled extra — NOT the headline value"}
 
+    # One more LABELLED figure: certified sampling (esmdiff_amd/certified.py) — the f16 engine draws, the sampler kernel flags
+    # the samples with a close call (winner within exp(2 eps) of the runner-up), those are re-run for that update on an
+    # F32_SPLIT engine.  Ids are compared here with the F32_SPLIT engine's own chain for the same seed.
+    cert_rec = None
+    if alt_engines.get("f16") is not None and args.mode == "ddpm" and not args.inpaint:
+        from esmdiff_amd.certified import CertifiedSampler
+        from esmdiff_amd.engine import Engine
+        ex = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank, precision="f32_split")
+        cs = CertifiedSampler(alt_engines["f16"], ex)
+        cs.ddpm_sample(seq, sch, seed=args.seed + 1000, sample_offset=rank * B)
+        sync_local()
+        ks, got = 2, []
+        tc0 = time.perf_counter()
+        stats = []
+        for k in range(ks):
+            got.append(cs.ddpm_sample(seq, sch, seed=args.seed + k, sample_offset=rank * B))
+            stats.append(cs.stats)
+        sync_local()
+        tc1 = time.perf_counter()
+        want = ex.ddpm_sample(seq, sch, seed=args.seed, sample_offset=rank * B)
+        sync_local()
+        tc2 = time.perf_counter()
+        plain = alt_engines["f16"].ddpm_sample(seq, sch, seed=args.seed, sample_offset=rank * B)
+        cert_rec = {"value": round(B * ks / (tc1 - tc0), 3), "unit": "samples/s", "steps": ks, "eps": cs.eps,
+                    "fast_engine": "f16", "exact_engine": "f32_split",
+                    "f32_split_engine_alone_same_session": round(B / (tc2 - tc1), 3),
+                    "ids_equal_to_f32_split_chain": bool(torch.equal(got[0], want)),
+                    "samples_identical_without_certification": int((plain == want).all(1).sum()),
+                    "rerun_share": round(sum(s_["sample_forwards_exact"] for s_ in stats) /
+                                         max(1, sum(s_["sample_forwards_fast"] for s_ in stats)), 4),
+                    "max_logit_err_observed": max(s_["max_logit_err_observed"] for s_ in stats),
+                    "eps_violations": sum(s_["eps_violations"] for s_ in stats),
+                    "what": "same workload, ids of the float32-grade chain: f16 engine + re-runs of the close calls on the F32_SPLIT "
+                            "engine (tests/test_gpu_strict.py::test_certified_sampler_equals_float32_chain_configs1_full_batch "
+                            "checks the ids against the exact-f32 engine).  Labelled extra — NOT the headline value"}
+        ex.close()
+
     if rank == 0:
         total_samples = B * world * args.steps
         value = total_samples / elapsed
@@ -630,6 +667,8 @@ def main():
             out["power"] = power_rec
             if alt_recs:
                 out["alt_precisions"] = alt_recs
+            if cert_rec is not None:
+                out["certified"] = cert_rec
             if shared_rec is not None:
                 shared_rec["flop_per_sample_executed"] = flops_forward_per_sample(L, cfg) * shared_rec["forwards_executed_per_sample"]
                 shared_rec["mfma_frac_whole_job"] = round(shared_rec["value"] * shared_rec["flop_per_sample_executed"] / (PEAK_BF16_TFLOPS * 1e12), 4)

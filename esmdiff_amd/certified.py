@@ -1,0 +1,110 @@
+"""Certified sampling: the ids of the f32-grade chain at close to the reduced-precision engine's speed.
+
+The state of the ancestral sampler (model.py:543-581) between two updates is a matrix of token ids, so a rounding error of
+the network does not accumulate from update to update: as long as every draw of an update came out the same, the next
+update starts from the identical input.  A draw is an arg-max of q_v / g_v (model.py:24-28) with q_v = exp(z_v - lse) *
+(mc_t - mc_s), or mc_s for the mask column.  With logits known to +-eps, the ratio of two candidates moves by at most
+exp(2 eps): between two tokens the logsumexp cancels and z_a - z_b moves by 2 eps; against the mask column z_a moves by
+eps and lse (1-Lipschitz in the max norm) by eps.  So a winner that beats the runner-up by more than the factor
+exp(2 eps) is the winner for ANY logits within eps — in particular for the f32 ones.  The sampler kernel reports,
+per sample, whether all of its draws were that clear (esmdiff_ddpm_step_margin, csrc/sampler.hip).  The few samples with
+a close call are run again through the f32-grade engine for that one update (same tokens in, same Philox keys) and take
+its ids.
+
+`eps` is a bound on the fast engine's logit error against f32, and it is an EMPIRICAL one (tests/test_gpu_kernels.py
+measures max |err| 1.7e-3 for the f16 engine at production width; the default 4e-3 leaves a factor 2.4): the result is
+"the f32 chain's ids unless a logit was off by more than eps", which tests/test_gpu_strict.py checks at configs[1]'s full
+size (100 samples, 335 340 draws: all ids equal).  The assumption is monitored while sampling: every re-run yields the
+fast and the f32-grade logits of the same input, and stats["max_logit_err_observed"] is their largest difference over
+the masked rows (stats["eps_violations"] counts re-run samples that exceeded eps).  No reference counterpart — the
+reference has one precision.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from .engine import Engine
+from .schedule import DDPMSchedule
+from .constants import STRUCTURE_MASK_TOKEN
+
+
+class CertifiedSampler:
+    """fast: a reduced-precision Engine (f16 recommended: its logit error is 8x below bf16's, so 8x fewer close calls);
+    exact: an f32-grade Engine of the same checkpoint (precision 'f32_split' or 'f32')."""
+
+    def __init__(self, fast: Engine, exact: Engine, eps: float = 4e-3):
+        if fast.device != exact.device:
+            raise ValueError("both engines must live on the same GPU")
+        if not eps > 0:
+            raise ValueError("eps must be positive")
+        self.fast, self.exact, self.eps = fast, exact, float(eps)
+        self.stats: dict = {}
+
+    @torch.no_grad()
+    def ddpm_sample(self, sequence_tokens: torch.Tensor, schedule: DDPMSchedule, *, seed: int, sample_offset: int = 0,
+                    input_prior: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Same arguments and result layout as Engine.ddpm_sample.  self.stats holds the re-run counts of the call."""
+        fast, exact = self.fast, self.exact
+        B, L = sequence_tokens.shape
+        dev = fast.device
+        seq = sequence_tokens.to(device=dev, dtype=torch.int64).contiguous()
+        if input_prior is None:
+            x = torch.full((B, L), STRUCTURE_MASK_TOKEN, dtype=torch.int64, device=dev)
+        else:
+            if tuple(input_prior.shape) != (B, L):
+                raise ValueError(f"Invalid input_prior shape: {tuple(input_prior.shape)} v.s. (seq) {(B, L)}")
+            x = input_prior.to(device=dev, dtype=torch.int64).contiguous().clone()
+        T = schedule.num_steps
+        tf_fast = fast.conditioning_rows(schedule.t_freq)
+        tf_exact = exact.conditioning_rows(schedule.t_freq)
+        ratio, diff = math.exp(2.0 * self.eps), 2.0 * self.eps
+        flags = torch.zeros(B, dtype=torch.int32, device=dev)
+        logits = torch.empty(B, L, fast.ld_logits, dtype=torch.float32, device=dev)
+        cap = exact.max_batch
+        reruns = []
+        err_max, violations, skipped_final = 0.0, 0, False
+        V = exact.cfg.n_structure_heads
+        shared0 = input_prior is None and B > 1 and bool((seq == seq[:1]).all())
+        for i in range(T + 1):
+            fin = i == T
+            if i == 0 and shared0 and not fin:
+                # every sample enters the first update with the same inputs (all-mask prior, one protein): ONE f32-grade
+                # forward serves them all, nothing to certify (the device loop's step-0 sharing, engine.hip)
+                lg1 = exact.forward_logits(x[:1], seq[:1], None if tf_exact is None else tf_exact[0])
+                logits[..., :V] = lg1
+                exact.ddpm_step(x, logits[..., :V], float(schedule.mc_t[0]), float(schedule.mc_s[0]), seed=seed,
+                                sample_offset=sample_offset, step=0)
+                reruns.append(0)
+                continue
+            if fin and not bool((x == STRUCTURE_MASK_TOKEN).any()):
+                reruns.append(0)                                  # nothing left to denoise: the pass is the identity
+                skipped_final = True
+                break
+            mc_t = 0.0 if fin else float(schedule.mc_t[i])
+            mc_s = 0.0 if fin else float(schedule.mc_s[i])
+            prev = x.clone()
+            lg = fast.forward_logits(x, seq, None if tf_fast is None else tf_fast[i], out=logits)
+            flags.zero_()
+            fast.ddpm_step_margin(x, lg, mc_t, mc_s, final=fin, seed=seed, sample_offset=sample_offset, step=i,
+                                  margin=diff if fin else ratio, flags=flags)
+            sus = torch.nonzero(flags).flatten()                  # (device -> host sync, B int32)
+            reruns.append(int(sus.numel()))
+            for c0 in range(0, int(sus.numel()), cap):
+                idx = sus[c0:c0 + cap]
+                xs = prev[idx].contiguous()
+                lg2 = exact.forward_logits(xs, seq[idx].contiguous(), None if tf_exact is None else tf_exact[i])
+                e = ((lg[idx] - lg2).abs().amax(-1) * (xs == STRUCTURE_MASK_TOKEN)).amax(-1)      # per re-run sample
+                err_max = max(err_max, float(e.max()))
+                violations += int((e > self.eps).sum())
+                for j, b in enumerate(idx.tolist()):
+                    exact.ddpm_step(xs[j:j + 1], lg2[j:j + 1], mc_t, mc_s, final=fin, seed=seed,
+                                    sample_offset=sample_offset + b, step=i)
+                x[idx] = xs
+        self.stats = {"samples": B, "updates": len(reruns), "eps": self.eps, "rerun_per_update": reruns,
+                      "max_logit_err_observed": err_max, "eps_violations": violations, "first_update_shared": shared0,
+                      "sample_forwards_exact": int(sum(reruns)) + int(shared0),
+                      "sample_forwards_fast": B * (len(reruns) - int(shared0) - int(skipped_final))}
+        return x

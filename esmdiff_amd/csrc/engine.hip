@@ -1174,6 +1174,20 @@ int esmdiff_ddpm_step(esmdiff_engine* e, int64_t* x_inout, const float* logits, 
   return 0;
 }
 
+int esmdiff_ddpm_step_margin(esmdiff_engine* e, int64_t* x_inout, const float* logits, int32_t ld_logits,
+                             float mc_t, float mc_s, int32_t final_, const esmdiff_rng* rng, int32_t step,
+                             int32_t B, int32_t L, float margin, int32_t* sample_flags, void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!x_inout || !logits || !sample_flags || !rng) return fail(e, ESMDIFF_E_INVALID, "null pointer");
+  if (B <= 0 || L <= 0 || ld_logits < e->cfg.vocab_out) return fail(e, ESMDIFF_E_INVALID, "bad shape");
+  if (e->cfg.vocab_out <= ESMDIFF_MASK_ID) return fail(e, ESMDIFF_E_INVALID, "ddpm needs the 4101-way head (mask column)");
+  if (!(final_ ? margin >= 0.f : margin >= 1.f))
+    return fail(e, ESMDIFF_E_INVALID, "margin %g: a ratio >= 1 for an update, a difference >= 0 for the final pass", margin);
+  HIP_TRY(e, launch_ddpm_step(x_inout, logits, ld_logits, e->cfg.vocab_out, mc_t, mc_s, final_, nullptr, 1, rng->seed,
+                              rng->sample_offset, step, B, L, (hipStream_t)stream, 0, margin, sample_flags));
+  return 0;
+}
+
 int esmdiff_ddpm_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout, int32_t B, int32_t L, int32_t T,
                         const float* mc_t, const float* mc_s, const float* t_freq, const esmdiff_rng* rng,
                         void* stream) {

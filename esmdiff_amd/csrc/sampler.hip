@@ -38,17 +38,22 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-template <int PER>
+// MARGIN (esmdiff_ddpm_step_margin): the same draw, plus the runner-up of the arg-max: sample_flags[b] is set when, for some
+// masked row of sample b, the winner does not beat the runner-up by the factor `margin` (final pass: by the difference
+// `margin`) — i.e. when a perturbation of the logits of that size could change the id.  The id written is the same bit for bit.
+template <int PER, bool MARGIN = false>
 __global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, const float* __restrict__ logits,
                                                        int ld, int V, float mc_t, float mc_s, int final_,
                                                        const float* __restrict__ u, int use_philox,
                                                        uint64_t seed, uint64_t sample_offset, int step, int L,
-                                                       int logits_period) {
+                                                       int logits_period, float margin = 0.f,
+                                                       int32_t* __restrict__ sample_flags = nullptr) {
   const int row = blockIdx.x;
   if (x[row] != MASK_ID) return;  // carry-over: copy_flag * x  (model.py:606-607)
 
   __shared__ float s_red[8];
   __shared__ int s_idx[4];
+  __shared__ float s_sec[4];
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   // logits_period > 0: sample b reads the logits of sample b % logits_period (step-0 sharing: every sample of the batch
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, 
   const float d = mc_t - mc_s;
   const int b = row / L, l = row - b * L;
   const float* urow = u ? u + (int64_t)row * V : nullptr;
-  float best = -3.402823466e38f;
+  float best = -3.402823466e38f, second = -3.402823466e38f;
   int best_i = 0x7fffffff;
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
@@ -111,8 +116,11 @@ __global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, 
         val = q / g;
       }
       if (best_i == 0x7fffffff || val > best) {
+        if constexpr (MARGIN) second = best_i == 0x7fffffff ? second : best;
         best = val;
         best_i = v;
+      } else if constexpr (MARGIN) {
+        second = fmaxf(second, val);
       }
     }
   }
@@ -121,6 +129,10 @@ __global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, 
   for (int off = 32; off >= 1; off >>= 1) {
     const float ob = __shfl_xor(best, off, 64);
     const int oi = __shfl_xor(best_i, off, 64);
+    if constexpr (MARGIN) {   // runner-up of the union: the smaller of the two winners, or either side's runner-up
+      const float os = __shfl_xor(second, off, 64);
+      second = fmaxf(fmaxf(second, os), fminf(best, ob));
+    }
     if (ob > best || (ob == best && oi < best_i)) {
       best = ob;
       best_i = oi;
@@ -130,32 +142,47 @@ __global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, 
   if (lane == 0) {
     s_red[wave] = best;
     s_idx[wave] = best_i;
+    if constexpr (MARGIN) s_sec[wave] = second;
   }
   __syncthreads();
   if (t == 0) {
     float bb = s_red[0];
     int bi = s_idx[0];
+    float ss = MARGIN ? s_sec[0] : 0.f;
 #pragma unroll
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 4; ++w) {
+      if constexpr (MARGIN) ss = fmaxf(fmaxf(ss, s_sec[w]), fminf(bb, s_red[w]));
       if (s_red[w] > bb || (s_red[w] == bb && s_idx[w] < bi)) {
         bb = s_red[w];
         bi = s_idx[w];
       }
+    }
     x[row] = (int64_t)bi;
+    if constexpr (MARGIN) {
+      // non-final: values are q / g > 0, the criterion is a ratio; final: log-probabilities, a difference
+      const bool safe = final_ ? (bb - ss > margin) : (bb > ss * margin);
+      if (!safe) sample_flags[row / L] = 1;    // (benign race: every writer stores 1)
+    }
   }
 }
 
 hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, float mc_t, float mc_s, int final_,
                             const float* u, int use_philox, uint64_t seed, uint64_t sample_offset, int step,
-                            int B, int L, hipStream_t stream, int logits_period) {
+                            int B, int L, hipStream_t stream, int logits_period, float margin, int32_t* sample_flags) {
   const int rows = B * L;
   if (rows <= 0) return hipSuccess;
   const int per = (V + NT - 1) / NT;
   if (per > MAX_PER_THREAD) return hipErrorInvalidValue;
   dim3 grid(rows), block(NT);
-#define ED_LAUNCH(P)                                                                                       \
-  hipLaunchKernelGGL(ddpm_step_kernel<P>, grid, block, 0, stream, x, logits, ld, V, mc_t, mc_s, final_, u, \
-                     use_philox, seed, sample_offset, step, L, logits_period)
+#define ED_LAUNCH(P)                                                                                                       \
+  do {                                                                                                                     \
+    if (sample_flags)                                                                                                      \
+      hipLaunchKernelGGL((ddpm_step_kernel<P, true>), grid, block, 0, stream, x, logits, ld, V, mc_t, mc_s, final_, u,     \
+                         use_philox, seed, sample_offset, step, L, logits_period, margin, sample_flags);                   \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((ddpm_step_kernel<P, false>), grid, block, 0, stream, x, logits, ld, V, mc_t, mc_s, final_, u,    \
+                         use_philox, seed, sample_offset, step, L, logits_period, 0.f, nullptr);                           \
+  } while (0)
   if (per <= 1) ED_LAUNCH(1);
   else if (per <= 4) ED_LAUNCH(4);
   else if (per <= 17) ED_LAUNCH(17);

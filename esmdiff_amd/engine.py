@@ -185,6 +185,22 @@ class Engine:
                                               B, L, _stream()))
         return x
 
+    def ddpm_step_margin(self, x: torch.Tensor, logits: torch.Tensor, mc_t: float, mc_s: float, *, final: bool,
+                         seed: int, sample_offset: int, step: int, margin: float, flags: torch.Tensor) -> torch.Tensor:
+        """ddpm_step (Philox noise) that also sets flags[b] = 1 (int32 [B], zeroed by the caller) when some masked row of
+        sample b was decided by less than `margin` (esmdiff_ddpm_step_margin; used by certified.py)."""
+        B, L = x.shape
+        assert x.dtype == torch.int64 and x.is_cuda and x.is_contiguous()
+        assert logits.dtype == torch.float32 and logits.is_cuda and logits.stride(-1) == 1
+        ld = logits.stride(1)
+        assert logits.stride(0) == ld * L and ld >= STRUCTURE_VOCAB
+        assert flags.dtype == torch.int32 and flags.is_cuda and flags.numel() == B and flags.is_contiguous()
+        rng = N.Rng(int(seed), int(sample_offset))
+        self._chk(self._lib.esmdiff_ddpm_step_margin(self._h, _ptr(x), _ptr(logits), ld, float(mc_t), float(mc_s), int(final),
+                                                     ctypes.byref(rng), int(step), B, L, float(margin), _ptr(flags),
+                                                     _stream()))
+        return x
+
     def ddpm_sample(self, sequence_tokens: torch.Tensor, schedule: DDPMSchedule, *, seed: int,
                     sample_offset: int = 0, input_prior: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Whole ancestral sampling loop on the device with Philox noise (esmdiff_ddpm_sample)."""

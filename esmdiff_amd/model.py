@@ -38,8 +38,19 @@ class MaskedDiffusionLanguageModeling:
         self.vocab_size = STRUCTURE_VOCAB
         self.mask_index = STRUCTURE_MASK_TOKEN
         self.neg_infinity = -1000000.0
-        self.net = Engine(cfg, state_dict, max_batch=max_batch, max_len=max_len, device=device, precision=precision,
-                          head_precision=head_precision)
+        # precision="certified": the f32-grade engine is `net` (every generic path — parity noise, gibbs, _model_wrapper — runs on
+        # it); the Philox ddpm loop draws on an f16 engine and re-runs only the close calls on `net` (certified.py): the ids of the
+        # F32_SPLIT chain at about twice its rate
+        self.certified = None
+        if precision == "certified":
+            from .certified import CertifiedSampler
+            self.net = Engine(cfg, state_dict, max_batch=max_batch, max_len=max_len, device=device, precision="f32_split")
+            self.fast = Engine(cfg, state_dict, max_batch=max_batch, max_len=max_len, device=device, precision="f16",
+                               head_precision=head_precision)
+            self.certified = CertifiedSampler(self.fast, self.net)
+        else:
+            self.net = Engine(cfg, state_dict, max_batch=max_batch, max_len=max_len, device=device, precision=precision,
+                              head_precision=head_precision)
         # exact step-0 sharing (include/esmdiff_hip.h): the CLI repeats ONE sequence per batch, so the first forward of a run has
         # identical rows; the engine checks that on the device and then serves all samples from a sub-batch forward — ids are
         # bit-identical to the unshared loop (tests/test_gpu_fullwidth.py::test_step0_sharing_is_exact).  bench.py's headline
@@ -122,8 +133,8 @@ class MaskedDiffusionLanguageModeling:
         sch = ddpm_schedule(num_steps, eps, sample_max_t, self.noise, self.cfg.freq_dim)
         B, L = sequence_tokens.shape
         if noise == "philox" and self.noise_removal:
-            return self.net.ddpm_sample(sequence_tokens, sch, seed=seed, sample_offset=sample_offset,
-                                        input_prior=input_prior)
+            loop = self.certified if self.certified is not None else self.net
+            return loop.ddpm_sample(sequence_tokens, sch, seed=seed, sample_offset=sample_offset, input_prior=input_prior)
         # step-by-step drive (parity mode / noise_removal off)
         seq = sequence_tokens.to(self.device)
         x = (self._sample_prior(B, L) if input_prior is None else input_prior.clone()).to(self.device).contiguous()

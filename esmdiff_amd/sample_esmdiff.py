@@ -207,7 +207,7 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
         (output_dir / f"{sample_basename}.json").write_text(json.dumps(
             {"sequence": sequence, "num_steps": num_steps, "num_samples": num_samples, "eps": eps, "seed": seed,
              "noise": noise, "world_size": world, "sampling_seconds": round(sample_t, 3),
-             "precision": getattr(getattr(model, "net", model), "precision", None),
+             "precision": "certified" if getattr(model, "certified", None) is not None else getattr(getattr(model, "net", model), "precision", None),
              "decoder_precision": getattr(decoder, "precision", None),
              **({} if ptm is None else {"ptm": [round(float(v), 4) for v in ptm.cpu()]})}, indent=1))
         if coords is not None:
@@ -325,11 +325,12 @@ def get_argparser(argv=None):
     p.add_argument("--synthetic_len", type=int, default=0, help="sample a random sequence of this length")
     p.add_argument("--n_max_residue_square", type=int, default=DEFAULT_NMAX)
     p.add_argument("--parity", action="store_true", help="uniforms from torch's CPU generator, like the reference")
-    p.add_argument("--precision", choices=["bf16", "f16", "f32", "f32_split"], default="bf16",
+    p.add_argument("--precision", choices=["bf16", "f16", "f32", "f32_split", "certified"], default="bf16",
                    help="arithmetic of the sampling network: bf16 = the MFMA throughput path (default); f32 = the strict path, the "
                         "reference's own float32 arithmetic on the f32-input MFMA (ids equal to a float32 run of the same seed; ~1/12 "
                         "of the throughput); f32_split = float32-grade linears as three f16 MFMA passes over split operands (~1/4); f16 = the "
-                        "bf16 path with IEEE-half operands (same speed, 1/8 of the rounding error)")
+                        "bf16 path with IEEE-half operands (same speed, 1/8 of the rounding error); certified = the f16 engine draws and only the "
+                        "samples with a close call are re-run on an f32_split engine for that update: the f32_split chain's ids at ~2x its rate")
     p.add_argument("--head_precision", choices=["bf16", "f32"], default="bf16",
                    help="bf16 network only: final LayerNorm + output head in float32 grade (+1 %% time, fewer near-tie flips)")
     p.add_argument("--decoder_precision", choices=["f32", "f32_split", "bf16"], default="f32",

@@ -157,6 +157,17 @@ int esmdiff_ddpm_step(esmdiff_engine* eng, int64_t* x_inout, const float* logits
                       float move_chance_t, float move_chance_s, int32_t final, const float* u,
                       const esmdiff_rng* rng, int32_t step, int32_t B, int32_t L, void* stream);
 
+/* esmdiff_ddpm_step with the Philox source, plus a per-sample report of how close the draw was: sample_flags[b]
+ * (device int32 [B], zeroed by the caller) is set to 1 when some masked row of sample b was decided by less than `margin`
+ * — update (final == 0): winner <= margin * runner-up of q_v / g_v (margin = exp(2 eps) covers logits known to +-eps:
+ * between two tokens the logsumexp cancels and z_a - z_b moves by at most 2 eps; against the mask column z_a moves by
+ * eps and the logsumexp by eps); final pass: winner - runner-up <= margin in log-probability (margin = 2 eps).  An unflagged sample's ids are the ids ANY logits within eps of these
+ * would have produced.  The ids written are those of esmdiff_ddpm_step, bit for bit.  No reference counterpart: it is
+ * what lets a reduced-precision engine hand the few close calls to an f32-grade one (esmdiff_amd/certified.py). */
+int esmdiff_ddpm_step_margin(esmdiff_engine* eng, int64_t* x_inout, const float* logits, int32_t ld_logits,
+                             float move_chance_t, float move_chance_s, int32_t final, const esmdiff_rng* rng,
+                             int32_t step, int32_t B, int32_t L, float margin, int32_t* sample_flags, void* stream);
+
 /* Replaces MaskedDiffusionLanguageModeling.ddpm_sample (model.py:543-581) for one batch, entirely on
  * the device, Philox noise: T updates + the noise-removal pass.  x_inout holds the prior on entry
  * (all MASK, model.py:555, or input_prior, :561) and the sample on return.

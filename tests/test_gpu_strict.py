@@ -451,6 +451,12 @@ def test_cli_precision_flags(tmp_path):
     out4 = tmp_path / "f16"
     main([a if a != str(tmp_path) else str(out4) for a in common[:-2]] + ["--precision", "f16", "--head_precision", "f32", "--mode", "ddpm"])
     assert json.loads((out4 / "step4_eps1e-05_N3" / "synthetic30.json").read_text())["precision"] == "f16"
+    # certified: the f16 engine draws, close calls re-run on F32_SPLIT -> the exact-f32 run's ids again
+    out5 = tmp_path / "cert"
+    main([a if a != str(tmp_path) else str(out5) for a in common[:-2]] + ["--precision", "certified", "--mode", "ddpm"])
+    d5 = out5 / "step4_eps1e-05_N3"
+    assert json.loads((d5 / "synthetic30.json").read_text())["precision"] == "certified"
+    assert np.array_equal(np.load(d5 / "synthetic30.tokens.npy"), ids_f32)
     assert np.load(out4 / "step4_eps1e-05_N3" / "synthetic30.tokens.npy").shape == (3, 30)
 
 
@@ -729,6 +735,111 @@ def test_bf16_vs_float32_chain_configs1_full_batch():
     assert out["f16_f32head"]["flip_rate_per_masked_draw"] <= 5e-5 and out["f16_f32head"]["samples_fully_identical"] >= 85, out["f16_f32head"]
     # F32_SPLIT: float32-grade arithmetic end to end
     assert out["f32_split"]["flip_rate_per_masked_draw"] < 1e-5 and out["f32_split"]["samples_fully_identical"] >= 97, out["f32_split"]
+
+
+def test_ddpm_step_margin_same_ids_and_flags():
+    """esmdiff_ddpm_step_margin: the ids are esmdiff_ddpm_step's bit for bit; the per-sample flags follow the runner-up test
+    (checked against a torch restatement of the race on the same Philox uniforms via explicit `u` on the plain step)."""
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.weights import random_init_state_dict
+    from oracle import c_oracle
+    eng = Engine(TINY, random_init_state_dict(TINY, seed=2), max_batch=6, max_len=33)
+    B, L = 6, 33
+    g = torch.Generator().manual_seed(8)
+    lg = (torch.randn(B, L, V, generator=g) * 2).cuda()
+    x0 = torch.full((B, L), MASK, dtype=torch.int64)
+    x0[:, ::3] = torch.randint(0, 4096, (B, 11), generator=g)
+    x0 = x0.cuda()
+    for fin, mc_t, mc_s in ((False, 0.7, 0.55), (True, 0.0, 0.0)):
+        want = eng.ddpm_step(x0.clone(), lg, mc_t, mc_s, final=fin, seed=5, sample_offset=40, step=3)
+        # the race restated in float64 from the same uniforms: winner / runner-up per masked row
+        z = lg.double().clone()
+        z[..., MASK] -= 1e6
+        lp = torch.log_softmax(z, -1)
+        if fin:
+            val = lp
+        else:
+            u = torch.from_numpy(np.stack([np.stack([c_oracle.philox_uniforms(5, 40 + b, 3, l, V) for l in range(L)])
+                                           for b in range(B)])).cuda().double()
+            q = lp.exp() * (mc_t - mc_s)
+            q[..., MASK] = mc_s
+            val = q / (1e-10 - torch.log(u + 1e-10))
+        top2 = val.topk(2, dim=-1).values
+        masked = x0 == MASK
+        for margin in ((0.0, 0.05, 0.5, 50.0) if fin else (1.0, 1.05, 1.5, 1e6)):
+            flags = torch.zeros(B, dtype=torch.int32, device="cuda")
+            got = eng.ddpm_step_margin(x0.clone(), lg, mc_t, mc_s, final=fin, seed=5, sample_offset=40, step=3, margin=margin,
+                                       flags=flags)
+            assert torch.equal(got, want)
+            gap = (top2[..., 0] - top2[..., 1]) if fin else (top2[..., 0] / top2[..., 1])
+            # rows whose gap is within 1e-4 (relative) of the margin may fall either way in float32
+            close = masked & (gap <= margin * (1 + 1e-4) + 1e-6)
+            clear = masked & (gap <= margin * (1 - 1e-4) - 1e-6)
+            f = flags.bool().cpu()
+            assert bool((f | ~clear.any(1).cpu()).all()), (fin, margin)          # every sample with a clearly close row is flagged
+            assert bool((~f | close.any(1).cpu()).all()), (fin, margin)          # and no sample without a close row is
+    with pytest.raises(RuntimeError, match="margin"):
+        eng.ddpm_step_margin(x0.clone(), lg, 0.7, 0.55, final=False, seed=5, sample_offset=0, step=0, margin=0.5,
+                             flags=torch.zeros(B, dtype=torch.int32, device="cuda"))
+    eng.close()
+
+
+def test_certified_sampler_equals_float32_chain_configs1_full_batch():
+    """esmdiff_amd/certified.py at BASELINE configs[1]'s full size (100 samples x 256 residues, 25 updates, 48 blocks): a
+    reduced-precision engine draws, the sampler kernel flags the samples with a close call, those are re-run for that one update
+    on the F32_SPLIT engine.  THE REFEREE IS THE EXACT-F32 ENGINE's chain (precision="f32").  Bar: every id of every sample equal
+    — for the f16 engine at the default eps = 4e-3 and for the bf16 engine at eps = 0.03 (its logit error is 8x larger) — with the
+    share of re-run sample-forwards and the wall time recorded."""
+    import time
+    from esmdiff_amd.certified import CertifiedSampler
+    from esmdiff_amd.config import ESM3_OPEN
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ESM3_OPEN
+    sd = random_init_state_dict(cfg, seed=11, device="cuda")
+    B, L, T = 100, 258, 25
+    g = torch.Generator().manual_seed(258)
+    seq = _seq(B, L, g).cuda()
+    sch = ddpm_schedule(T, freq_dim=cfg.freq_dim)
+    strict = Engine(cfg, sd, max_batch=B, max_len=L, precision="f32")
+    ref = strict.ddpm_sample(seq, sch, seed=23)
+    strict.close()
+    exact = Engine(cfg, sd, max_batch=B, max_len=L, precision="f32_split")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    sp = exact.ddpm_sample(seq, sch, seed=23)
+    torch.cuda.synchronize(); t_split = time.perf_counter() - t0
+    out = {"B": B, "L_tok": L, "steps": T, "referee": "exact-f32 engine chain", "f32_split_alone_seconds": round(t_split, 2),
+           "f32_split_alone_equal": bool(torch.equal(sp, ref))}
+    for name, kw, eps in (("f16", {"precision": "f16"}, 4e-3), ("f16_f32head", {"precision": "f16", "head_precision": "f32"}, 2.5e-3),
+                          ("bf16", {}, 0.03)):
+        fast = Engine(cfg, sd, max_batch=B, max_len=L, **kw)
+        cs = CertifiedSampler(fast, exact, eps=eps)
+        cs.ddpm_sample(seq, sch, seed=23)                                          # warm-up (allocator, clocks)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        got = cs.ddpm_sample(seq, sch, seed=23)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        plain = fast.ddpm_sample(seq, sch, seed=23)
+        fast.close()
+        st = cs.stats
+        out[name] = {"eps": eps, "ids_equal_to_f32_chain": bool(torch.equal(got, ref)),
+                     "samples_identical": int((got == ref).all(1).sum()),
+                     "uncertified_samples_identical": int((plain == ref).all(1).sum()),
+                     "seconds": round(dt, 2), "samples_per_s": round(B / dt, 2),
+                     "sample_forwards_exact": st["sample_forwards_exact"], "sample_forwards_fast": st["sample_forwards_fast"],
+                     "rerun_share": round(st["sample_forwards_exact"] / st["sample_forwards_fast"], 4),
+                     "max_logit_err_observed": st["max_logit_err_observed"], "eps_violations": st["eps_violations"],
+                     "rerun_per_update": st["rerun_per_update"]}
+    exact.close()
+    del sd
+    _record("certified_configs1_full_batch", out)
+    assert out["f32_split_alone_equal"], out
+    for name in ("f16", "f16_f32head", "bf16"):
+        assert out[name]["ids_equal_to_f32_chain"] and out[name]["eps_violations"] == 0, out[name]
+    # measured: f16 14 % re-runs, largest logit error seen 2.1e-3 (eps 4e-3); with the float32 head 1.3e-3 (eps 2.5e-3)
+    assert out["f16"]["rerun_share"] < 0.2 and out["f16"]["max_logit_err_observed"] < 3e-3, out["f16"]
+    assert out["f16_f32head"]["max_logit_err_observed"] < 2e-3, out["f16_f32head"]
 
 
 def test_model_wrapper_semantics_vs_reference_parameterization():
