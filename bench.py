@@ -589,15 +589,15 @@ def main():
                               "power": pw(pw_alt), "headline_engine_power": pw(pw_base),
                               "what": "same workload, labelled extra — NOT the headline value"}
 
-    # One more LABELLED figure: certified sampling (esmdiff_amd/certified.py) — the f16 engine draws, the sampler kernel flags
+    # One more LABELLED figure: certified sampling (esmdiff_amd/certified.py) — the f16 engine (f32-grade head) draws, the sampler kernel flags
     # the samples with a close call (winner within exp(2 eps) of the runner-up), those are re-run for that update on an
     # F32_SPLIT engine.  Ids are compared here with the F32_SPLIT engine's own chain for the same seed.
     cert_rec = None
-    if alt_engines.get("f16") is not None and args.mode == "ddpm" and not args.inpaint:
+    if alt_engines.get("f16_head_f32") is not None and args.mode == "ddpm" and not args.inpaint:
         from esmdiff_amd.certified import CertifiedSampler
         from esmdiff_amd.engine import Engine
         ex = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank, precision="f32_split")
-        cs = CertifiedSampler(alt_engines["f16"], ex)
+        cs = CertifiedSampler(alt_engines["f16_head_f32"], ex)
         cs.ddpm_sample(seq, sch, seed=args.seed + 1000, sample_offset=rank * B)
         sync_local()
         ks, got = 2, []
@@ -611,9 +611,11 @@ def main():
         want = ex.ddpm_sample(seq, sch, seed=args.seed, sample_offset=rank * B)
         sync_local()
         tc2 = time.perf_counter()
-        plain = alt_engines["f16"].ddpm_sample(seq, sch, seed=args.seed, sample_offset=rank * B)
-        cert_rec = {"value": round(B * ks / (tc1 - tc0), 3), "unit": "samples/s", "steps": ks, "eps": cs.eps,
-                    "fast_engine": "f16", "exact_engine": "f32_split",
+        plain = alt_engines["f16_head_f32"].ddpm_sample(seq, sch, seed=args.seed, sample_offset=rank * B)
+        cert_rec = {"value": round(B * ks / (tc1 - tc0), 3), "unit": "samples/s", "steps": ks,
+                    "eps": "auto: 2.0 x the largest logit error observed so far",
+                    "eps_used": [min(s_["eps_min_used"] for s_ in stats), max(s_["eps_max_used"] for s_ in stats)],
+                    "fast_engine": "f16 + f32-grade head", "exact_engine": "f32_split",
                     "f32_split_engine_alone_same_session": round(B / (tc2 - tc1), 3),
                     "ids_equal_to_f32_split_chain": bool(torch.equal(got[0], want)),
                     "samples_identical_without_certification": int((plain == want).all(1).sum()),

@@ -11,13 +11,15 @@ per sample, whether all of its draws were that clear (esmdiff_ddpm_step_margin, 
 a close call are run again through the f32-grade engine for that one update (same tokens in, same Philox keys) and take
 its ids.
 
-`eps` is a bound on the fast engine's logit error against f32, and it is an EMPIRICAL one (tests/test_gpu_kernels.py
-measures max |err| 1.7e-3 for the f16 engine at production width; the default 4e-3 leaves a factor 2.4): the result is
-"the f32 chain's ids unless a logit was off by more than eps", which tests/test_gpu_strict.py checks at configs[1]'s full
-size (100 samples, 335 340 draws: all ids equal).  The assumption is monitored while sampling: every re-run yields the
-fast and the f32-grade logits of the same input, and stats["max_logit_err_observed"] is their largest difference over
-the masked rows (stats["eps_violations"] counts re-run samples that exceeded eps).  No reference counterpart — the
-reference has one precision.
+`eps` is a bound on the fast engine's logit error against f32, and it is an EMPIRICAL one: the result is "the f32 chain's
+ids unless a logit was off by more than eps", which tests/test_gpu_strict.py checks at configs[1]'s full size (100
+samples, 335 340 draws: all ids equal).  It is measured while sampling: every re-run yields the fast and the f32-grade
+logits of the same input (258 x 4101 of them per sample), `max_logit_err_observed` is their largest difference over the
+masked rows, and with eps=None (the default) the bound used for the NEXT update is `safety` (2.0) x the largest error
+seen so far by this engine pair — the logit scale of a checkpoint, and with it the error, is not known in advance (random
+init: logit std 0.6, f16 error up to 2.1e-3; with the f32-grade head 1.3e-3).  Before the first certified update two
+samples are run on both engines to start the estimate.  stats["eps_violations"] counts re-run samples whose error
+exceeded the eps their update was certified with.  No reference counterpart — the reference has one precision.
 """
 from __future__ import annotations
 
@@ -35,13 +37,29 @@ class CertifiedSampler:
     """fast: a reduced-precision Engine (f16 recommended: its logit error is 8x below bf16's, so 8x fewer close calls);
     exact: an f32-grade Engine of the same checkpoint (precision 'f32_split' or 'f32')."""
 
-    def __init__(self, fast: Engine, exact: Engine, eps: float = 4e-3):
+    def __init__(self, fast: Engine, exact: Engine, eps: Optional[float] = None, safety: float = 2.0, eps_floor: float = 1e-5):
         if fast.device != exact.device:
             raise ValueError("both engines must live on the same GPU")
-        if not eps > 0:
+        if eps is not None and not eps > 0:
             raise ValueError("eps must be positive")
-        self.fast, self.exact, self.eps = fast, exact, float(eps)
+        if not safety >= 1.0:
+            raise ValueError("safety must be >= 1")
+        self.fast, self.exact = fast, exact
+        self.eps = None if eps is None else float(eps)          # None: safety x the largest error observed so far
+        self.safety, self.eps_floor = float(safety), float(eps_floor)
+        self.err_seen = 0.0                                     # largest |fast - exact| logit over masked rows, all calls
+        self.n_seen = 0                                         # sample-forwards that estimate rests on
         self.stats: dict = {}
+
+    def _eps_now(self) -> float:
+        return self.eps if self.eps is not None else max(self.eps_floor, self.safety * self.err_seen)
+
+    def _observe(self, lg_fast: torch.Tensor, lg_exact: torch.Tensor, x_in: torch.Tensor) -> torch.Tensor:
+        """Largest logit difference per sample over its masked rows; feeds the running estimate."""
+        e = ((lg_fast - lg_exact).abs().amax(-1) * (x_in == STRUCTURE_MASK_TOKEN)).amax(-1)
+        self.err_seen = max(self.err_seen, float(e.max()))
+        self.n_seen += int(e.numel())
+        return e
 
     @torch.no_grad()
     def ddpm_sample(self, sequence_tokens: torch.Tensor, schedule: DDPMSchedule, *, seed: int, sample_offset: int = 0,
@@ -60,12 +78,11 @@ class CertifiedSampler:
         T = schedule.num_steps
         tf_fast = fast.conditioning_rows(schedule.t_freq)
         tf_exact = exact.conditioning_rows(schedule.t_freq)
-        ratio, diff = math.exp(2.0 * self.eps), 2.0 * self.eps
         flags = torch.zeros(B, dtype=torch.int32, device=dev)
         logits = torch.empty(B, L, fast.ld_logits, dtype=torch.float32, device=dev)
         cap = exact.max_batch
         reruns = []
-        err_max, violations, skipped_final = 0.0, 0, False
+        err_max, violations, skipped_final, probes, eps_used = 0.0, 0, False, 0, []
         V = exact.cfg.n_structure_heads
         shared0 = input_prior is None and B > 1 and bool((seq == seq[:1]).all())
         for i in range(T + 1):
@@ -74,19 +91,33 @@ class CertifiedSampler:
                 # every sample enters the first update with the same inputs (all-mask prior, one protein): ONE f32-grade
                 # forward serves them all, nothing to certify (the device loop's step-0 sharing, engine.hip)
                 lg1 = exact.forward_logits(x[:1], seq[:1], None if tf_exact is None else tf_exact[0])
+                if self.eps is None and self.n_seen == 0:          # start the error estimate on the same input
+                    lgf = fast.forward_logits(x[:1], seq[:1], None if tf_fast is None else tf_fast[0])
+                    err_max = max(err_max, float(self._observe(lgf, lg1, x[:1]).max()))
+                    probes += 1
                 logits[..., :V] = lg1
                 exact.ddpm_step(x, logits[..., :V], float(schedule.mc_t[0]), float(schedule.mc_s[0]), seed=seed,
                                 sample_offset=sample_offset, step=0)
                 reruns.append(0)
+                eps_used.append(None)
                 continue
             if fin and not bool((x == STRUCTURE_MASK_TOKEN).any()):
                 reruns.append(0)                                  # nothing left to denoise: the pass is the identity
+                eps_used.append(None)
                 skipped_final = True
                 break
             mc_t = 0.0 if fin else float(schedule.mc_t[i])
             mc_s = 0.0 if fin else float(schedule.mc_s[i])
             prev = x.clone()
             lg = fast.forward_logits(x, seq, None if tf_fast is None else tf_fast[i], out=logits)
+            if self.eps is None and self.n_seen < 3:              # thin estimate: two samples on both engines first
+                n = min(2, B)
+                lgp = exact.forward_logits(prev[:n], seq[:n], None if tf_exact is None else tf_exact[i])
+                err_max = max(err_max, float(self._observe(lg[:n], lgp, prev[:n]).max()))
+                probes += n
+            eps_i = self._eps_now()
+            eps_used.append(eps_i)
+            ratio, diff = math.exp(2.0 * eps_i), 2.0 * eps_i
             flags.zero_()
             fast.ddpm_step_margin(x, lg, mc_t, mc_s, final=fin, seed=seed, sample_offset=sample_offset, step=i,
                                   margin=diff if fin else ratio, flags=flags)
@@ -96,15 +127,18 @@ class CertifiedSampler:
                 idx = sus[c0:c0 + cap]
                 xs = prev[idx].contiguous()
                 lg2 = exact.forward_logits(xs, seq[idx].contiguous(), None if tf_exact is None else tf_exact[i])
-                e = ((lg[idx] - lg2).abs().amax(-1) * (xs == STRUCTURE_MASK_TOKEN)).amax(-1)      # per re-run sample
+                e = self._observe(lg[idx], lg2, xs)               # per re-run sample
                 err_max = max(err_max, float(e.max()))
-                violations += int((e > self.eps).sum())
+                violations += int((e > eps_i).sum())
                 for j, b in enumerate(idx.tolist()):
                     exact.ddpm_step(xs[j:j + 1], lg2[j:j + 1], mc_t, mc_s, final=fin, seed=seed,
                                     sample_offset=sample_offset + b, step=i)
                 x[idx] = xs
-        self.stats = {"samples": B, "updates": len(reruns), "eps": self.eps, "rerun_per_update": reruns,
-                      "max_logit_err_observed": err_max, "eps_violations": violations, "first_update_shared": shared0,
-                      "sample_forwards_exact": int(sum(reruns)) + int(shared0),
+        used = [e_ for e_ in eps_used if e_ is not None]
+        self.stats = {"samples": B, "updates": len(reruns), "eps": self.eps if self.eps is not None else "auto",
+                      "safety": self.safety, "eps_min_used": min(used) if used else None, "eps_max_used": max(used) if used else None,
+                      "rerun_per_update": reruns, "max_logit_err_observed": err_max, "max_logit_err_all_calls": self.err_seen,
+                      "eps_violations": violations, "first_update_shared": shared0,
+                      "sample_forwards_exact": int(sum(reruns)) + int(shared0) + (probes if not shared0 else 0),
                       "sample_forwards_fast": B * (len(reruns) - int(shared0) - int(skipped_final))}
         return x
