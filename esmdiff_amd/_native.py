@@ -48,7 +48,7 @@ EXPORTS = [
     "esmdiff_metrics_bonding_validity", "esmdiff_metrics_pwd", "esmdiff_metrics_js_columns", "esmdiff_encoder_create", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error",
     "esmdiff_encoder_encode", "esmdiff_gemm_f32", "esmdiff_set_step0_sharing", "esmdiff_get_counters",
     "esmdiff_set_gibbs_options", "esmdiff_split_rows", "esmdiff_split_weight", "esmdiff_gemm_split",
-    "esmdiff_get_embeddings", "esmdiff_set_final_skip", "esmdiff_gemm_f16", "esmdiff_ddpm_step_margin",
+    "esmdiff_get_embeddings", "esmdiff_set_final_skip", "esmdiff_gemm_f16", "esmdiff_ddpm_step_margin", "esmdiff_forward_logits_sigmas",
 ]
 
 
@@ -81,6 +81,8 @@ def lib():
     L.esmdiff_last_error.argtypes = [vp]
     L.esmdiff_last_error.restype = ctypes.c_char_p
     L.esmdiff_forward_logits.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.esmdiff_forward_logits_sigmas.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    L.esmdiff_forward_logits_sigmas.restype = ctypes.c_int
     L.esmdiff_ddpm_step.argtypes = [vp, vp, vp, i32, f32, f32, i32, vp, ctypes.POINTER(Rng), i32, i32, i32, vp]
     L.esmdiff_ddpm_step_margin.argtypes = [vp, vp, vp, i32, f32, f32, i32, ctypes.POINTER(Rng), i32, i32, i32, f32, vp, vp]
     L.esmdiff_ddpm_step_margin.restype = ctypes.c_int

@@ -5,7 +5,8 @@
 // collapses to  x[b,l] = E_seq[seq] + E_struct[struct'] + c, where c is one constant vector (built at
 // engine create from plddt_projection / structure_per_res_plddt_projection / ss8_embed / sasa_embed)
 // and struct' has BOS/PAD/EOS/chainbreak forced from the sequence track (net.py:445-454).  The
-// time-conditioning vector (auxiliary_embeddings, identical for all rows: model.py:466-471) is added in
+// time-conditioning vector (auxiliary_embeddings: sigma_embedder(sigma) tiled over the rows of a sample, model.py:466-471;
+// one vector for the whole batch in the sampling loop, one per sample when the caller passes per-sample sigmas) is added in
 // the same pass.
 // sigma_mlp: TimestepEmbedder.mlp (net.py:489-492): Linear -> SiLU -> Linear on the 256-d sinusoid.
 #include "kernels.h"
@@ -17,9 +18,10 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ seq, const int64_t* __restrict__ xtok,
                                                     const float* __restrict__ e_seq, const float* __restrict__ e_struct,
                                                     const float* __restrict__ cvec, const float* __restrict__ cond,
-                                                    float* __restrict__ out, int M, int D) {
+                                                    float* __restrict__ out, int M, int D, int L, int cond_stride) {
   const int row = blockIdx.x;
   if (row >= M) return;
+  if (cond) cond += (int64_t)(row / L) * cond_stride;   // cond_stride 0: one vector for all samples
   // ids are validated by the host wrapper (Engine._check_ids); a direct C-ABI caller's out-of-range id is clamped
   // here so that it can never read outside the embedding tables
   const int64_t s = min(max(seq[row], (int64_t)0), (int64_t)63);
@@ -47,13 +49,15 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
   }
 }
 
-// y[n] = act(W[n,:] · x + b[n]); one wave per output, f32.
+// y[r][n] = act(W[n,:] · x[r] + b[n]); one wave per output, f32; blockIdx.y = r (one input vector per sigma).
 template <bool SILU>
 __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                                    const float* __restrict__ x, float* __restrict__ y, int N, int K) {
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
+  x += (int64_t)blockIdx.y * K;
+  y += (int64_t)blockIdx.y * N;
   float acc = 0.f;
   for (int k = lane; k < K; k += 64) acc += W[(int64_t)n * K + k] * x[k];
 #pragma unroll
@@ -67,18 +71,20 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ W, 
 
 hipError_t launch_embed(const int64_t* seq, const int64_t* xtok, const float* e_seq, const float* e_struct,
                         const float* cvec, const float* cond, float* out, int B, int L, int D,
-                        hipStream_t stream) {
+                        hipStream_t stream, int cond_stride) {
   const int M = B * L;
   if (M <= 0) return hipSuccess;
   if (D % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(256), 0, stream, seq, xtok, e_seq, e_struct, cvec, cond, out, M, D);
+  hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(256), 0, stream, seq, xtok, e_seq, e_struct, cvec, cond, out, M, D, L,
+                     cond_stride);
   return hipGetLastError();
 }
 
 hipError_t launch_sigma_mlp(const float* t_freq, const float* w1, const float* b1, const float* w2,
-                            const float* b2, float* hidden, float* cond, int F, int D, hipStream_t stream) {
-  hipLaunchKernelGGL(gemv_kernel<true>, dim3((D + 3) / 4), dim3(256), 0, stream, w1, b1, t_freq, hidden, D, F);
-  hipLaunchKernelGGL(gemv_kernel<false>, dim3((D + 3) / 4), dim3(256), 0, stream, w2, b2, hidden, cond, D, D);
+                            const float* b2, float* hidden, float* cond, int F, int D, hipStream_t stream, int n_sigma) {
+  // t_freq [n_sigma, F] -> hidden [n_sigma, D] -> cond [n_sigma, D]
+  hipLaunchKernelGGL(gemv_kernel<true>, dim3((D + 3) / 4, n_sigma), dim3(256), 0, stream, w1, b1, t_freq, hidden, D, F);
+  hipLaunchKernelGGL(gemv_kernel<false>, dim3((D + 3) / 4, n_sigma), dim3(256), 0, stream, w2, b2, hidden, cond, D, D);
   return hipGetLastError();
 }
 

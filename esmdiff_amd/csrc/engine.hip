@@ -100,6 +100,7 @@ struct esmdiff_engine {
   float *logits = nullptr, *cond = nullptr, *sig_hidden = nullptr, *tfreq = nullptr, *g_entropy = nullptr;
   int32_t *g_sampled = nullptr, *g_nunmask = nullptr;
   int ld_logits = 0, tfreq_rows = 0;
+  int sigma_rows = 1;   // sinusoid rows the next forward reads: 1 (all samples share sigma) or B (esmdiff_forward_logits_sigmas)
   // two-stream forward: the second half of a large batch runs on `side`, forked/joined with events
   std::vector<hipStream_t> side;
   std::vector<hipEvent_t> ev_join;
@@ -404,7 +405,7 @@ static int strict_part(esmdiff_engine* e, const SPart& w, const float* cond, int
   const int B = w.B, M = B * L;
   Prof p{e, st};
   if (e->kind == 1) RUN(S_EMBED, launch_gather_rows(w.xtok, e->e_struct, w.x, M, D, ESMDIFF_VOCAB, st));
-  else RUN(S_EMBED, launch_embed(w.seq, w.xtok, e->e_seq, e->e_struct, e->cvec, cond, w.x, B, L, D, st));
+  else RUN(S_EMBED, launch_embed(w.seq, w.xtok, e->e_seq, e->e_struct, e->cvec, cond, w.x, B, L, D, st, e->sigma_rows > 1 ? D : 0));
 #define LIN(section, sw, fw, A32, lda, Kdim, out, bias, n_rows, ldc, n_valid, div, epi)                                  \
   do {                                                                                                                   \
     if (sp && (sw).w) RUN(section, launch_gemm256w4_split(a2, rs, (sw).w, (sw).inv, out, bias, M, round_up(n_rows, 256), Kdim, ldc, div, epi, st)); \
@@ -495,7 +496,8 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
   } while (0)
   const float* cond = nullptr;
   if (t_freq_dev && e->sig_w1) {
-    RUN(S_EMBED, launch_sigma_mlp(t_freq_dev, e->sig_w1, e->sig_b1, e->sig_w2, e->sig_b2, e->sig_hidden, e->cond, c.freq_dim, D, st));
+    RUN(S_EMBED, launch_sigma_mlp(t_freq_dev, e->sig_w1, e->sig_b1, e->sig_w2, e->sig_b2, e->sig_hidden, e->cond, c.freq_dim, D, st,
+                                  e->sigma_rows));
     cond = e->cond;
   }
   const bool geom = e->has_geom && e->frames_B > 0;
@@ -522,8 +524,10 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
     HIP_TRY(e, hipEventRecord(e->ev_fork, st));
     HIP_TRY(e, hipStreamWaitEvent(e->side[0], e->ev_fork, 0));
   }
-  for (int pi = 0; pi < np; ++pi)
-    if (int r = strict_part(e, parts[pi], cond, ld, L)) return r;
+  for (int pi = 0; pi < np; ++pi) {   // (per-sample sigmas: the part's first conditioning row)
+    const int64_t b0 = (int64_t)B * pi / np;
+    if (int r = strict_part(e, parts[pi], cond && e->sigma_rows > 1 ? cond + b0 * D : cond, ld, L)) return r;
+  }
   if (np > 1) {
     HIP_TRY(e, hipEventRecord(e->ev_join[0], e->side[0]));
     HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join[0], 0));
@@ -987,8 +991,8 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       TRY(dalloc(e, &e->tm_rows, Mx));
       TRY(dalloc(e, &e->ptm_dev, (size_t)cfg->max_batch));
     }
-    TRY(dalloc(e, &e->cond, (size_t)D));
-    TRY(dalloc(e, &e->sig_hidden, (size_t)D));
+    TRY(dalloc(e, &e->cond, (size_t)cfg->max_batch * D));          // one conditioning vector per sample at most
+    TRY(dalloc(e, &e->sig_hidden, (size_t)cfg->max_batch * D));
     e->tfreq_rows = 1026;
     TRY(dalloc(e, &e->tfreq, (size_t)e->tfreq_rows * F));
     TRY(dalloc(e, &e->g_entropy, Mx));
@@ -1140,6 +1144,18 @@ int esmdiff_forward_logits(esmdiff_engine* e, const int64_t* seq, const int64_t*
     return 0;
   }
   return forward(e, seq, x, t_freq, logits_out, ld_logits, B, L, (hipStream_t)stream);
+}
+
+int esmdiff_forward_logits_sigmas(esmdiff_engine* e, const int64_t* seq, const int64_t* x, const float* t_freq,
+                                  float* logits_out, int32_t ld_logits, int32_t B, int32_t L, void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!t_freq) return fail(e, ESMDIFF_E_INVALID, "null pointer (t_freq: [B, freq_dim], one sinusoid per sample)");
+  if (!e->sig_w1) return fail(e, ESMDIFF_E_INVALID, "per-sample sigmas need the sigma_embedder weights");
+  if (B <= 0 || B > e->cfg.max_batch) return fail(e, ESMDIFF_E_INVALID, "B = %d outside 1..max_batch (%d)", B, e->cfg.max_batch);
+  e->sigma_rows = B;
+  const int r = esmdiff_forward_logits(e, seq, x, t_freq, logits_out, ld_logits, B, L, stream);
+  e->sigma_rows = 1;
+  return r;
 }
 
 int esmdiff_get_embeddings(esmdiff_engine* e, float* out, int32_t B, int32_t L, void* stream) {

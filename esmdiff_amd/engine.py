@@ -142,7 +142,8 @@ class Engine:
 
     def forward_logits(self, x: torch.Tensor, sequence_tokens: torch.Tensor, t_freq: Optional[torch.Tensor],
                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """x, sequence_tokens: (B,L) int64.  t_freq: (freq_dim,) f32 sinusoid of sigma, or None.
+        """x, sequence_tokens: (B,L) int64.  t_freq: (freq_dim,) f32 sinusoid of the sigma all samples share, (B, freq_dim) for
+        one sigma per sample (esmdiff_forward_logits_sigmas), or None.
         Returns raw structure logits, a (B,L,4101) view of a (B,L,ld) float32 buffer."""
         B, L = x.shape
         x = self._tok(x, B, L)
@@ -151,8 +152,13 @@ class Engine:
         if out is None:
             out = torch.empty(B, L, self.ld_logits, dtype=torch.float32, device=self.device)
         tf = None if t_freq is None else t_freq.to(device=self.device, dtype=torch.float32).contiguous()
-        self._chk(self._lib.esmdiff_forward_logits(self._h, _ptr(seq), _ptr(x), _ptr(tf), _ptr(out), out.shape[-1],
-                                                   B, L, _stream()))
+        if tf is not None and tf.dim() == 2:
+            if tf.shape[0] != B:
+                raise ValueError(f"per-sample conditioning: {tf.shape[0]} sinusoid rows for a batch of {B}")
+            fn = self._lib.esmdiff_forward_logits_sigmas
+        else:
+            fn = self._lib.esmdiff_forward_logits
+        self._chk(fn(self._h, _ptr(seq), _ptr(x), _ptr(tf), _ptr(out), out.shape[-1], B, L, _stream()))
         return out[..., :self.cfg.n_structure_heads]
 
     def embeddings(self, B: int, L: int) -> torch.Tensor:

@@ -94,8 +94,8 @@ class MaskedDiffusionLanguageModeling:
     @torch.no_grad()
     def _model_wrapper(self, xt, sequence_tokens=None, sigma=None, shield_special_tokens: bool = False):
         """The reference's `_model_wrapper` (model.py:464-492): log-probabilities (B, L, 4101) of the SUBS parameterisation at
-        noise level `sigma` ((B,) or (B, 1); every row must carry the same value, as in the sampling loop — the engine embeds one
-        sigma per forward; None = no time conditioning at all), optionally with the five special ids shielded (:484-486).
+        noise level `sigma` ((B,) or (B, 1): one value per sample as in the reference, or a single value; None = no time
+        conditioning at all), optionally with the five special ids shielded (:484-486).
         Returns (logits, None) like the reference with sequence_prediction off; sequence_prediction is not built."""
         from .schedule import timestep_embedding
         if self.sequence_prediction:
@@ -108,10 +108,13 @@ class MaskedDiffusionLanguageModeling:
         tf = None
         if sigma is not None:
             sg = torch.as_tensor(sigma, dtype=torch.float32).reshape(-1)          # _process_sigma: squeeze
-            if sg.numel() not in (1, B) or bool((sg != sg[0]).any()):
-                raise ValueError("_model_wrapper: one sigma per call (all rows equal), as ddpm_sample passes it")
-            tf = self.net.conditioning_rows(timestep_embedding(sg[:1], self.cfg.freq_dim))
-            tf = None if tf is None else tf[0]
+            if sg.numel() not in (1, B):
+                raise ValueError(f"_model_wrapper: sigma must hold 1 or B = {B} values, got {sg.numel()}")
+            if bool((sg != sg[0]).any()):     # one sigma per sample (model.py:466-471): esmdiff_forward_logits_sigmas
+                tf = self.net.conditioning_rows(timestep_embedding(sg, self.cfg.freq_dim))
+            else:                             # what the sampling loop passes: one sigma for the whole batch
+                tf = self.net.conditioning_rows(timestep_embedding(sg[:1], self.cfg.freq_dim))
+                tf = None if tf is None else tf[0]
         raw = self.net.forward_logits(xt, sequence_tokens.to(self.device), tf)
         logits = self.logits_parameterization(raw.float(), xt)
         if shield_special_tokens:

@@ -143,6 +143,13 @@ int esmdiff_forward_logits(esmdiff_engine* eng, const int64_t* seq, const int64_
                            const float* t_freq, float* logits_out, int32_t ld_logits,
                            int32_t B, int32_t L, void* stream);
 
+/* The same forward with ONE SIGMA PER SAMPLE, as `_model_wrapper(x, sequence_tokens, sigma)` takes it (model.py:464-481: sigma is
+ * a (B,) vector, conditions = sigma_embedder(sigma) is (B, d_model), tiled over each sample's rows): t_freq = the sinusoids
+ * [B, freq_dim] (device).  The sampling loops always pass one sigma for the whole batch; this entry is for callers that mix
+ * noise levels in one batch (a training-style evaluation of the denoiser, or samples at different updates in one forward). */
+int esmdiff_forward_logits_sigmas(esmdiff_engine* eng, const int64_t* seq, const int64_t* x, const float* t_freq,
+                                  float* logits_out, int32_t ld_logits, int32_t B, int32_t L, void* stream);
+
 /* ESMOutput.embeddings of the forward that just ran (net.py:468-469, :312-320: the transformer stack's pre-norm hidden
  * state, the second value `self.transformer(...)` returns): out f32 [B,L,d_model].  (B, L) must be the last forward's. */
 int esmdiff_get_embeddings(esmdiff_engine* eng, float* out, int32_t B, int32_t L, void* stream);

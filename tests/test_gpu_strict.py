@@ -737,6 +737,60 @@ def test_bf16_vs_float32_chain_configs1_full_batch():
     assert out["f32_split"]["flip_rate_per_masked_draw"] < 1e-5 and out["f32_split"]["samples_fully_identical"] >= 97, out["f32_split"]
 
 
+@pytest.mark.parametrize("precision", ["bf16", "f16", "f32", "f32_split"])
+def test_forward_with_one_sigma_per_sample(precision):
+    """`_model_wrapper(x, seq, sigma)` with a (B,) sigma of DIFFERENT values (model.py:464-481: conditions = sigma_embedder(sigma),
+    one row per sample): esmdiff_forward_logits_sigmas.  Each sample's logits must be those of a forward of that sample alone at its
+    own sigma — bit for bit on the float32-grade engines (row results do not depend on the batch), within the 16-bit engines' error
+    otherwise — and the float32-grade result within round-off of the oracle network conditioned per sample.  B = 5 at L = 40 also
+    crosses no two-stream cut; a second shape (B = 40, L = 258 tokens, 10 320 tokens) runs the two-stream forward, where the second
+    sub-batch must read ITS samples' conditioning rows."""
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.model import MaskedDiffusionLanguageModeling
+    from esmdiff_amd.schedule import LogLinearNoise, timestep_embedding
+    from esmdiff_amd.weights import random_init_state_dict
+    from oracle.esm3_ref import build_from_state_dict
+    sd = random_init_state_dict(TINY, seed=4)
+    model = MaskedDiffusionLanguageModeling(sd, TINY, LogLinearNoise(), max_batch=40, max_len=258, device=0, precision=precision)
+    eng = model.net
+    net, emb = build_from_state_dict(TINY, sd)
+    exact = precision in ("f32", "f32_split")
+    for B, L in ((5, 40), (40, 258)):
+        g = torch.Generator().manual_seed(B)
+        seq = _seq(B, L, g)
+        xt = torch.full((B, L), MASK, dtype=torch.int64)
+        xt[:, 3:17] = torch.randint(0, 4096, (B, 14), generator=g)
+        sigma = torch.linspace(0.05, 6.9, B)
+        tf = timestep_embedding(sigma, TINY.freq_dim)
+        got = eng.forward_logits(xt.cuda(), seq.cuda(), tf).clone()
+        worst = 0.0
+        for b in (range(B) if B <= 8 else (0, 1, B // 2 - 1, B // 2, B - 1)):
+            alone = eng.forward_logits(xt[b:b + 1].cuda(), seq[b:b + 1].cuda(), tf[b])
+            if exact:
+                assert torch.equal(got[b:b + 1], alone), (precision, B, b)
+            else:
+                worst = max(worst, float((got[b:b + 1] - alone).abs().max()))
+        assert worst < 0.02, (precision, worst)                    # (16-bit engines: batch-size dependent GEMM paths)
+        if B <= 8:
+            with torch.no_grad():
+                cond = emb(sigma)[:, None, :].expand(B, L, -1)
+                ref = net(structure_tokens=xt, sequence_tokens=seq, auxiliary_embeddings=cond).structure_logits
+            err = float((got.cpu() - ref).abs().max())
+            assert err < (5e-5 if exact else 0.05), (precision, err)
+            # and the wrapper: per-sample sigma in, SUBS log-probabilities out; masked rows normalised
+            lp, none = model._model_wrapper(xt, seq, sigma[:, None])
+            assert none is None and torch.allclose(torch.logsumexp(lp[xt.cuda() == MASK], -1), torch.zeros(1, device="cuda"), atol=1e-4)
+            same, _ = model._model_wrapper(xt, seq, sigma[2].repeat(B))          # all equal -> the shared-sigma entry
+            one, _ = model._model_wrapper(xt[2:3], seq[2:3], sigma[2:3])
+            if exact:
+                assert torch.equal(same[2:3], one) and torch.equal(lp[2:3], one)
+    with pytest.raises(ValueError, match="sinusoid rows"):
+        eng.forward_logits(xt.cuda(), seq.cuda(), tf[:3])
+    with pytest.raises(ValueError, match="1 or B"):
+        model._model_wrapper(xt, seq, sigma[:3])
+    eng.close()
+
+
 def test_ddpm_step_margin_same_ids_and_flags():
     """esmdiff_ddpm_step_margin: the ids are esmdiff_ddpm_step's bit for bit; the per-sample flags follow the runner-up test
     (checked against a torch restatement of the race on the same Philox uniforms via explicit `u` on the plain step)."""
@@ -883,8 +937,8 @@ def test_model_wrapper_semantics_vs_reference_parameterization():
     sh, _ = model._model_wrapper(xt, seq, sigma, shield_special_tokens=True)
     assert torch.equal(sh.cpu()[..., :4096], got[..., :4096])
     assert float((sh.cpu()[..., 4096:] - (got[..., 4096:] - 1e6)).abs().max()) < 1.0    # (-1e6 + -1e6 in float32)
-    with pytest.raises(ValueError):
-        model._model_wrapper(xt, seq, torch.tensor([0.1, 0.2, 0.3]))
+    with pytest.raises(ValueError):                                   # B = 3: a sigma vector must hold 1 or 3 values
+        model._model_wrapper(xt, seq, torch.tensor([0.1, 0.2]))
     model.sequence_prediction = True
     with pytest.raises(NotImplementedError):
         model._model_wrapper(xt, seq, sigma)
