@@ -19,7 +19,7 @@ import torch
 from .config import ESM3_OPEN, ModelConfig
 from .constants import STRUCTURE_MASK_TOKEN, STRUCTURE_VOCAB
 from .engine import Engine
-from .schedule import CosineNoise, LogLinearNoise, Noise, ddpm_schedule
+from .schedule import CosineNoise, CosineSqrNoise, GeometricNoise, Linear, LogLinearNoise, Noise, ddpm_schedule
 from .weights import load_checkpoint_state_dict, random_init_state_dict
 
 
@@ -176,10 +176,14 @@ def config_from_hydra_yaml(path, cfg: ModelConfig = ESM3_OPEN):
     m = (yaml.safe_load(Path(path).read_text()) or {}).get("model", {}) or {}
     ns = m.get("noise_schedule") or {}
     target = str(ns.get("_target_", "slm.utils.noise_utils.LogLinearNoise")).rsplit(".", 1)[-1]
-    kinds = {"LogLinearNoise": LogLinearNoise, "CosineNoise": CosineNoise}
+    # every schedule class of noise_utils.py:122-213 (hydra passes the yaml's keys to the constructor)
+    kinds = {"LogLinearNoise": (LogLinearNoise, ("eps",)), "CosineNoise": (CosineNoise, ("eps",)),
+             "CosineSqrNoise": (CosineSqrNoise, ("eps",)), "Linear": (Linear, ("sigma_min", "sigma_max")),
+             "GeometricNoise": (GeometricNoise, ("sigma_min", "sigma_max"))}
     if target not in kinds:
-        raise NotImplementedError(f"noise schedule {target} (from {path}) is not built: LogLinearNoise / CosineNoise only")
-    noise = kinds[target](**({"eps": float(ns["eps"])} if "eps" in ns else {}))
+        raise NotImplementedError(f"noise schedule {target} (from {path}) is not one of {sorted(kinds)}")
+    cls, keys = kinds[target]
+    noise = cls(**{k: float(ns[k]) for k in keys if k in ns})
     net = m.get("net") or {}
     cfg = dataclasses.replace(cfg, time_conditioning=bool(m.get("time_conditioning", cfg.time_conditioning)),
                               n_structure_heads=int(net.get("n_structure_heads", cfg.n_structure_heads)))

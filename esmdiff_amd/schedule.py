@@ -30,6 +30,14 @@ class Noise:
 class LogLinearNoise(Noise):
     def __init__(self, eps: float = 1e-3):
         self.eps = eps
+        self.sigma_max = self.total_noise(torch.tensor(1.0))                # noise_utils.py:199-200
+        self.sigma_min = self.eps + self.total_noise(torch.tensor(0.0))
+
+    def importance_sampling_transformation(self, t):                        # noise_utils.py:208-213
+        f_T = torch.log1p(-torch.exp(-self.sigma_max))
+        f_0 = torch.log1p(-torch.exp(-self.sigma_min))
+        sigma_t = -torch.log1p(-torch.exp(t * f_T + (1 - t) * f_0))
+        return -torch.expm1(-sigma_t) / (1 - self.eps)
 
     def total_noise(self, t):
         return -torch.log1p(-(1 - self.eps) * t)
@@ -50,6 +58,71 @@ class CosineNoise(Noise):
         cos = (1 - self.eps) * torch.cos(t * torch.pi / 2)
         sin = (1 - self.eps) * torch.sin(t * torch.pi / 2)
         return (torch.pi / 2) * sin / (cos + self.eps)
+
+
+class CosineSqrNoise(Noise):
+    """noise_utils.py:138-152."""
+
+    def __init__(self, eps: float = 1e-3):
+        self.eps = eps
+
+    def total_noise(self, t):
+        cos2 = torch.cos(t * torch.pi / 2) ** 2
+        return -torch.log(self.eps + (1 - self.eps) * cos2)
+
+    def rate_noise(self, t):
+        cos2 = (1 - self.eps) * (torch.cos(t * torch.pi / 2) ** 2)
+        sin = (1 - self.eps) * torch.sin(t * torch.pi)
+        return (torch.pi / 2) * sin / (cos2 + self.eps)
+
+
+class Linear(Noise):
+    """noise_utils.py:155-172: sigma grows linearly from sigma_min to sigma_max."""
+
+    def __init__(self, sigma_min=0, sigma_max=10, dtype=torch.float32):
+        self.sigma_min = torch.tensor(sigma_min, dtype=dtype)
+        self.sigma_max = torch.tensor(sigma_max, dtype=dtype)
+
+    def total_noise(self, t):
+        return self.sigma_min + t * (self.sigma_max - self.sigma_min)
+
+    def rate_noise(self, t):
+        return self.sigma_max - self.sigma_min
+
+    def importance_sampling_transformation(self, t):
+        f_T = torch.log1p(-torch.exp(-self.sigma_max))
+        f_0 = torch.log1p(-torch.exp(-self.sigma_min))
+        sigma_t = -torch.log1p(-torch.exp(t * f_T + (1 - t) * f_0))
+        return (sigma_t - self.sigma_min) / (self.sigma_max - self.sigma_min)
+
+
+class GeometricNoise(Noise):
+    """noise_utils.py:175-185: sigma(t) = sigma_min^(1-t) * sigma_max^t."""
+
+    def __init__(self, sigma_min=1e-3, sigma_max=1):
+        self.sigmas = 1.0 * torch.tensor([sigma_min, sigma_max])
+
+    def total_noise(self, t):
+        return self.sigmas[0] ** (1 - t) * self.sigmas[1] ** t
+
+    def rate_noise(self, t):
+        return self.total_noise(t) * (self.sigmas[1].log() - self.sigmas[0].log())
+
+
+def get_noise(noise_type: str, sigma_min=None, sigma_max=None, dtype=torch.float32) -> Noise:
+    """`get_noise(config)` (noise_utils.py:75-90) with the config fields as arguments: type in geometric / loglinear / cosine /
+    cosinesqr / linear; sigma_min / sigma_max for geometric and linear."""
+    if noise_type == "geometric":
+        return GeometricNoise(sigma_min, sigma_max)
+    if noise_type == "loglinear":
+        return LogLinearNoise()
+    if noise_type == "cosine":
+        return CosineNoise()
+    if noise_type == "cosinesqr":
+        return CosineSqrNoise()
+    if noise_type == "linear":
+        return Linear(sigma_min, sigma_max, dtype)
+    raise ValueError(f"{noise_type} is not a valid noise")
 
 
 def timestep_embedding(sigma: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:

@@ -52,6 +52,75 @@ class CosineNoiseRef:
         return self.total_noise(t), self.rate_noise(t)
 
 
+class CosineSqrNoiseRef:
+    """noise_utils.py:138-152.  sigma(t) = -log(eps + (1 - eps) cos^2(pi t / 2))."""
+
+    def __init__(self, eps: float = 1e-3):
+        self.eps = eps
+
+    def total_noise(self, t):                                    # :149-151
+        return -torch.log(self.eps + (1 - self.eps) * torch.cos(t * torch.pi / 2) ** 2)
+
+    def rate_noise(self, t):                                     # :143-147
+        c = (1 - self.eps) * (torch.cos(t * torch.pi / 2) ** 2)
+        s = (1 - self.eps) * torch.sin(t * torch.pi)
+        return (torch.pi / 2) * s / (c + self.eps)
+
+    def __call__(self, t):
+        return self.total_noise(t), self.rate_noise(t)
+
+
+class LinearNoiseRef:
+    """noise_utils.py:155-172.  sigma(t) = sigma_min + t (sigma_max - sigma_min); the rate is that constant (a 0-d tensor)."""
+
+    def __init__(self, sigma_min=0, sigma_max=10, dtype=torch.float32):
+        self.sigma_min = torch.tensor(sigma_min, dtype=dtype)
+        self.sigma_max = torch.tensor(sigma_max, dtype=dtype)
+
+    def total_noise(self, t):                                    # :164-165
+        return self.sigma_min + t * (self.sigma_max - self.sigma_min)
+
+    def rate_noise(self, t):                                     # :161-162
+        return self.sigma_max - self.sigma_min
+
+    def importance_sampling_transformation(self, t):             # :167-172
+        f_T = torch.log1p(-torch.exp(-self.sigma_max))
+        f_0 = torch.log1p(-torch.exp(-self.sigma_min))
+        sigma_t = -torch.log1p(-torch.exp(t * f_T + (1 - t) * f_0))
+        return (sigma_t - self.sigma_min) / (self.sigma_max - self.sigma_min)
+
+    def __call__(self, t):
+        return self.total_noise(t), self.rate_noise(t)
+
+
+class GeometricNoiseRef:
+    """noise_utils.py:175-185.  sigma(t) = sigma_min^(1-t) sigma_max^t."""
+
+    def __init__(self, sigma_min=1e-3, sigma_max=1):
+        self.sigmas = 1.0 * torch.tensor([sigma_min, sigma_max])
+
+    def total_noise(self, t):                                    # :184-185
+        return self.sigmas[0] ** (1 - t) * self.sigmas[1] ** t
+
+    def rate_noise(self, t):                                     # :180-182
+        return self.sigmas[0] ** (1 - t) * self.sigmas[1] ** t * (self.sigmas[1].log() - self.sigmas[0].log())
+
+    def __call__(self, t):
+        return self.total_noise(t), self.rate_noise(t)
+
+
+def loglinear_importance_sampling_ref(t, eps: float = 1e-3):
+    """LogLinearNoise.importance_sampling_transformation, noise_utils.py:208-213 (sigma_max / sigma_min as its __init__ sets
+    them, :199-200)."""
+    n = LogLinearNoiseRef(eps)
+    sigma_max = n.total_noise(torch.tensor(1.0))
+    sigma_min = eps + n.total_noise(torch.tensor(0.0))
+    f_T = torch.log1p(-torch.exp(-sigma_max))
+    f_0 = torch.log1p(-torch.exp(-sigma_min))
+    sigma_t = -torch.log1p(-torch.exp(t * f_T + (1 - t) * f_0))
+    return -torch.expm1(-sigma_t) / (1 - eps)
+
+
 # ---- time conditioning: slm/models/net.py:486-522 ----------------------------------------------
 def timestep_embedding_ref(sigma: torch.Tensor, dim: int, max_period: float = 10000.0) -> torch.Tensor:
     """net.py:497-517: cat[cos(sigma f), sin(sigma f)], f_k = exp(-ln(max_period) k / half)."""

@@ -17,6 +17,7 @@ the reference's code, not by a restatement.
 
 Fixtures:
   G1 schedule tables          LogLinearNoise / CosineNoise sigma, dsigma, move chance
+  G1b other schedules         CosineSqrNoise / Linear / GeometricNoise tables, importance_sampling_transformation
   G2 timestep embedding       TimestepEmbedder.timestep_embedding + MLP
   G3 logits_parameterization  seeded logits with mixed masks
   G4 _sample_categorical      with the uniforms torch drew recorded
@@ -243,6 +244,31 @@ def g1_schedules():
     np.savez_compressed(OUT / "g1_schedules.npz", **out)
 
 
+def g1b_schedules_other():
+    """The schedules `get_noise` can also build (noise_utils.py:75-90, :138-185): CosineSqrNoise, Linear, GeometricNoise, at the
+    sampler's T = 25 grid; plus importance_sampling_transformation of Linear and LogLinearNoise on a t grid."""
+    out = {}
+    T, eps = 25, 1e-5
+    ts = torch.linspace(1.0, eps, T + 1)
+    dt = (1 - eps) / T
+    t = ts[:, None]
+    for nm, sched in (("cosinesqr", noise_utils.CosineSqrNoise(eps=1e-3)), ("linear", noise_utils.Linear(0, 10)),
+                      ("geometric", noise_utils.GeometricNoise(1e-3, 1))):
+        sig_t, dsig_t = sched(t)
+        sig_s, _ = sched(t - dt)
+        out[f"{nm}_sigma_t"] = sig_t.squeeze(-1).numpy()
+        out[f"{nm}_dsigma_t"] = (dsig_t * torch.ones_like(t)).squeeze(-1).numpy()
+        out[f"{nm}_sigma_s"] = sig_s.squeeze(-1).numpy()
+        out[f"{nm}_mc_t"] = (1 - torch.exp(-sig_t.squeeze(-1))).numpy()
+        out[f"{nm}_mc_s"] = (1 - torch.exp(-sig_s.squeeze(-1))).numpy()
+    grid = torch.linspace(0.0, 1.0, 21)
+    out["t_grid"] = grid.numpy()
+    out["linear_importance"] = noise_utils.Linear(1e-3, 10).importance_sampling_transformation(grid).numpy()
+    out["linear_importance_sigma_min0"] = noise_utils.Linear(0, 10).importance_sampling_transformation(grid).numpy()   # degenerate: 0 / nan
+    out["loglinear_importance"] = noise_utils.LogLinearNoise().importance_sampling_transformation(grid).numpy()
+    np.savez_compressed(OUT / "g1b_schedules_other.npz", **out)
+
+
 def g2_timestep():
     sig = torch.tensor([0.0, 1e-5, 0.01, 0.5, 1.0, 3.3, 6.9077683], dtype=torch.float32)
     out = {"sigma": sig.numpy()}
@@ -387,7 +413,11 @@ def g8_merge_pdb():
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["g1b"]:          # later addition: only this fixture (the others are unchanged)
+        g1b_schedules_other()
+        sys.exit(0)
     g1_schedules()
+    g1b_schedules_other()
     g2_timestep()
     g3_logits_param()
     g4_categorical()

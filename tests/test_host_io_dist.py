@@ -270,7 +270,18 @@ def test_hydra_config_next_to_checkpoint(tmp_path):
     (run / ".hydra" / "config.yaml").write_text("model:\n  noise_schedule:\n    _target_: slm.utils.noise_utils.LogLinearNoise\n")
     cfg, noise = config_from_hydra_yaml(y)
     assert isinstance(noise, LogLinearNoise) and cfg.time_conditioning is True
-    (run / ".hydra" / "config.yaml").write_text("model:\n  noise_schedule:\n    _target_: slm.utils.noise_utils.GeometricNoise\n")
+    # the other schedule classes of noise_utils.py (constructor keys from the yaml, as hydra passes them)
+    from esmdiff_amd.schedule import CosineSqrNoise, GeometricNoise, Linear
+    (run / ".hydra" / "config.yaml").write_text(
+        "model:\n  noise_schedule:\n    _target_: slm.utils.noise_utils.GeometricNoise\n    sigma_min: 0.01\n    sigma_max: 2\n")
+    cfg, noise = config_from_hydra_yaml(y)
+    assert isinstance(noise, GeometricNoise) and [round(float(v), 4) for v in noise.sigmas] == [0.01, 2.0]
+    (run / ".hydra" / "config.yaml").write_text("model:\n  noise_schedule:\n    _target_: slm.utils.noise_utils.Linear\n    sigma_max: 8\n")
+    cfg, noise = config_from_hydra_yaml(y)
+    assert isinstance(noise, Linear) and float(noise.sigma_min) == 0.0 and float(noise.sigma_max) == 8.0
+    (run / ".hydra" / "config.yaml").write_text("model:\n  noise_schedule:\n    _target_: slm.utils.noise_utils.CosineSqrNoise\n")
+    assert isinstance(config_from_hydra_yaml(y)[1], CosineSqrNoise)
+    (run / ".hydra" / "config.yaml").write_text("model:\n  noise_schedule:\n    _target_: slm.utils.noise_utils.SigmoidNoise\n")
     with pytest.raises(NotImplementedError):
         config_from_hydra_yaml(y)
     with pytest.raises(FileNotFoundError):

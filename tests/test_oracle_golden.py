@@ -37,6 +37,41 @@ def test_g1_schedules(golden_dir):
     assert abs(float(g["loglinear_mc_t_T25"][1]) - 0.95904040) < 1e-6
 
 
+def test_g1b_other_schedules(golden_dir):
+    """The schedules `get_noise` can also build (noise_utils.py:75-90, :138-185), recorded from the reference at the sampler's
+    T = 25 grid: oracle restatement and the product classes, bit for bit."""
+    from esmdiff_amd import schedule as S
+    g = np.load(golden_dir / "g1b_schedules_other.npz")
+    T, eps = 25, 1e-5
+    for nm, ref, prod in (("cosinesqr", R.CosineSqrNoiseRef(1e-3), S.get_noise("cosinesqr")),
+                          ("linear", R.LinearNoiseRef(0, 10), S.get_noise("linear", 0, 10)),
+                          ("geometric", R.GeometricNoiseRef(1e-3, 1), S.get_noise("geometric", 1e-3, 1))):
+        s = R.ddpm_schedule_ref(T, eps, 1.0, ref)
+        for k in ("sigma_t", "sigma_s", "mc_t", "mc_s"):
+            assert np.array_equal(s[k].numpy(), g[f"{nm}_{k}"]), (nm, k)
+        t = s["timesteps"][:, None]
+        assert np.array_equal((ref(t)[1] * torch.ones_like(t)).squeeze(-1).numpy(), g[f"{nm}_dsigma_t"]), nm
+        p = S.ddpm_schedule(T, eps, 1.0, prod)
+        for k in ("sigma_t", "mc_t", "mc_s"):
+            assert np.array_equal(getattr(p, k).numpy(), g[f"{nm}_{k}"]), (nm, k)
+        assert np.array_equal((prod(t)[1] * torch.ones_like(t)).squeeze(-1).numpy(), g[f"{nm}_dsigma_t"]), nm
+    grid = torch.from_numpy(g["t_grid"])
+    assert np.array_equal(R.LinearNoiseRef(1e-3, 10).importance_sampling_transformation(grid).numpy(), g["linear_importance"])
+    assert np.array_equal(S.Linear(1e-3, 10).importance_sampling_transformation(grid).numpy(), g["linear_importance"])
+    assert float(np.abs(g["linear_importance"]).max()) > 0.5                      # (a live case, not the degenerate one below)
+    # sigma_min = 0 (log1p(-1) = -inf inside): the reference returns zeros and a nan; so do the restatements
+    assert np.array_equal(S.Linear(0, 10).importance_sampling_transformation(grid).numpy(), g["linear_importance_sigma_min0"],
+                          equal_nan=True)
+    assert np.array_equal(R.loglinear_importance_sampling_ref(grid).numpy(), g["loglinear_importance"])
+    assert np.array_equal(S.LogLinearNoise().importance_sampling_transformation(grid).numpy(), g["loglinear_importance"])
+    g1 = np.load(golden_dir / "g1_schedules.npz")
+    assert np.array_equal(S.LogLinearNoise().sigma_max.numpy(), g1["loglinear_sigma_max"])
+    assert np.array_equal(S.LogLinearNoise().sigma_min.numpy(), g1["loglinear_sigma_min"])
+    assert isinstance(S.get_noise("loglinear"), S.LogLinearNoise) and isinstance(S.get_noise("cosine"), S.CosineNoise)
+    with pytest.raises(ValueError, match="not a valid noise"):
+        S.get_noise("sigmoid")
+
+
 def test_g2_timestep_embedding(golden_dir):
     g = np.load(golden_dir / "g2_timestep.npz")
     sig = torch.from_numpy(g["sigma"])
