@@ -121,6 +121,48 @@ class MaskedDiffusionLanguageModeling:
             logits[..., STRUCTURE_MASK_TOKEN:STRUCTURE_MASK_TOKEN + 5] += self.neg_infinity
         return logits, None
 
+    def _process_sigma(self, sigma):
+        """model.py:535-541: (B, 1) -> (B,); zeros when the model is not time-conditioned."""
+        if sigma.ndim > 1:
+            sigma = sigma.squeeze(-1)
+        if not self.time_conditioning:
+            sigma = torch.zeros_like(sigma)
+        assert sigma.ndim == 1, sigma.shape
+        return sigma
+
+    @torch.no_grad()
+    def _ddpm_update(self, x, t, sequence_tokens, dt, *, u=None, seed: Optional[int] = None, sample_offset: int = 0, step: int = 0,
+                     t_freq: Optional[torch.Tensor] = None):
+        """One reverse-diffusion update, the reference's `_ddpm_update(x, t, sequence_tokens, dt)` (model.py:583-607): t is (B, 1);
+        sigma_t = noise(t), sigma_s = noise(t - dt), move chances 1 - exp(-sigma); network at sigma_t; draw; carry the unmasked
+        rows over.  Noise: explicit uniforms `u` (B, L, 4101) — what torch.rand_like(q_xs) draws — or Philox(seed, sample, step).
+        x is updated in place and returned.  Rows of t may differ (the reference allows it; its loop never does it): the network
+        then runs with one sigma per sample and the draw runs per sample.  t_freq: the conditioning row(s) already prepared
+        for sigma_t by the caller (ddpm_sample passes its schedule table's row), else computed here."""
+        from .schedule import timestep_embedding
+        x = x.to(self.device).contiguous()
+        seq = sequence_tokens.to(self.device)
+        B, L = x.shape
+        t = torch.as_tensor(t, dtype=torch.float32).reshape(B, 1).cpu()
+        sigma_t = self.noise(t)[0].squeeze(-1)
+        sigma_s = self.noise(t - dt)[0].squeeze(-1)
+        mc_t, mc_s = 1 - torch.exp(-sigma_t), 1 - torch.exp(-sigma_s)
+        shared = bool((t == t[0]).all())
+        if t_freq is None:
+            tf = self.net.conditioning_rows(timestep_embedding(sigma_t[:1] if shared else sigma_t, self.cfg.freq_dim))
+            t_freq = None if tf is None else (tf[0] if shared else tf)
+        logits = self.net.forward_logits(x, seq, t_freq)
+        if u is None and seed is None:
+            raise ValueError("_ddpm_update needs explicit uniforms `u` or a Philox `seed`")
+        if shared:
+            self.net.ddpm_step(x, logits, float(mc_t[0]), float(mc_s[0]), u=u, seed=None if u is not None else seed,
+                               sample_offset=sample_offset, step=step)
+        else:
+            for b in range(B):
+                self.net.ddpm_step(x[b:b + 1], logits[b:b + 1], float(mc_t[b]), float(mc_s[b]), u=None if u is None else u[b:b + 1],
+                                   seed=None if u is not None else seed, sample_offset=sample_offset + b, step=step)
+        return x
+
     @torch.no_grad()
     def ddpm_sample(self, sequence_tokens, num_steps=None, eps=1e-5, input_prior=None, sample_max_t=1.0, *,
                     seed: int = 0, sample_offset: int = 0, noise: str = "philox"):
@@ -154,13 +196,9 @@ class MaskedDiffusionLanguageModeling:
         elif noise != "philox":
             raise ValueError(f"unknown noise source {noise!r}")
         for i in range(num_steps):
-            logits = self.net.forward_logits(x, seq, tf[i])
-            if noise == "torch-cpu":
-                u = torch.rand(B, L, STRUCTURE_VOCAB, generator=gen)   # == torch.rand_like(q_xs) on the CPU generator
-                self.net.ddpm_step(x, logits, sch.mc_t[i].item(), sch.mc_s[i].item(), u=u)
-            else:
-                self.net.ddpm_step(x, logits, sch.mc_t[i].item(), sch.mc_s[i].item(), seed=seed,
-                                   sample_offset=sample_offset, step=i)
+            t = sch.timesteps[i] * torch.ones(B, 1)
+            u = torch.rand(B, L, STRUCTURE_VOCAB, generator=gen) if noise == "torch-cpu" else None   # == torch.rand_like(q_xs), model.py:27
+            x = self._ddpm_update(x, t, seq, sch.dt, u=u, seed=seed, sample_offset=sample_offset, step=i, t_freq=tf[i])
         if self.noise_removal:
             logits = self.net.forward_logits(x, seq, tf[num_steps])
             self.net.ddpm_step(x, logits, 0.0, 0.0, final=True)

@@ -791,6 +791,44 @@ def test_forward_with_one_sigma_per_sample(precision):
     eng.close()
 
 
+def test_ddpm_update_method_and_per_sample_t():
+    """`MaskedDiffusionLanguageModeling._ddpm_update(x, t, sequence_tokens, dt)` (model.py:583-607) as a standalone call on a
+    float32-grade engine: with the loop's t (all rows equal) T calls + the noise-removal pass reproduce ddpm_sample's ids; with a
+    DIFFERENT t per sample (the signature allows it) every sample gets the update it gets alone at its own t — bit for bit."""
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.model import MaskedDiffusionLanguageModeling
+    from esmdiff_amd.schedule import LogLinearNoise
+    from esmdiff_amd.weights import random_init_state_dict
+    sd = random_init_state_dict(TINY, seed=4)
+    model = MaskedDiffusionLanguageModeling(sd, TINY, LogLinearNoise(), max_batch=4, max_len=40, device=0, precision="f32_split",
+                                            step0_sharing=False)
+    B, L, T, eps = 4, 40, 6, 1e-5
+    g = torch.Generator().manual_seed(12)
+    seq = _seq(B, L, g)
+    want = model.ddpm_sample(seq, num_steps=T, seed=9)
+    ts = torch.linspace(1.0, eps, T + 1)
+    dt = (1 - eps) / T
+    x = model._sample_prior(B, L)
+    for i in range(T):
+        x = model._ddpm_update(x, ts[i] * torch.ones(B, 1), seq, dt, seed=9, step=i)
+    sigma_T = model.noise(ts[-1] * torch.ones(B, 1))[0]
+    lp, _ = model._model_wrapper(x, seq, sigma_T)
+    assert torch.equal(lp.argmax(-1), want)                                     # model.py:575-579
+    assert torch.equal(model._process_sigma(sigma_T), sigma_T.squeeze(-1))
+    # one t per sample
+    x0 = model._sample_prior(B, L)
+    x0[:, 5:20] = torch.randint(0, 4096, (B, 15), generator=g)
+    t = torch.tensor([[0.9], [0.55], [0.3], [0.12]])
+    got = model._ddpm_update(x0.clone(), t, seq, dt, seed=3, sample_offset=20, step=2).cpu()
+    for b in range(B):
+        alone = model._ddpm_update(x0[b:b + 1].clone(), t[b:b + 1], seq[b:b + 1], dt, seed=3, sample_offset=20 + b, step=2).cpu()
+        assert torch.equal(got[b:b + 1], alone), b
+    assert torch.equal(got[:, 5:20], x0[:, 5:20]) and int((got == MASK).sum()) < int((x0 == MASK).sum())
+    with pytest.raises(ValueError, match="uniforms"):
+        model._ddpm_update(x0.clone(), t, seq, dt)
+    model.net.close()
+
+
 def test_ddpm_step_margin_same_ids_and_flags():
     """esmdiff_ddpm_step_margin: the ids are esmdiff_ddpm_step's bit for bit; the per-sample flags follow the runner-up test
     (checked against a torch restatement of the race on the same Philox uniforms via explicit `u` on the plain step)."""
