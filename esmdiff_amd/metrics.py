@@ -157,3 +157,72 @@ def bonding_validity(ca_coords_dict, ref_key: str = "target", rounded: bool = Tr
     res = {k: _call(L_.esmdiff_metrics_bonding_validity, v.data_ptr(), v.shape[0], ref.data_ptr(), ref.shape[0], ref.shape[1])
            for k, v in dev.items()}
     return _round(res, rounded)
+
+
+# ---- the small helpers around the metrics (eval_utils.py:37-129, :191-224), on the device, float64 ---------------------------
+def radius_of_gyration(coords, masses=None) -> torch.Tensor:
+    """eval_utils.py:105-129: (n, L, 3) -> (n,).  weights = masses / sum (equal masses when None); the centre is the plain mean."""
+    d = _dev(coords)
+    L = d.shape[1]
+    if masses is None:
+        m = torch.ones(L, dtype=torch.float64, device="cuda")
+    else:
+        m = torch.as_tensor(np.asarray(masses, dtype=np.float64)).to("cuda")
+        assert m.dim() == 1, f"masses should be 1D, got {tuple(m.shape)}"
+        assert m.shape[0] == L, f"masses {tuple(m.shape)} != number of particles {L}"
+    w = m / m.sum()
+    centered = d - d.mean(-2, keepdim=True)
+    return (((centered ** 2).sum(-1) * w).sum(-1)) ** 0.5
+
+
+def rmsf(coords) -> torch.Tensor:
+    """eval_utils.py:51-54: (n, L, 3) -> (L,)."""
+    d = _dev(coords)
+    return torch.sqrt(torch.var(d, dim=0, unbiased=False).mean(-1))
+
+
+def adjacent_ca_distance(coords) -> torch.Tensor:
+    """eval_utils.py:64-74: (n, L, 3) -> (n, L - 1)."""
+    d = _dev(coords)
+    dx = d[:, :-1] - d[:, 1:]
+    return torch.sqrt((dx ** 2).sum(-1))
+
+
+def distance_matrix_ca(coords) -> torch.Tensor:
+    """eval_utils.py:77-87: (n, L, 3) -> (n, L, L)."""
+    d = _dev(coords)
+    dx = d[:, None, :, :] - d[:, :, None, :]
+    return torch.sqrt((dx ** 2).sum(-1))
+
+
+def idp_metrics(ca_coords_dict, ref_key: str = "target", pwd_offset: int = 3):
+    """eval_utils.py:191-224: (mse_pwd, mse_rg, mse_contact, mae_pwd, mae_rg, mae_contact) dictionaries — mean pairwise distances
+    (csrc/metrics.hip's pair kernel), mean radius of gyration and log contact probabilities (< 8 A, pseudo-count 0.01) of every
+    ensemble against the reference ensemble's."""
+    pseudo_c = 0.01
+
+    def stats(ca):
+        pwd = pairwise_distance_ca(ca, k=pwd_offset)
+        return pwd.mean(0), radius_of_gyration(ca).mean(0), torch.log((pwd < 8.0).to(torch.float64).mean(0) + pseudo_c)
+
+    ref = stats(ca_coords_dict[ref_key])
+    out = tuple({} for _ in range(6))
+    for name, ca in ca_coords_dict.items():
+        cur = stats(ca)
+        for j in range(3):
+            diff = cur[j] - ref[j]
+            out[j][name] = float((diff ** 2).mean())
+            out[3 + j][name] = float(diff.abs().mean())
+    return out
+
+
+def position_specific_entropy(tokens: torch.Tensor) -> torch.Tensor:
+    """eval_utils.py:37-49: tokens (n_frames, L) int64 -> (L,) float32 entropy in bits of each column's token frequencies; one
+    scatter-add over a (L, n_ids) count table instead of a Python loop over columns."""
+    t = torch.as_tensor(tokens).to(device="cuda", dtype=torch.int64)
+    n, L = t.shape
+    n_ids = int(t.max()) + 1
+    counts = torch.zeros(L, n_ids, dtype=torch.float32, device="cuda")
+    counts.scatter_add_(1, t.t().contiguous(), torch.ones(L, n, dtype=torch.float32, device="cuda"))
+    f = counts / n
+    return -(torch.where(f > 0, f * torch.log2(f.clamp_min(1e-38)), torch.zeros_like(f))).sum(-1)

@@ -143,6 +143,36 @@ def merge_pdbfiles(input, save_to: Path, verbose: bool = True) -> None:
         print(f"Merged {len(pdb_files)} PDB files into {save_to} with {n_model} models.")
 
 
+def split_pdbfile(input, output_dir=None, sep: str = "_", verbose: bool = True):
+    """eval_utils.py:495-530, the inverse of merge_pdbfiles: the ATOM / TER lines of every MODEL ... ENDMDL block as one PDB
+    string closed by 'END'; with output_dir, also written to `<stem><sep><i>.pdb` there.  Returns the list of strings."""
+    input = Path(input)
+    assert input.exists() and input.suffix == ".pdb", f"File {input} does not exist or not a .pdb file."
+    if output_dir is not None:
+        output_dir = Path(output_dir)
+        output_dir.mkdir(parents=True, exist_ok=True)
+    parts, cur = [], ""
+    with open(input, "r") as fi:
+        for line in fi:
+            if line.startswith("MODEL"):
+                cur = ""
+            elif line.startswith("ATOM") or line.startswith("TER"):
+                cur += line
+            elif line.startswith("ENDMDL") or line.startswith("END"):
+                if cur == "":
+                    continue
+                cur += "END\n"
+                if output_dir is not None:
+                    (output_dir / f"{input.stem}{sep}{len(parts)}.pdb").write_text(cur)
+                parts.append(cur)
+                cur = ""
+            elif verbose:
+                print(f"Warning: line '{line}' is not recognized. Skip.")
+    if verbose:
+        print(f">>> Split pdb {input} into {len(parts)}/{len(parts)} structures.")
+    return parts
+
+
 def timer(func):
     """Prints the elapsed time and appends it to a tuple result; a None result passes through."""
     def wrapper(*args, **kwargs):

@@ -114,3 +114,71 @@ def bonding_validity(model_ca, ref_ca) -> float:
 def pairwise_adjacent(coords):
     d = coords[..., :-1, :] - coords[..., 1:, :]
     return np.sqrt((d[..., 0] ** 2 + d[..., 1] ** 2) + d[..., 2] ** 2)
+
+
+# ---- the small helpers around the metrics (r04; pinned to tests/golden/g9c_ensemble_helpers.npz) ----------------------------
+def radius_of_gyration_masses(coords: np.ndarray, masses: np.ndarray) -> np.ndarray:
+    """eval_utils.py:105-129 with masses: weights = m / sum(m); the centre stays the unweighted mean (:126)."""
+    w = masses / masses.sum()
+    centered = coords - coords.mean(-2, keepdims=True)
+    return ((centered ** 2).sum(-1) * w).sum(-1) ** 0.5
+
+
+def rmsf(coords: np.ndarray) -> np.ndarray:
+    """eval_utils.py:51-54: sqrt of the per-atom variance over frames, averaged over x, y, z."""
+    return np.sqrt(np.mean(np.var(coords, axis=0), axis=-1))
+
+
+def distance_matrix_ca(coords: np.ndarray) -> np.ndarray:
+    """eval_utils.py:77-87: (..., L, 3) -> (..., L, L)."""
+    d = coords[..., None, :, :] - coords[..., None, :]
+    return np.sqrt(np.sum(d ** 2, axis=-1))
+
+
+def idp_metrics(ens: dict, ref_key: str = "target", pwd_offset: int = 3):
+    """eval_utils.py:191-224: MSE / MAE between an ensemble and the reference ensemble of the mean pairwise distances, the mean
+    radius of gyration and the log contact probabilities (pairs closer than 8 A, pseudo-count 0.01)."""
+    pseudo_c = 0.01
+    ref_pwd = pairwise_distance_ca(ens[ref_key], pwd_offset)
+    ref_mean, ref_rg = ref_pwd.mean(axis=0), radius_of_gyration(ens[ref_key]).mean(axis=0)
+    ref_con = np.log((ref_pwd < 8.0).mean(axis=0) + pseudo_c)
+    out = [dict() for _ in range(6)]
+    for name, ca in ens.items():
+        pwd = pairwise_distance_ca(ca, pwd_offset)
+        rg = radius_of_gyration(ca).mean(axis=0)
+        con = np.log((pwd < 8.0).mean(axis=0) + pseudo_c)
+        out[0][name] = np.mean((pwd.mean(axis=0) - ref_mean) ** 2)
+        out[1][name] = np.mean((rg - ref_rg) ** 2)
+        out[2][name] = np.mean((con - ref_con) ** 2)
+        out[3][name] = np.mean(np.abs(pwd.mean(axis=0) - ref_mean))
+        out[4][name] = np.mean(np.abs(rg - ref_rg))
+        out[5][name] = np.mean(np.abs(con - ref_con))
+    return tuple(out)
+
+
+def position_specific_entropy(tokens: np.ndarray) -> np.ndarray:
+    """eval_utils.py:37-49: per column, the entropy (bits) of the token frequencies over the frames; float32 like the reference's
+    torch.zeros accumulator."""
+    n = tokens.shape[0]
+    out = np.zeros(tokens.shape[1], dtype=np.float32)
+    for c in range(tokens.shape[1]):
+        f = (np.bincount(tokens[:, c]) / np.float32(n)).astype(np.float32)
+        f = f[f > 0]
+        out[c] = -np.sum(f * np.log2(f), dtype=np.float32)
+    return out
+
+
+def split_pdb_text(text: str):
+    """eval_utils.py:495-530 on a string: ATOM / TER lines between MODEL and ENDMDL (or END), each model closed by 'END'."""
+    parts, cur = [], ""
+    for line in text.splitlines(keepends=True):
+        if line.startswith("MODEL"):
+            cur = ""
+        elif line.startswith("ATOM") or line.startswith("TER"):
+            cur += line
+        elif line.startswith("ENDMDL") or line.startswith("END"):
+            if cur == "":
+                continue
+            parts.append(cur + "END\n")
+            cur = ""
+    return parts

@@ -81,6 +81,41 @@ def main():
         print(name, dict(zip(keys, outb[name + "_raw"])))
     outb["keys"] = np.array(keys)
     np.savez_compressed(HERE / "g9b_metrics_weights.npz", **outb)
+    g9c(ens, keys, rng)
+
+
+def g9c(ens, keys, rng):
+    """g9c (r04): the small ensemble helpers around the metrics — idp_metrics :191-224, rmsf :51-54, adjacent_ca_distance :64-74,
+    distance_matrix_ca :77-87, radius_of_gyration with masses :105-129, position_specific_entropy :37-49, split_pdbfile :495-530
+    (on the merged file of g8)."""
+    import json
+    import tempfile
+
+    import torch
+    out = {}
+    names = ("mse_pwd", "mse_rg", "mse_contact", "mae_pwd", "mae_rg", "mae_contact")
+    for tag, kw in (("", {}), ("_k1", {"pwd_offset": 1})):
+        for nm, d in zip(names, E.idp_metrics(dict(ens), **kw)):
+            out[f"idp_{nm}{tag}"] = np.array([float(d[k]) for k in keys])
+    out["rmsf_target"] = E.rmsf(ens["target"])
+    out["adjacent_model_a"] = E.adjacent_ca_distance(ens["model_a"])
+    out["distance_matrix_model_b"] = E.distance_matrix_ca(ens["model_b"])
+    masses = rng.uniform(10.0, 20.0, size=ens["target"].shape[1])
+    out["masses"] = masses
+    out["rg_target_masses"] = E.radius_of_gyration(ens["target"], masses=masses)
+    tok = torch.from_numpy(rng.integers(0, 7, size=(40, 9)))
+    tok[:, 2] = 3                                                   # a position with one token only: entropy 0
+    out["tokens"] = tok.numpy()
+    out["position_specific_entropy"] = E.position_specific_entropy(tok).numpy()
+    np.savez_compressed(HERE / "g9c_ensemble_helpers.npz", **out)
+    g8 = json.loads((HERE / "g8_merge_pdb.json").read_text())
+    with tempfile.TemporaryDirectory() as d:
+        src = Path(d) / "merged.pdb"
+        src.write_text(g8["merged"])
+        parts = E.split_pdbfile(src, output_dir=Path(d) / "split", verbose=False)
+        files = {p.name: p.read_text() for p in sorted((Path(d) / "split").iterdir())}
+    (HERE / "g9c_split_pdb.json").write_text(json.dumps({"parts": parts, "files": files}, indent=1))
+    print("g9c", {k: out[k].shape for k in out})
 
 
 if __name__ == "__main__":

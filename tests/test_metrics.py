@@ -148,3 +148,64 @@ def test_device_js_tica_follows_the_oracle_and_is_sign_scale_free():
     with pytest.raises(ValueError, match="lagtime"):
         M.js_tica({"target": ref[:15], "m": mod}, lagtime=20)
     assert M.js_tica({"target": ref, "m": mod}, lagtime=20, return_tic=False)["m"] == float(np.around(res["m"], 4))
+
+
+# ---- g9c: the small helpers around the metrics (eval_utils.py:37-129, :191-224, :495-530) ---------------------------------
+GC = np.load(Path(__file__).parent / "golden" / "g9c_ensemble_helpers.npz")
+IDP = ("mse_pwd", "mse_rg", "mse_contact", "mae_pwd", "mae_rg", "mae_contact")
+
+
+def test_g9c_oracle_reproduces_reference_helpers():
+    import json
+    for tag, k in (("", 3), ("_k1", 1)):
+        got = R.idp_metrics(dict(ENS), pwd_offset=k)
+        for nm, d in zip(IDP, got):
+            want = GC[f"idp_{nm}{tag}"]
+            assert np.allclose([d[key] for key in KEYS], want, rtol=1e-12, atol=1e-14), (nm, tag)
+            assert d["target"] == 0.0
+    assert np.allclose(R.rmsf(ENS["target"]), GC["rmsf_target"], rtol=1e-13, atol=0)
+    assert np.array_equal(R.pairwise_adjacent(ENS["model_a"]), GC["adjacent_model_a"])
+    assert np.allclose(R.distance_matrix_ca(ENS["model_b"]), GC["distance_matrix_model_b"], rtol=1e-15, atol=0)
+    assert np.allclose(R.radius_of_gyration_masses(ENS["target"], GC["masses"]), GC["rg_target_masses"], rtol=1e-14, atol=0)
+    pse = R.position_specific_entropy(GC["tokens"])
+    assert np.allclose(pse, GC["position_specific_entropy"], rtol=0, atol=1e-6) and pse[2] == 0.0
+    g = json.loads((Path(__file__).parent / "golden" / "g9c_split_pdb.json").read_text())
+    merged = json.loads((Path(__file__).parent / "golden" / "g8_merge_pdb.json").read_text())["merged"]
+    assert R.split_pdb_text(merged) == g["parts"] and len(g["parts"]) == 2
+
+
+def test_g9c_split_pdbfile_inverts_merge(tmp_path):
+    import json
+
+    from esmdiff_amd.pdbio import merge_pdbfiles, split_pdbfile
+    g = json.loads((Path(__file__).parent / "golden" / "g9c_split_pdb.json").read_text())
+    g8 = json.loads((Path(__file__).parent / "golden" / "g8_merge_pdb.json").read_text())
+    src = tmp_path / "merged.pdb"
+    src.write_text(g8["merged"])
+    parts = split_pdbfile(src, output_dir=tmp_path / "split", verbose=False)
+    assert parts == g["parts"]
+    assert {p.name: p.read_text() for p in sorted((tmp_path / "split").iterdir())} == g["files"]
+    assert split_pdbfile(src, verbose=False) == g["parts"] and len(list((tmp_path / "split").iterdir())) == 2
+    # round trip: merging the split files gives the merged file back
+    merge_pdbfiles(sorted((tmp_path / "split").iterdir()), tmp_path / "again.pdb", verbose=False)
+    assert (tmp_path / "again.pdb").read_text() == g8["merged"]
+    with pytest.raises(AssertionError):
+        split_pdbfile(tmp_path / "nope.pdb")
+
+
+@pytest.mark.gpu
+def test_g9c_device_helpers_reproduce_reference():
+    from esmdiff_amd import metrics as M
+    for tag, k in (("", 3), ("_k1", 1)):
+        got = M.idp_metrics(dict(ENS), pwd_offset=k)
+        for nm, d in zip(IDP, got):
+            assert np.allclose([d[key] for key in KEYS], GC[f"idp_{nm}{tag}"], rtol=1e-11, atol=1e-13), (nm, tag)
+    assert np.allclose(M.rmsf(ENS["target"]).cpu().numpy(), GC["rmsf_target"], rtol=1e-12, atol=0)
+    assert np.allclose(M.adjacent_ca_distance(ENS["model_a"]).cpu().numpy(), GC["adjacent_model_a"], rtol=1e-14, atol=0)
+    assert np.allclose(M.distance_matrix_ca(ENS["model_b"]).cpu().numpy(), GC["distance_matrix_model_b"], rtol=1e-14, atol=0)
+    assert np.allclose(M.radius_of_gyration(ENS["target"], GC["masses"]).cpu().numpy(), GC["rg_target_masses"], rtol=1e-13, atol=0)
+    assert np.allclose(M.radius_of_gyration(ENS["target"]).cpu().numpy(), G["rg_target"], rtol=1e-13, atol=0)
+    pse = M.position_specific_entropy(torch.from_numpy(GC["tokens"])).cpu().numpy()
+    assert pse.dtype == np.float32 and np.allclose(pse, GC["position_specific_entropy"], rtol=0, atol=1e-6) and pse[2] == 0.0
+    with pytest.raises(AssertionError, match="masses"):
+        M.radius_of_gyration(ENS["target"], GC["masses"][:5])
