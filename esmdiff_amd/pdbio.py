@@ -144,33 +144,31 @@ def merge_pdbfiles(input, save_to: Path, verbose: bool = True) -> None:
 
 
 def split_pdbfile(input, output_dir=None, sep: str = "_", verbose: bool = True):
-    """eval_utils.py:495-530, the inverse of merge_pdbfiles: the ATOM / TER lines of every MODEL ... ENDMDL block as one PDB
-    string closed by 'END'; with output_dir, also written to `<stem><sep><i>.pdb` there.  Returns the list of strings."""
+    """eval_utils.py:495-530, the inverse of merge_pdbfiles: one PDB string per MODEL block — its ATOM / TER records, closed by
+    'END' — and, with output_dir, one file `<stem><sep><i>.pdb` per block.  Returns the list of strings."""
     input = Path(input)
     assert input.exists() and input.suffix == ".pdb", f"File {input} does not exist or not a .pdb file."
+    blocks, records = [], []
+    for line in input.read_text().splitlines(keepends=True):
+        name = line[:6].strip()                      # PDB record name, columns 1-6
+        if name == "MODEL":
+            records = []
+        elif name in ("ATOM", "TER"):
+            records.append(line)
+        elif name in ("ENDMDL", "END"):
+            if records:                              # (the file's last END follows an ENDMDL: nothing pending)
+                blocks.append("".join(records) + "END\n")
+                records = []
+        elif verbose:
+            print(f"Warning: line '{line}' is not recognized. Skip.")
     if output_dir is not None:
         output_dir = Path(output_dir)
         output_dir.mkdir(parents=True, exist_ok=True)
-    parts, cur = [], ""
-    with open(input, "r") as fi:
-        for line in fi:
-            if line.startswith("MODEL"):
-                cur = ""
-            elif line.startswith("ATOM") or line.startswith("TER"):
-                cur += line
-            elif line.startswith("ENDMDL") or line.startswith("END"):
-                if cur == "":
-                    continue
-                cur += "END\n"
-                if output_dir is not None:
-                    (output_dir / f"{input.stem}{sep}{len(parts)}.pdb").write_text(cur)
-                parts.append(cur)
-                cur = ""
-            elif verbose:
-                print(f"Warning: line '{line}' is not recognized. Skip.")
+        for i, text in enumerate(blocks):
+            (output_dir / f"{input.stem}{sep}{i}.pdb").write_text(text)
     if verbose:
-        print(f">>> Split pdb {input} into {len(parts)}/{len(parts)} structures.")
-    return parts
+        print(f">>> Split pdb {input} into {len(blocks)} structures.")
+    return blocks
 
 
 def timer(func):

@@ -169,16 +169,15 @@ def position_specific_entropy(tokens: np.ndarray) -> np.ndarray:
 
 
 def split_pdb_text(text: str):
-    """eval_utils.py:495-530 on a string: ATOM / TER lines between MODEL and ENDMDL (or END), each model closed by 'END'."""
-    parts, cur = [], ""
+    """eval_utils.py:495-530 on a string: the ATOM / TER records of every MODEL block, each block closed by 'END'."""
+    blocks, records = [], []
     for line in text.splitlines(keepends=True):
-        if line.startswith("MODEL"):
-            cur = ""
-        elif line.startswith("ATOM") or line.startswith("TER"):
-            cur += line
-        elif line.startswith("ENDMDL") or line.startswith("END"):
-            if cur == "":
-                continue
-            parts.append(cur + "END\n")
-            cur = ""
-    return parts
+        name = line[:6].strip()
+        if name == "MODEL":
+            records = []
+        elif name in ("ATOM", "TER"):
+            records.append(line)
+        elif name in ("ENDMDL", "END") and records:
+            blocks.append("".join(records) + "END\n")
+            records = []
+    return blocks
