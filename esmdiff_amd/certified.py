@@ -82,7 +82,7 @@ class CertifiedSampler:
         logits = torch.empty(B, L, fast.ld_logits, dtype=torch.float32, device=dev)
         cap = exact.max_batch
         reruns = []
-        err_max, violations, skipped_final, probes, eps_used = 0.0, 0, False, 0, []
+        err_max, violations, skipped_final, probes_exact, probes_fast, eps_used = 0.0, 0, False, 0, 0, []
         V = exact.cfg.n_structure_heads
         shared0 = input_prior is None and B > 1 and bool((seq == seq[:1]).all())
         for i in range(T + 1):
@@ -94,7 +94,7 @@ class CertifiedSampler:
                 if self.eps is None and self.n_seen == 0:          # start the error estimate on the same input
                     lgf = fast.forward_logits(x[:1], seq[:1], None if tf_fast is None else tf_fast[0])
                     err_max = max(err_max, float(self._observe(lgf, lg1, x[:1]).max()))
-                    probes += 1
+                    probes_fast += 1
                 logits[..., :V] = lg1
                 exact.ddpm_step(x, logits[..., :V], float(schedule.mc_t[0]), float(schedule.mc_s[0]), seed=seed,
                                 sample_offset=sample_offset, step=0)
@@ -114,7 +114,7 @@ class CertifiedSampler:
                 n = min(2, B)
                 lgp = exact.forward_logits(prev[:n], seq[:n], None if tf_exact is None else tf_exact[i])
                 err_max = max(err_max, float(self._observe(lg[:n], lgp, prev[:n]).max()))
-                probes += n
+                probes_exact += n
             eps_i = self._eps_now()
             eps_used.append(eps_i)
             ratio, diff = math.exp(2.0 * eps_i), 2.0 * eps_i
@@ -139,6 +139,6 @@ class CertifiedSampler:
                       "safety": self.safety, "eps_min_used": min(used) if used else None, "eps_max_used": max(used) if used else None,
                       "rerun_per_update": reruns, "max_logit_err_observed": err_max, "max_logit_err_all_calls": self.err_seen,
                       "eps_violations": violations, "first_update_shared": shared0,
-                      "sample_forwards_exact": int(sum(reruns)) + int(shared0) + (probes if not shared0 else 0),
-                      "sample_forwards_fast": B * (len(reruns) - int(shared0) - int(skipped_final))}
+                      "sample_forwards_exact": int(sum(reruns)) + int(shared0) + probes_exact,
+                      "sample_forwards_fast": B * (len(reruns) - int(shared0) - int(skipped_final)) + probes_fast}
         return x
