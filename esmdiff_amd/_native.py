@@ -130,7 +130,7 @@ def lib():
     for n in EXPORTS:
         if n not in ("esmdiff_engine_destroy", "esmdiff_last_error", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error"):
             getattr(L, n).restype = ctypes.c_int
-    if L.esmdiff_abi_version() != 5:
+    if L.esmdiff_abi_version() != 6:
         raise RuntimeError("libesmdiff_hip.so ABI version mismatch")
     _lib = L
     return L

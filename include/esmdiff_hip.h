@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESMDIFF_ABI_VERSION 5
+#define ESMDIFF_ABI_VERSION 6   /* 6: + esmdiff_ddpm_step_margin, esmdiff_forward_logits_sigmas (additions only) */
 
 /* structure-track vocabulary: esm constants mirrored at model.py:380-381 */
 #define ESMDIFF_VOCAB 4101
