@@ -48,7 +48,7 @@ EXPORTS = [
     "esmdiff_metrics_bonding_validity", "esmdiff_metrics_pwd", "esmdiff_metrics_js_columns", "esmdiff_encoder_create", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error",
     "esmdiff_encoder_encode", "esmdiff_gemm_f32", "esmdiff_set_step0_sharing", "esmdiff_get_counters",
     "esmdiff_set_gibbs_options", "esmdiff_split_rows", "esmdiff_split_weight", "esmdiff_gemm_split",
-    "esmdiff_get_embeddings", "esmdiff_set_final_skip", "esmdiff_gemm_f16", "esmdiff_ddpm_step_margin", "esmdiff_forward_logits_sigmas",
+    "esmdiff_get_embeddings", "esmdiff_set_final_skip", "esmdiff_gemm_f16", "esmdiff_ddpm_step_margin", "esmdiff_forward_logits_sigmas", "esmdiff_set_small_batch_splitk",
 ]
 
 
@@ -120,6 +120,7 @@ def lib():
     L.esmdiff_set_gibbs_options.argtypes = [vp, i32, ctypes.POINTER(i32), i32]
     L.esmdiff_set_step0_sharing.argtypes = [vp, i32]
     L.esmdiff_set_final_skip.argtypes = [vp, i32]
+    L.esmdiff_set_small_batch_splitk.argtypes = [vp, i32]
     L.esmdiff_get_counters.argtypes = [vp, c_i64p, c_i64p, i32]
     L.esmdiff_gemm_f32.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     L.esmdiff_get_embeddings.argtypes = [vp, vp, i32, i32, vp]

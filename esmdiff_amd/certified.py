@@ -45,6 +45,8 @@ class CertifiedSampler:
         if not safety >= 1.0:
             raise ValueError("safety must be >= 1")
         self.fast, self.exact = fast, exact
+        if getattr(exact, "precision", None) == "f32_split":      # the re-runs are small batches: K-sliced residual linears
+            exact.set_small_batch_splitk(True)
         self.eps = None if eps is None else float(eps)          # None: safety x the largest error observed so far
         self.safety, self.eps_floor = float(safety), float(eps_floor)
         self.err_seen = 0.0                                     # largest |fast - exact| logit over masked rows, all calls

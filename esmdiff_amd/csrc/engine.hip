@@ -105,6 +105,11 @@ struct esmdiff_engine {
   std::vector<hipStream_t> side;
   std::vector<hipEvent_t> ev_join;
   hipEvent_t ev_fork = nullptr;
+  // F32_SPLIT, opt-in (esmdiff_set_small_batch_splitk): at <= splitk_max_rows rows the two residual linears (6 column tiles each)
+  // run K-sliced (out-proj 3 slices, FFN-down 4) so that a small batch uses more than a few dozen CUs; partial planes in sk_parts
+  bool splitk_small = false;
+  int splitk_max_rows = 4096;
+  float* sk_parts = nullptr;
   int64_t strict_dual_min_tokens = 8192;   // F32_SPLIT: two sub-batch streams from this many tokens (ESMDIFF_STRICT_DUAL_MIN_TOKENS)
   int64_t dual_min_tokens = 2200, dual_small_max_tokens = 1024;  // two streams from / small window up to (tokens), see forward()
   int stream_offset_us = 0;  // phase offset of the second sub-batch stream (ESMDIFF_STREAM_OFFSET_US), see forward()
@@ -404,6 +409,9 @@ static int strict_part(esmdiff_engine* e, const SPart& w, const float* cond, int
   hipStream_t st = w.st;
   const int B = w.B, M = B * L;
   Prof p{e, st};
+  // K-sliced residual linears: only where the slicing constraints hold for this model (3 D / 3 and 3 FH / 4 multiples of 128)
+  const bool sk = sp && e->splitk_small && e->sk_parts && M <= e->splitk_max_rows && e->kind == 0 && D % 128 == 0 && (3 * FH) % 512 == 0 &&
+                  D >= 384 && 3 * FH / 4 >= 384;
   if (e->kind == 1) RUN(S_EMBED, launch_gather_rows(w.xtok, e->e_struct, w.x, M, D, ESMDIFF_VOCAB, st));
   else RUN(S_EMBED, launch_embed(w.seq, w.xtok, e->e_seq, e->e_struct, e->cvec, cond, w.x, B, L, D, st, e->sigma_rows > 1 ? D : 0));
 #define LIN(section, sw, fw, A32, lda, Kdim, out, bias, n_rows, ldc, n_valid, div, epi)                                  \
@@ -427,7 +435,12 @@ static int strict_part(esmdiff_engine* e, const SPart& w, const float* cond, int
       RUN(S_QKROPE, launch_qk_norm_rope_f32(w.fqkv, ly.q_ln_w, ly.k_ln_w, e->rope_cos, e->rope_sin, w.fq, w.fk, B, L, H, st));
       RUN(S_ATTN, launch_attention_f32(w.fq, w.fk, w.fqkv, w.fctx, B, L, H, st));
     }
-    LIN(S_OUT, ly.s_out, ly.fw_out, w.fctx, D, D, w.x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
+    if (sk) {
+      RUN(S_OUT, launch_gemm256w4_splitk(a2, ly.s_out.w, ly.s_out.inv, e->sk_parts, M, D, D, 3, st));
+      RUN(S_OUT, launch_splitk_reduce_resid(e->sk_parts, rs, w.x, M, D, 3, c.residue_scale, st));
+    } else {
+      LIN(S_OUT, ly.s_out, ly.fw_out, w.fctx, D, D, w.x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
+    }
     if (i == 0 && geom) {   // x = x + geom_attn(s_norm(x), frames) / scaling_factor
       const bool gs = sp && e->s_gproj.w;
       if (gs) RUN(S_LN, launch_layernorm_split(w.x, e->g_snorm_w, nullptr, a2, rs, nullptr, M, D, 0, st));
@@ -444,8 +457,13 @@ static int strict_part(esmdiff_engine* e, const SPart& w, const float* cond, int
       // the next split row (w.a2b: [M, 3 FH], one scale per layer) — then FFN-down with that constant folded into its weight scale
       RUN(S_FFN_UP, launch_gemm256w4_split(a2, rs, ly.s_up.w, ly.s_up.inv, reinterpret_cast<float*>(w.a2b), nullptr, M, 2 * FH, D, 3 * FH,
                                            ly.mid_scale, 4, st));
-      RUN(S_FFN_DOWN, launch_gemm256w4_split(w.a2b, nullptr, ly.s_down.w, ly.s_down.inv / ly.mid_scale, w.x, nullptr, M, D, FH, D,
-                                             c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
+      if (sk) {
+        RUN(S_FFN_DOWN, launch_gemm256w4_splitk(w.a2b, ly.s_down.w, ly.s_down.inv / ly.mid_scale, e->sk_parts, M, D, FH, 4, st));
+        RUN(S_FFN_DOWN, launch_splitk_reduce_resid(e->sk_parts, nullptr, w.x, M, D, 4, c.residue_scale, st));
+      } else {
+        RUN(S_FFN_DOWN, launch_gemm256w4_split(w.a2b, nullptr, ly.s_down.w, ly.s_down.inv / ly.mid_scale, w.x, nullptr, M, D, FH, D,
+                                               c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
+      }
     } else {
       LIN(S_FFN_UP, ly.s_up, ly.fw_up, w.fh, D, D, w.fgu, nullptr, 2 * FH, 2 * FH, 2 * FH, 1.f, ESMDIFF_F32EPI_STORE);
       if (sp) RUN(S_FFN_UP, launch_swiglu_split(w.fgu, a2, rs, M, FH, st));
@@ -631,6 +649,18 @@ int esmdiff_set_step0_sharing(esmdiff_engine* e, int32_t on) {
 int esmdiff_set_final_skip(esmdiff_engine* e, int32_t on) {
   if (!e) return ESMDIFF_E_INVALID;
   e->final_skip = on ? 1 : 0;
+  return 0;
+}
+
+int esmdiff_set_small_batch_splitk(esmdiff_engine* e, int32_t on) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (on && !e->split) return fail(e, ESMDIFF_E_INVALID, "K-sliced small batches exist for the F32_SPLIT precision only");
+  if (on && !e->sk_parts) {
+    HIP_TRY(e, hipSetDevice(e->device));
+    const size_t n = (size_t)4 * ((e->splitk_max_rows + 255) / 256 * 256) * e->cfg.d_model;
+    if (int r = dalloc(e, &e->sk_parts, n)) return r;
+  }
+  e->splitk_small = on != 0;
   return 0;
 }
 

@@ -105,7 +105,12 @@ template <int EPI, int SPLIT = 0>
 __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                            void* __restrict__ out, const float* __restrict__ bias, int M,
                                                            int N, int K, int ldc, float alpha, int tiles_m, int tiles_n,
-                                                           const float* __restrict__ rs = nullptr, float div = 1.f) {
+                                                           const float* __restrict__ rs = nullptr, float div = 1.f,
+                                                           int ld_ab = 0, int m_pad = 0, int m_real = 0) {
+  // SPLIT == 2 (launch_gemm256w4_splitk): K slices of the SPLIT == 1 product as extra row blocks.  The grid walks
+  // S * m_pad "virtual" rows; virtual row block s = m0 / m_pad reads columns s*K .. (s+1)*K of the physical rows
+  // m0 - s*m_pad .. of A and of every W row (row stride ld_ab = the whole 3 K1 walk), and its f32 partial products go to
+  // rows m0 .. of `out` ([S * m_pad, N]).  Everything but the source addresses below is the SPLIT == 1 kernel.
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x 64 KiB
 
   const int n_tiles = tiles_m * tiles_n, bid = blockIdx.x;
@@ -136,9 +141,17 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16_t* __restr
     for (int h = 0; h < 2; ++h) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int am = min(m0_ + h * 128 + (i * 4 + wave) * 8 + srow, M - 1);
-        ao[h][i] = (uint32_t)(((int64_t)am * K + schunk * 8) * 2);
-        wo[h][i] = (uint32_t)(((int64_t)(n0_ + h * 128 + (i * 4 + wave) * 8 + srow) * K + schunk * 8) * 2);
+        if constexpr (SPLIT == 2) {
+          const int slice = m0_ / m_pad;
+          const int am = min(m0_ - slice * m_pad + h * 128 + (i * 4 + wave) * 8 + srow, m_real - 1);
+          const int64_t col = (int64_t)slice * K + schunk * 8;
+          ao[h][i] = (uint32_t)(((int64_t)am * ld_ab + col) * 2);
+          wo[h][i] = (uint32_t)(((int64_t)(n0_ + h * 128 + (i * 4 + wave) * 8 + srow) * ld_ab + col) * 2);
+        } else {
+          const int am = min(m0_ + h * 128 + (i * 4 + wave) * 8 + srow, M - 1);
+          ao[h][i] = (uint32_t)(((int64_t)am * K + schunk * 8) * 2);
+          wo[h][i] = (uint32_t)(((int64_t)(n0_ + h * 128 + (i * 4 + wave) * 8 + srow) * K + schunk * 8) * 2);
+        }
       }
     }
   };
@@ -535,6 +548,31 @@ hipError_t launch_gemm256w4_split(const uint16_t* A2, const float* rs, const uin
     default: return hipErrorInvalidValue;
   }
 #undef ED_GEMM_S
+  return hipGetLastError();
+}
+
+// The same product cut into S slices of the 3 K walk, for launches with too few tiles to fill the chip: parts[s] ([m_pad, N]
+// f32, m_pad = M rounded up to 256) = (slice s of A2) . (slice s of W2)^T * w_scale, row scales NOT applied; the caller sums
+// the slices in order and applies rs (gemm_split.hip::launch_splitk_reduce_resid).  3 K / S must be a multiple of 128.
+hipError_t launch_gemm256w4_splitk(const uint16_t* A2, const uint16_t* W2, float w_scale, float* parts, int M, int N, int K,
+                                   int S, hipStream_t stream) {
+  using namespace g4;
+  if (M <= 0) return hipSuccess;
+  if (S < 2 || N % BN != 0 || (3 * K) % S != 0 || ((3 * K) / S) % (2 * BK) != 0 || (3 * K) / S < 6 * BK) return hipErrorInvalidValue;
+  const int tiles_m_phys = (M + BM - 1) / BM, tiles_n = N / BN, m_pad = tiles_m_phys * BM;
+  const int tiles_m = S * tiles_m_phys;
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n >= 8 ? (n / 8) * 8 : 8;
+  }();
+  const int n_tiles = tiles_m * tiles_n;
+  dim3 grid(n_tiles < n_cu ? n_tiles : n_cu), block(256);
+  const size_t lds = 2 * STAGE_BYTES;
+  const hipError_t a_ = ensure_dynamic_lds((const void*)gemm256w4_kernel<ESMDIFF_F32EPI_STORE, 2>, (int)lds);
+  if (a_ != hipSuccess) return a_;
+  hipLaunchKernelGGL((gemm256w4_kernel<ESMDIFF_F32EPI_STORE, 2>), grid, block, lds, stream, A2, W2, (void*)parts, (const float*)nullptr,
+                     S * m_pad, N, (3 * K) / S, N, w_scale, tiles_m, tiles_n, (const float*)nullptr, 1.f, 3 * K, m_pad, M);
   return hipGetLastError();
 }
 

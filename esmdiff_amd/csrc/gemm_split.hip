@@ -291,7 +291,40 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const void* __restric
   dst[r * 3 * K + 2 * K + c] = hb;
 }
 
+// x[m, n] = x[m, n] + ((parts[0] + parts[1]) + ... + parts[S-1])[m, n] * rs[m] / div: the epilogue of the K-sliced split GEMM
+// (gemm256w4.hip::launch_gemm256w4_splitk) for the two residual linears.  parts: [S][m_pad, N] f32, slices summed in order; the
+// row scale is a power of two, so applying it after the sum is exact; `x + v / div` is the unsliced kernel's expression.
+__global__ __launch_bounds__(256) void splitk_reduce_resid_kernel(const float* __restrict__ parts, const float* __restrict__ rs,
+                                                                  float* __restrict__ x, int M, int N, int S, int64_t plane, float div) {
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one float4 per thread
+  const int n4 = N >> 2;
+  if (i4 >= (int64_t)M * n4) return;
+  const int m = (int)(i4 / n4);
+  const int64_t off = (int64_t)m * N + (i4 - (int64_t)m * n4) * 4;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(parts + off);
+  for (int s = 1; s < S; ++s) {
+    const f32x4 p = *reinterpret_cast<const f32x4*>(parts + s * plane + off);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = acc[e] + p[e];
+  }
+  const float sc = rs ? rs[m] : 1.0f;
+  f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) xv[e] = xv[e] + (acc[e] * sc) / div;
+  *reinterpret_cast<f32x4*>(x + off) = xv;
+}
+
 }  // namespace
+
+hipError_t launch_splitk_reduce_resid(const float* parts, const float* rs, float* x, int M, int N, int S, float div,
+                                      hipStream_t stream) {
+  if (M <= 0) return hipSuccess;
+  if ((N & 3) || S < 2) return hipErrorInvalidValue;
+  const int64_t plane = (int64_t)((M + 255) / 256 * 256) * N;
+  const int64_t n = (int64_t)M * (N >> 2);
+  hipLaunchKernelGGL(splitk_reduce_resid_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, parts, rs, x, M, N, S, plane, div);
+  return hipGetLastError();
+}
 
 hipError_t launch_split_rows(const float* src, int ld, uint16_t* dst, float* rs, int M, int K, hipStream_t stream) {
   if (M <= 0) return hipSuccess;

@@ -312,6 +312,11 @@ class Engine:
         bit-identical to the unshared run.  Off by default."""
         self._chk(self._lib.esmdiff_set_step0_sharing(self._h, int(bool(on))))
 
+    def set_small_batch_splitk(self, on: bool) -> None:
+        """F32_SPLIT engines: K-sliced residual linears for forwards of <= 4096 rows (esmdiff_set_small_batch_splitk) — faster
+        small batches, at the price of the bit-for-bit batch independence across that row count.  Off by default."""
+        self._chk(self._lib.esmdiff_set_small_batch_splitk(self._h, int(bool(on))))
+
     def set_final_skip(self, on: bool) -> None:
         """Exact skip of the noise-removal forward (esmdiff_set_final_skip): after the last update only the samples that still
         hold a MASK run forward T + 1 (none, almost always); ids are bit-identical to the full run.  Off by default."""

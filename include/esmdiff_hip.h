@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESMDIFF_ABI_VERSION 6   /* 6: + esmdiff_ddpm_step_margin, esmdiff_forward_logits_sigmas (additions only) */
+#define ESMDIFF_ABI_VERSION 6   /* 6: + esmdiff_ddpm_step_margin, esmdiff_forward_logits_sigmas, esmdiff_set_small_batch_splitk (additions only) */
 
 /* structure-track vocabulary: esm constants mirrored at model.py:380-381 */
 #define ESMDIFF_VOCAB 4101
@@ -149,6 +149,14 @@ int esmdiff_forward_logits(esmdiff_engine* eng, const int64_t* seq, const int64_
  * noise levels in one batch (a training-style evaluation of the denoiser, or samples at different updates in one forward). */
 int esmdiff_forward_logits_sigmas(esmdiff_engine* eng, const int64_t* seq, const int64_t* x, const float* t_freq,
                                   float* logits_out, int32_t ld_logits, int32_t B, int32_t L, void* stream);
+
+/* F32_SPLIT engines, off by default: forwards of at most 4096 rows run their two residual linears (out-proj, FFN-down: 6 column
+ * tiles each, i.e. a few dozen of the 256 CUs at such sizes) as K slices in ONE launch (3 and 4 slices as extra row blocks of the
+ * persistent GEMM) plus a pass that sums the slices in order and adds into the residual stream.  Float32 grade as before, but the
+ * summation order over K differs from the unsliced kernel's, so with the option ON a sample's last bits depend on whether its
+ * batch had more than 4096 rows; OFF (default) the engine stays batch-independent bit for bit.  Used by the certified sampler
+ * for its re-runs (small batches by construction). */
+int esmdiff_set_small_batch_splitk(esmdiff_engine* eng, int32_t on);
 
 /* ESMOutput.embeddings of the forward that just ran (net.py:468-469, :312-320: the transformer stack's pre-norm hidden
  * state, the second value `self.transformer(...)` returns): out f32 [B,L,d_model].  (B, L) must be the last forward's. */
