@@ -63,6 +63,31 @@ class CertifiedSampler:
         self.n_seen += int(e.numel())
         return e
 
+    def _rerun(self, i, idx, xs, sq, lg_fast, schedule, tf_exact, seed, sample_offset):
+        """Update i of the samples `idx` on the f32-grade engine (current stream): xs (their tokens before the update) -> their
+        certified tokens; also the largest fast-vs-exact logit difference per sample over its masked rows."""
+        exact, T = self.exact, schedule.num_steps
+        fin = i == T
+        mc_t = 0.0 if fin else float(schedule.mc_t[i])
+        mc_s = 0.0 if fin else float(schedule.mc_s[i])
+        out, errs = xs.clone(), []
+        for c0 in range(0, xs.shape[0], exact.max_batch):
+            sl = slice(c0, c0 + exact.max_batch)
+            lg2 = exact.forward_logits(xs[sl], sq[sl], None if tf_exact is None else tf_exact[i])
+            errs.append(((lg_fast[sl] - lg2).abs().amax(-1) * (xs[sl] == STRUCTURE_MASK_TOKEN)).amax(-1))
+            for j, b in enumerate(idx[sl].tolist()):
+                exact.ddpm_step(out[c0 + j:c0 + j + 1], lg2[j:j + 1], mc_t, mc_s, final=fin, seed=seed,
+                                sample_offset=sample_offset + b, step=i)
+        return out, torch.cat(errs)
+
+    def _account(self, e: torch.Tensor, eps_i: float, acc: dict) -> None:
+        """Error observations of a re-run: the running estimate, this call's maximum, the eps violations."""
+        m = float(e.max())
+        self.err_seen = max(self.err_seen, m)
+        self.n_seen += int(e.numel())
+        acc["err"] = max(acc["err"], m)
+        acc["viol"] += int((e > eps_i).sum())
+
     @torch.no_grad()
     def ddpm_sample(self, sequence_tokens: torch.Tensor, schedule: DDPMSchedule, *, seed: int, sample_offset: int = 0,
                     input_prior: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -84,7 +109,8 @@ class CertifiedSampler:
         logits = torch.empty(B, L, fast.ld_logits, dtype=torch.float32, device=dev)
         cap = exact.max_batch
         reruns = []
-        err_max, violations, skipped_final, probes_exact, probes_fast, eps_used = 0.0, 0, False, 0, 0, []
+        skipped_final, probes_exact, probes_fast, eps_used = False, 0, 0, []
+        acc = {"err": 0.0, "viol": 0}                               # largest logit error seen in this call, eps violations
         V = exact.cfg.n_structure_heads
         shared0 = input_prior is None and B > 1 and bool((seq == seq[:1]).all())
         for i in range(T + 1):
@@ -95,7 +121,7 @@ class CertifiedSampler:
                 lg1 = exact.forward_logits(x[:1], seq[:1], None if tf_exact is None else tf_exact[0])
                 if self.eps is None and self.n_seen == 0:          # start the error estimate on the same input
                     lgf = fast.forward_logits(x[:1], seq[:1], None if tf_fast is None else tf_fast[0])
-                    err_max = max(err_max, float(self._observe(lgf, lg1, x[:1]).max()))
+                    acc["err"] = max(acc["err"], float(self._observe(lgf, lg1, x[:1]).max()))
                     probes_fast += 1
                 logits[..., :V] = lg1
                 exact.ddpm_step(x, logits[..., :V], float(schedule.mc_t[0]), float(schedule.mc_s[0]), seed=seed,
@@ -115,7 +141,7 @@ class CertifiedSampler:
             if self.eps is None and self.n_seen < 3:              # thin estimate: two samples on both engines first
                 n = min(2, B)
                 lgp = exact.forward_logits(prev[:n], seq[:n], None if tf_exact is None else tf_exact[i])
-                err_max = max(err_max, float(self._observe(lg[:n], lgp, prev[:n]).max()))
+                acc["err"] = max(acc["err"], float(self._observe(lg[:n], lgp, prev[:n]).max()))
                 probes_exact += n
             eps_i = self._eps_now()
             eps_used.append(eps_i)
@@ -125,17 +151,13 @@ class CertifiedSampler:
                                   margin=diff if fin else ratio, flags=flags)
             sus = torch.nonzero(flags).flatten()                  # (device -> host sync, B int32)
             reruns.append(int(sus.numel()))
-            for c0 in range(0, int(sus.numel()), cap):
-                idx = sus[c0:c0 + cap]
-                xs = prev[idx].contiguous()
-                lg2 = exact.forward_logits(xs, seq[idx].contiguous(), None if tf_exact is None else tf_exact[i])
-                e = self._observe(lg[idx], lg2, xs)               # per re-run sample
-                err_max = max(err_max, float(e.max()))
-                violations += int((e > eps_i).sum())
-                for j, b in enumerate(idx.tolist()):
-                    exact.ddpm_step(xs[j:j + 1], lg2[j:j + 1], mc_t, mc_s, final=fin, seed=seed,
-                                    sample_offset=sample_offset + b, step=i)
-                x[idx] = xs
+            if int(sus.numel()) == 0:
+                continue
+            xs, sq, lgf = prev[sus], seq[sus], lg[sus]                       # (index gathers: fresh contiguous tensors)
+            xr, e = self._rerun(i, sus, xs, sq, lgf, schedule, tf_exact, seed, sample_offset)
+            self._account(e, eps_i, acc)
+            x[sus] = xr
+        err_max, violations = acc["err"], acc["viol"]
         used = [e_ for e_ in eps_used if e_ is not None]
         self.stats = {"samples": B, "updates": len(reruns), "eps": self.eps if self.eps is not None else "auto",
                       "safety": self.safety, "eps_min_used": min(used) if used else None, "eps_max_used": max(used) if used else None,

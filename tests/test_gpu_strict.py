@@ -961,6 +961,7 @@ def test_certified_sampler_equals_float32_chain_configs1_full_batch():
                      "sample_forwards_exact": st["sample_forwards_exact"], "sample_forwards_fast": st["sample_forwards_fast"],
                      "rerun_share": round(st["sample_forwards_exact"] / st["sample_forwards_fast"], 4),
                      "max_logit_err_observed": st["max_logit_err_observed"], "eps_violations": st["eps_violations"],
+
                      "rerun_per_update": st["rerun_per_update"]}
     exact.close()
     del sd
