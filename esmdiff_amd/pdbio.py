@@ -143,6 +143,67 @@ def merge_pdbfiles(input, save_to: Path, verbose: bool = True) -> None:
         print(f"Merged {len(pdb_files)} PDB files into {save_to} with {n_model} models.")
 
 
+def _backbone_coords_from_pdb(pdb_path, target_atoms=("N", "CA", "C")) -> np.ndarray:
+    """models/utils.py:240-267 without biotite: the backbone atoms named in `target_atoms` of every MODEL of a PDB file (a file
+    without MODEL records is one model) -> (n_models, L, len(target_atoms), 3), or (n_models, L, 3) for a single atom name.
+    ATOM records only, first alternate location; every model must hold the same number of each atom."""
+    want = {a: j for j, a in enumerate(target_atoms)}
+    models, cur = [], [[] for _ in target_atoms]
+
+    def close():
+        if any(cur):
+            n = {len(c) for c in cur}
+            if len(n) != 1:
+                raise ValueError(f"{pdb_path}: a model with unequal numbers of {list(target_atoms)} atoms ({[len(c) for c in cur]})")
+            arr = np.stack([np.asarray(c, dtype=np.float32) for c in cur], axis=1)        # L, na, 3
+            models.append(arr[:, 0] if len(target_atoms) == 1 else arr)
+            for c in cur:
+                c.clear()
+
+    with open(pdb_path) as fh:
+        for line in fh:
+            name = line[:6].strip()
+            if name in ("MODEL", "ENDMDL"):
+                close()
+            elif name == "ATOM" and line[16] in (" ", "A"):
+                j = want.get(line[12:16].strip())
+                if j is not None:
+                    cur[j].append((float(line[30:38]), float(line[38:46]), float(line[46:54])))
+    close()
+    if not models:
+        raise ValueError(f"no backbone ATOM records in {pdb_path}")
+    if len({m.shape for m in models}) != 1:
+        raise ValueError(f"{pdb_path}: models of different lengths {sorted({m.shape[0] for m in models})}")
+    return np.stack(models, axis=0)
+
+
+def load_coords(input_path, max_n_model: Optional[int] = 10000, uniform_sample: bool = True, ca_only: bool = True,
+                verbose: bool = True) -> np.ndarray:
+    """models/utils.py:274-317: the ensemble behind a path as an array for the metrics — a (multi-MODEL) .pdb, a .npy in nm
+    (scaled to Angstrom), a directory of .pdb files, or a glob pattern; CA only -> (n, L, 3), else N / CA / C -> (n, L, 3, 3).
+    More than max_n_model models: every (n // max_n_model)-th one (uniform_sample) or the first max_n_model."""
+    import glob as _glob
+    import os
+    assert os.path.exists(input_path) or _glob.glob(str(input_path)), f"File {input_path} does not exist."
+    input_path = Path(input_path)
+    atoms = ("CA",) if ca_only else ("N", "CA", "C")
+    if input_path.name.endswith(".pdb") and input_path.exists():
+        coords = _backbone_coords_from_pdb(input_path, atoms)
+    elif input_path.name.endswith(".npy"):
+        coords = np.load(input_path) / 0.1                    # nm -> Angstrom (coordinate_scale, models/utils.py:270-271)
+    elif input_path.is_dir():
+        coords = np.concatenate([_backbone_coords_from_pdb(f, atoms) for f in input_path.iterdir() if f.name.endswith(".pdb")], axis=0)
+    else:
+        # (the reference asserts os.path.exists first, which no pattern passes; here a pattern that matches files is accepted)
+        print("[Warning] Unrecoginzed path, infer as glob pattern")
+        coords = np.concatenate([_backbone_coords_from_pdb(f, atoms) for f in sorted(_glob.glob(str(input_path))) if f.endswith(".pdb")], axis=0)
+    if max_n_model is not None and len(coords) > max_n_model > 0:
+        coords = coords[::len(coords) // max_n_model] if uniform_sample else coords[:max_n_model]
+    if verbose:
+        print(f"Loaded {len(coords)} models from input: {input_path} (shape={coords.shape})")
+    return coords
+
+
 def split_pdbfile(input, output_dir=None, sep: str = "_", verbose: bool = True):
     """eval_utils.py:495-530, the inverse of merge_pdbfiles: one PDB string per MODEL block — its ATOM / TER records, closed by
     'END' — and, with output_dir, one file `<stem><sep><i>.pdb` per block.  Returns the list of strings."""

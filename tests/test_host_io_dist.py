@@ -81,6 +81,42 @@ def test_infer_oxygen_geometry(tmp_path):
     assert sum(ln.startswith("ATOM") for ln in (tmp_path / "n.pdb").read_text().splitlines()) == 3 * L
 
 
+def test_load_coords_reads_back_what_the_cli_writes(tmp_path):
+    """models/utils.py:274-317 `load_coords`: the evaluation scripts' way from an ensemble on disk to the (n, L, 3) array the
+    metrics take — here on this repository's own output: per-sample backbone PDBs merged into one multi-MODEL file."""
+    from esmdiff_amd.pdbio import load_coords, merge_pdbfiles, write_backbone_pdb
+    rng = np.random.default_rng(0)
+    n, L = 7, 12
+    seq = "ACDEFGHIKLMN"
+    bb = np.cumsum(rng.normal(size=(n, L, 3, 3)) * 0.3 + np.array([1.3, 0.2, 0.1]), axis=1).astype(np.float32)
+    for i in range(n):
+        write_backbone_pdb(tmp_path / f"s_{i}.pdb", seq, bb[i])
+    merge_pdbfiles([tmp_path / f"s_{i}.pdb" for i in range(n)], tmp_path / "ens.pdb", verbose=False)
+    ca = load_coords(tmp_path / "ens.pdb", verbose=False)
+    assert ca.shape == (n, L, 3) and np.allclose(ca, bb[:, :, 1], atol=6e-4)              # %8.3f records
+    full = load_coords(tmp_path / "ens.pdb", ca_only=False, verbose=False)
+    assert full.shape == (n, L, 3, 3) and np.allclose(full, bb, atol=6e-4)
+    # more models than wanted: uniform stride n // max (the reference's rule: 7 // 3 = 2 -> models 0, 2, 4, 6), or the first ones
+    assert np.array_equal(load_coords(tmp_path / "ens.pdb", max_n_model=3, verbose=False), ca[::2])
+    assert np.array_equal(load_coords(tmp_path / "ens.pdb", max_n_model=3, uniform_sample=False, verbose=False), ca[:3])
+    # a single-model file without MODEL records, a directory of them, a glob pattern, an .npy in nm
+    assert load_coords(tmp_path / "s_3.pdb", verbose=False).shape == (1, L, 3)
+    d = tmp_path / "dir"
+    d.mkdir()
+    for i in (1, 4):
+        (d / f"m{i}.pdb").write_text((tmp_path / f"s_{i}.pdb").read_text())
+    got = load_coords(d, verbose=False)
+    assert got.shape == (2, L, 3) and {tuple(np.round(g[0], 3)) for g in got} == {tuple(np.round(bb[i, 0, 1], 3)) for i in (1, 4)}
+    assert load_coords(str(tmp_path / "s_*.pdb"), verbose=False).shape == (n, L, 3)
+    np.save(tmp_path / "traj.npy", bb[:, :, 1] * 0.1)
+    assert np.allclose(load_coords(tmp_path / "traj.npy", verbose=False), bb[:, :, 1], rtol=1e-6)
+    with pytest.raises(AssertionError, match="does not exist"):
+        load_coords(tmp_path / "nope.pdb")
+    (tmp_path / "bad.pdb").write_text((tmp_path / "ens.pdb").read_text().replace(" CA  ASP A   3", " CB  ASP A   3", 1))
+    with pytest.raises(ValueError, match="unequal|different lengths"):
+        load_coords(tmp_path / "bad.pdb", verbose=False)
+
+
 def test_merge_pdbfiles_matches_reference_golden(golden_dir, tmp_path):
     from esmdiff_amd.pdbio import merge_pdbfiles
     g = json.loads((golden_dir / "g8_merge_pdb.json").read_text())
