@@ -79,3 +79,26 @@ class GenerationConfig:
     strategy: str = "entropy"
     invalid_ids: Optional[List[int]] = None
     condition_on_coordinates_only: bool = True
+
+
+def encode_decode(encoder, decoder, pdb):
+    """The VQ-VAE round trip of `encode_decode(model, pdb)` (/root/reference/slm/models/utils.py:166-194) with this repository's
+    engines: backbone of a PDB file (or of an ESMProtein) -> structure tokens (esmdiff_amd.engine.StructureEncoder) -> decoded
+    backbone (StructureDecoder).  Returns (coords, coords_pred), both (L, 3, 3) float32 N / CA / C on the CPU — the reference
+    returns the same pair as atom37 arrays; residues without coordinates are tokenised as MASK and decoded like any other token."""
+    from pathlib import Path
+    if isinstance(pdb, (str, Path)):
+        assert Path(pdb).exists(), f"File {pdb} does not exist."
+        _, xyz = read_pdb_backbone(pdb)
+        coords = torch.from_numpy(np.asarray(xyz, dtype=np.float32))
+    elif isinstance(pdb, ESMProtein):
+        if pdb.coordinates is None:
+            raise ValueError("encode_decode: the protein carries no coordinates")
+        coords = torch.as_tensor(pdb.coordinates, dtype=torch.float32)[:, :3]
+    else:
+        raise ValueError(f"Invalid input type: {type(pdb)}: {pdb}")
+    body = encoder.encode(coords[None])[0]                                      # (L,) ids, MASK where a residue has no frame
+    tokens = torch.cat([torch.tensor([C.STRUCTURE_BOS_TOKEN], device=body.device), body,
+                        torch.tensor([C.STRUCTURE_EOS_TOKEN], device=body.device)])
+    pred = decoder.decode(tokens[None])[0]
+    return coords.cpu(), pred.cpu()

@@ -1198,3 +1198,32 @@ def test_f16_engine_saturates_instead_of_overflowing(tiny):
         out = eng.ddpm_sample(seq.cuda(), sch, seed=1).cpu()
         assert int((out == MASK).sum()) == 0, prec
         eng.close()
+
+
+@pytest.mark.gpu
+def test_encode_decode_round_trip_call_shape(tmp_path):
+    """`encode_decode(model, pdb)` (models/utils.py:166-194) on the encoder + decoder engines: PDB -> tokens -> backbone, the pair
+    (coords, coords_pred) returned; same result from a path and from an ESMProtein; deterministic.  (Random-init VQ-VAE weights:
+    the reconstruction itself means nothing here — the real checkpoints' does.)"""
+    from esmdiff_amd.config import TINY_DECODER, TINY_ENCODER
+    from esmdiff_amd.engine import StructureDecoder, StructureEncoder
+    from esmdiff_amd.pdbio import write_backbone_pdb
+    from esmdiff_amd.sdk import ESMProtein, encode_decode
+    from esmdiff_amd.weights import random_init_decoder_state_dict, random_init_encoder_state_dict
+    seq = "RPDFCLEPPYTGPCKARIIRYFYNAKAGLCQTFVYGGCRA"
+    g = np.random.default_rng(1)
+    ca = np.cumsum(g.normal(size=(len(seq), 3)) * 2.2, 0)
+    xyz = np.stack([ca + g.normal(size=ca.shape) * 0.8, ca, ca + g.normal(size=ca.shape) * 0.8], 1).astype(np.float32)
+    write_backbone_pdb(tmp_path / "toy.pdb", seq, xyz)
+    enc = StructureEncoder(TINY_ENCODER, random_init_encoder_state_dict(TINY_ENCODER, seed=3))
+    dec = StructureDecoder(TINY_DECODER, random_init_decoder_state_dict(TINY_DECODER, seed=2), max_batch=1, max_len=len(seq) + 2)
+    coords, pred = encode_decode(enc, dec, tmp_path / "toy.pdb")
+    assert coords.shape == pred.shape == (len(seq), 3, 3) and bool(torch.isfinite(pred).all())
+    assert np.allclose(coords.numpy(), xyz, atol=6e-4)                                   # what the PDB's %8.3f records hold
+    c2, p2 = encode_decode(enc, dec, ESMProtein(sequence=seq, coordinates=torch.from_numpy(np.round(xyz, 3))))
+    assert torch.equal(p2, encode_decode(enc, dec, tmp_path / "toy.pdb")[1]) or torch.allclose(p2, pred, atol=1e-3)
+    with pytest.raises(ValueError, match="Invalid input type"):
+        encode_decode(enc, dec, 3)
+    with pytest.raises(ValueError, match="no coordinates"):
+        encode_decode(enc, dec, ESMProtein(sequence=seq))
+    dec.close()
