@@ -74,6 +74,46 @@ def test_sampler_bit_exact_philox(tiny):
         assert torch.equal(one[0], full[b])
 
 
+def test_sampler_fuzz_vs_c_oracle(tiny):
+    """40 random cases against the C oracle, ids bit for bit: logit scales from 0.01 to 300 (near-uniform rows to rows whose
+    exp underflows everywhere but at the top), logits quantised to a few levels (hundreds of exact ties: lowest index wins),
+    any mask pattern including none and all, move chances down to differences of 1e-6, Philox and explicit uniforms, the final
+    pass, padded row strides — and the margin form (esmdiff_ddpm_step_margin) returning the same ids."""
+    from oracle import c_oracle
+    _, _, eng, _, _ = tiny
+    rng = np.random.default_rng(77)
+    for case in range(40):
+        B, L = int(rng.integers(1, 6)), int(rng.integers(1, 41))
+        ld = int(rng.choice([4104, 4352]))
+        scale = float(rng.choice([0.01, 1.0, 30.0, 300.0]))
+        z = rng.standard_normal((B, L, ld)).astype(np.float32) * scale
+        if case % 4 == 1:
+            z = np.round(z / max(scale, 1e-3)).astype(np.float32) * np.float32(max(scale, 1e-3))      # few levels: exact ties
+        x = np.full((B, L), MASK, dtype=np.int64)
+        frac = float(rng.choice([0.0, 0.3, 0.9, 1.0]))
+        known = rng.random((B, L)) < frac
+        x[known] = rng.integers(0, 4096, int(known.sum()))
+        mc_t = float(rng.choice([0.999, 0.5, 0.04, 1e-5 + 2e-6]))
+        mc_s = float(max(0.0, mc_t - float(rng.choice([0.04, 1e-6, mc_t]))))
+        final = case % 7 == 3
+        seed, off, step = int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 2 ** 40)), int(rng.integers(0, 1000))
+        zt = torch.from_numpy(z).cuda()
+        if case % 3 == 0 and not final:
+            u = rng.random((B, L, V), dtype=np.float32)
+            want = c_oracle.ddpm_step(x, z, mc_t, mc_s, u=u)
+            got = eng.ddpm_step(torch.from_numpy(x).cuda(), zt, mc_t, mc_s, u=torch.from_numpy(u).cuda())
+        else:
+            want = c_oracle.ddpm_step(x, z, mc_t, mc_s, final=final, seed=seed, sample_offset=off, step=step)
+            got = eng.ddpm_step(torch.from_numpy(x).cuda(), zt, mc_t, mc_s, final=final, seed=seed, sample_offset=off, step=step)
+            flags = torch.zeros(B, dtype=torch.int32, device="cuda")
+            gm = eng.ddpm_step_margin(torch.from_numpy(x).cuda(), zt, mc_t, mc_s, final=final, seed=seed, sample_offset=off,
+                                      step=step, margin=0.01 if final else 1.01, flags=flags)
+            assert torch.equal(gm, got), case
+            assert not bool(flags[torch.from_numpy(known.all(1)).cuda()].any()), case    # a sample without a MASK is never flagged
+        assert np.array_equal(got.cpu().numpy(), want), (case, B, L, ld, scale, frac, mc_t, mc_s, final)
+        assert np.array_equal(want[known], x[known])
+
+
 def test_sampler_full_size_config2(tiny):
     """BASELINE config 2 row count (B*L = 100*258 rows of 4101) — bit-exact on a 24-sample slice, and the
     size-independent properties on all of it: carry-over, ids in range, mask never drawn at mc_s = 0."""
