@@ -942,6 +942,47 @@ def test_gibbs_step_bit_exact(tiny, tiny_stock, vocab, B, L, temp, top_p):
     assert int(got[(got != x.numpy())].max()) < 4096
 
 
+def test_gibbs_step_fuzz_vs_c_oracle(tiny, tiny_stock):
+    """30 random cases of the entropy-ordered unmasking step against the C oracle restatement, ids bit for bit: logit scales
+    0.05-100 (flat rows: huge nuclei; peaked rows: a nucleus of one), quantised logits (ties in the nucleus cut and in the
+    entropy ranking), temperatures 0.2-3, top-p 0.05-1.0, any number of positions to unmask including 0 and more than are
+    masked, both head widths, both noise sources."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(5)
+    for case in range(30):
+        vocab = 4101 if case % 2 else 4096
+        eng = tiny[2] if vocab == 4101 else tiny_stock
+        B, L = int(rng.integers(1, 5)), int(rng.integers(3, 41))
+        scale = float(rng.choice([0.05, 1.0, 10.0, 100.0]))
+        z = rng.standard_normal((B, L, 4104)).astype(np.float32) * scale
+        if case % 5 == 2:
+            z = np.round(z / max(scale, 1e-3)).astype(np.float32) * np.float32(max(scale, 1e-3))
+        if case % 3 == 0:
+            z[:, ::3, 4099] += 9.0 * scale                                   # heavy special id: the two widths differ
+        seq = np.concatenate([[0], rng.integers(4, 24, L - 2), [2]])[None].repeat(B, 0).astype(np.int64)
+        x = np.full((B, L), MASK, dtype=np.int64)
+        x[:, 0], x[:, -1] = 4098, 4097
+        known = rng.random((B, L)) < float(rng.choice([0.0, 0.5, 0.95]))
+        known[:, 0] = known[:, -1] = False
+        x[known] = rng.integers(0, 4096, int(known.sum()))
+        n_un = rng.integers(0, L + 2, B).astype(np.int32)
+        temp, top_p = float(rng.choice([0.2, 1.0, 1.4, 3.0])), float(rng.choice([0.05, 0.5, 0.9, 1.0]))
+        xt, st, zt, nt = torch.from_numpy(x).cuda(), torch.from_numpy(seq).cuda(), torch.from_numpy(z).cuda(), torch.from_numpy(n_un)
+        if case % 4 == 0:
+            u = rng.random((B, L, 4096), dtype=np.float32)
+            want = c_oracle.gibbs_step(x, seq, z, temp, top_p, n_un, u=u, vocab=vocab)
+            got = eng.gibbs_step(xt, st, zt, temp, top_p, nt, u=torch.from_numpy(u).cuda())
+        else:
+            seed, off, step = int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 2 ** 40)), int(rng.integers(0, 500))
+            want = c_oracle.gibbs_step(x, seq, z, temp, top_p, n_un, seed=seed, sample_offset=off, step=step, vocab=vocab)
+            got = eng.gibbs_step(xt, st, zt, temp, top_p, nt, seed=seed, sample_offset=off, step=step)
+        got = got.cpu().numpy()
+        assert np.array_equal(got, want), (case, vocab, B, L, scale, temp, top_p, n_un.tolist())
+        masked = (x == MASK).sum(1)
+        assert ((got != x).sum(1) == np.minimum(n_un, masked)).all(), case
+        assert np.array_equal(got[x != MASK], x[x != MASK])
+
+
 def test_gibbs_iterative_sampling_raw_and_cli(tiny, tmp_path):
     """The reference's gibbs call shape: lists of ESMProtein / GenerationConfig in, list of ESMProtein out."""
     from esmdiff_amd.gibbs import iterative_sampling_raw, unmask_schedule
