@@ -835,34 +835,37 @@ def test_ddpm_update_method_and_per_sample_t():
 
 def test_split_engine_small_batch_splitk(full48):
     """esmdiff_set_small_batch_splitk on the full 48-block F32_SPLIT engine: the two residual linears of a small forward run as K
-    slices (3 / 4) of the same product.  Still float32 grade — logits within 2e-5 of the option-off engine and of the oracle bar, the
-    26-update chain's ids unchanged — batch-independent WITHIN the small regime (a sample alone = the sample in a batch of 4, bit for
-    bit), and the option off again gives the original bits back."""
+    slices (3 / 4) of the same product.  Still float32 grade — logits within 2e-5 of the option-off engine and of the exact-f32
+    engine, the 26-update chain's ids unchanged — batch-independent WITHIN the small regime (a sample alone = the sample in a batch
+    of 4, bit for bit), and the option off again gives the original bits back.  Two sizes: 240 rows (one row tile) and 1 032 rows
+    (five row tiles, m_pad = 1 280: the virtual row blocks of the slices are 1 280 rows apart)."""
     cfg, strict, fast, net, emb = full48
     from esmdiff_amd.schedule import ddpm_schedule
     sp = _SPLIT48
-    B, L, T = 4, 60, 25
-    g = torch.Generator().manual_seed(31)
-    seq = _seq(B, L, g).cuda()
-    sch = ddpm_schedule(T, freq_dim=cfg.freq_dim)
-    x = torch.full((B, L), MASK, dtype=torch.int64, device="cuda")
-    x[:, 7:31] = torch.randint(0, 4096, (B, 24), generator=g).cuda()
-    off = sp.forward_logits(x, seq, sch.t_freq[4]).clone()
-    ids_off = sp.ddpm_sample(seq, sch, seed=3)
-    ref = strict.forward_logits(x, seq, sch.t_freq[4]).clone()
-    sp.set_small_batch_splitk(True)
-    try:
-        on = sp.forward_logits(x, seq, sch.t_freq[4]).clone()
-        alone = sp.forward_logits(x[2:3], seq[2:3], sch.t_freq[4]).clone()
-        ids_on = sp.ddpm_sample(seq, sch, seed=3)
-    finally:
-        sp.set_small_batch_splitk(False)
-    again = sp.forward_logits(x, seq, sch.t_freq[4])
-    rec = {"max_abs_on_vs_off": float((on - off).abs().max()), "max_abs_on_vs_exact_f32": float((on - ref).abs().max()),
-           "max_abs_off_vs_exact_f32": float((off - ref).abs().max()), "bits_differ": not torch.equal(on, off)}
+    rec = {}
+    for B, L, T in ((4, 60, 25), (4, 258, 3)):
+        g = torch.Generator().manual_seed(31 + L)
+        seq = _seq(B, L, g).cuda()
+        sch = ddpm_schedule(T, freq_dim=cfg.freq_dim)
+        x = torch.full((B, L), MASK, dtype=torch.int64, device="cuda")
+        x[:, 7:31] = torch.randint(0, 4096, (B, 24), generator=g).cuda()
+        off = sp.forward_logits(x, seq, sch.t_freq[2]).clone()
+        ids_off = sp.ddpm_sample(seq, sch, seed=3)
+        ref = strict.forward_logits(x, seq, sch.t_freq[2]).clone()
+        sp.set_small_batch_splitk(True)
+        try:
+            on = sp.forward_logits(x, seq, sch.t_freq[2]).clone()
+            alone = sp.forward_logits(x[2:3], seq[2:3], sch.t_freq[2]).clone()
+            ids_on = sp.ddpm_sample(seq, sch, seed=3)
+        finally:
+            sp.set_small_batch_splitk(False)
+        again = sp.forward_logits(x, seq, sch.t_freq[2])
+        r = {"max_abs_on_vs_off": float((on - off).abs().max()), "max_abs_on_vs_exact_f32": float((on - ref).abs().max()),
+             "max_abs_off_vs_exact_f32": float((off - ref).abs().max()), "bits_differ": not torch.equal(on, off)}
+        rec[f"B{B}_L{L}"] = r
+        assert r["max_abs_on_vs_off"] < 2e-5 and r["max_abs_on_vs_exact_f32"] < 2e-5, r
+        assert torch.equal(alone, on[2:3]) and torch.equal(again, off) and torch.equal(ids_on, ids_off), r
     _record("split_small_batch_splitk", rec)
-    assert rec["max_abs_on_vs_off"] < 2e-5 and rec["max_abs_on_vs_exact_f32"] < 2e-5, rec
-    assert torch.equal(alone, on[2:3]) and torch.equal(again, off) and torch.equal(ids_on, ids_off), rec
     with pytest.raises(RuntimeError, match="F32_SPLIT"):
         fast.set_small_batch_splitk(True)
 
