@@ -410,6 +410,8 @@ static int strict_part(esmdiff_engine* e, const SPart& w, const float* cond, int
   const int B = w.B, M = B * L;
   Prof p{e, st};
   // K-sliced residual linears: only where the slicing constraints hold for this model (3 D / 3 and 3 FH / 4 multiples of 128)
+  // this part's slice planes: the parts of a two-stream forward use disjoint regions (4 planes of its padded rows each)
+  float* const skp = e->sk_parts ? e->sk_parts + (size_t)4 * D * ((size_t)round_up((int)((w.x - e->x) / D), 256) + (w.x != e->x ? 256 : 0)) : nullptr;
   const bool sk = sp && e->splitk_small && e->sk_parts && M <= e->splitk_max_rows && e->kind == 0 && D % 128 == 0 && (3 * FH) % 512 == 0 &&
                   D >= 384 && 3 * FH / 4 >= 384;
   if (e->kind == 1) RUN(S_EMBED, launch_gather_rows(w.xtok, e->e_struct, w.x, M, D, ESMDIFF_VOCAB, st));
@@ -436,8 +438,8 @@ static int strict_part(esmdiff_engine* e, const SPart& w, const float* cond, int
       RUN(S_ATTN, launch_attention_f32(w.fq, w.fk, w.fqkv, w.fctx, B, L, H, st));
     }
     if (sk) {
-      RUN(S_OUT, launch_gemm256w4_splitk(a2, ly.s_out.w, ly.s_out.inv, e->sk_parts, M, D, D, 3, st));
-      RUN(S_OUT, launch_splitk_reduce_resid(e->sk_parts, rs, w.x, M, D, 3, c.residue_scale, st));
+      RUN(S_OUT, launch_gemm256w4_splitk(a2, ly.s_out.w, ly.s_out.inv, skp, M, D, D, 3, st));
+      RUN(S_OUT, launch_splitk_reduce_resid(skp, rs, w.x, M, D, 3, c.residue_scale, st));
     } else {
       LIN(S_OUT, ly.s_out, ly.fw_out, w.fctx, D, D, w.x, nullptr, D, D, D, c.residue_scale, ESMDIFF_F32EPI_RESID_DIV);
     }
@@ -458,8 +460,8 @@ static int strict_part(esmdiff_engine* e, const SPart& w, const float* cond, int
       RUN(S_FFN_UP, launch_gemm256w4_split(a2, rs, ly.s_up.w, ly.s_up.inv, reinterpret_cast<float*>(w.a2b), nullptr, M, 2 * FH, D, 3 * FH,
                                            ly.mid_scale, 4, st));
       if (sk) {
-        RUN(S_FFN_DOWN, launch_gemm256w4_splitk(w.a2b, ly.s_down.w, ly.s_down.inv / ly.mid_scale, e->sk_parts, M, D, FH, 4, st));
-        RUN(S_FFN_DOWN, launch_splitk_reduce_resid(e->sk_parts, nullptr, w.x, M, D, 4, c.residue_scale, st));
+        RUN(S_FFN_DOWN, launch_gemm256w4_splitk(w.a2b, ly.s_down.w, ly.s_down.inv / ly.mid_scale, skp, M, D, FH, 4, st));
+        RUN(S_FFN_DOWN, launch_splitk_reduce_resid(skp, nullptr, w.x, M, D, 4, c.residue_scale, st));
       } else {
         RUN(S_FFN_DOWN, launch_gemm256w4_split(w.a2b, nullptr, ly.s_down.w, ly.s_down.inv / ly.mid_scale, w.x, nullptr, M, D, FH, D,
                                                c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
@@ -655,9 +657,11 @@ int esmdiff_set_final_skip(esmdiff_engine* e, int32_t on) {
 int esmdiff_set_small_batch_splitk(esmdiff_engine* e, int32_t on) {
   if (!e) return ESMDIFF_E_INVALID;
   if (on && !e->split) return fail(e, ESMDIFF_E_INVALID, "K-sliced small batches exist for the F32_SPLIT precision only");
+  if (const char* mr = getenv("ESMDIFF_SPLITK_MAX_ROWS")) e->splitk_max_rows = atoi(mr);   // (experiments: K-sliced at every size)
   if (on && !e->sk_parts) {
     HIP_TRY(e, hipSetDevice(e->device));
-    const size_t n = (size_t)4 * ((e->splitk_max_rows + 255) / 256 * 256) * e->cfg.d_model;
+    const int64_t rows = std::min<int64_t>(e->splitk_max_rows, (int64_t)e->cfg.max_batch * e->cfg.max_len);
+    const size_t n = (size_t)4 * (size_t)((rows + 255) / 256 * 256 + 512) * e->cfg.d_model;
     if (int r = dalloc(e, &e->sk_parts, n)) return r;
   }
   e->splitk_small = on != 0;
