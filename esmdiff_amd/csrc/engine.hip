@@ -661,7 +661,8 @@ int esmdiff_set_small_batch_splitk(esmdiff_engine* e, int32_t on) {
   if (on && !e->sk_parts) {
     HIP_TRY(e, hipSetDevice(e->device));
     const int64_t rows = std::min<int64_t>(e->splitk_max_rows, (int64_t)e->cfg.max_batch * e->cfg.max_len);
-    const size_t n = (size_t)4 * (size_t)((rows + 255) / 256 * 256 + 512) * e->cfg.d_model;
+    // two parts of a two-stream forward may both qualify (e.g. 2 x 4096 rows): room for two padded parts + the part offset
+    const size_t n = (size_t)4 * (size_t)(2 * ((rows + 255) / 256 * 256) + 512) * e->cfg.d_model;
     if (int r = dalloc(e, &e->sk_parts, n)) return r;
   }
   e->splitk_small = on != 0;

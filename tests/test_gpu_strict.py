@@ -870,6 +870,30 @@ def test_split_engine_small_batch_splitk(full48):
         fast.set_small_batch_splitk(True)
 
 
+def test_split_splitk_two_stream_parts_at_the_row_limit():
+    """8 192 tokens = the two-stream threshold of the F32_SPLIT forward, cut into two parts of 4 096 rows = the K-slicing limit:
+    both parts run K-sliced, each in its own region of the slice planes (a sizing bug once let the second part write past the
+    allocation).  TINY model; logits equal to the same samples run one by one (small regime, same slicing), bit for bit."""
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    B, L = 32, 256
+    eng = Engine(TINY, random_init_state_dict(TINY, seed=1), max_batch=B, max_len=L, precision="f32_split")
+    eng.set_small_batch_splitk(True)
+    g = torch.Generator().manual_seed(8)
+    seq = _seq(B, L, g).cuda()
+    x = torch.full((B, L), MASK, dtype=torch.int64, device="cuda")
+    x[:, 9:40] = torch.randint(0, 4096, (B, 31), generator=g).cuda()
+    sch = ddpm_schedule(4, freq_dim=TINY.freq_dim)
+    both = eng.forward_logits(x, seq, sch.t_freq[1]).clone()
+    for b in (0, 15, 16, 31):
+        assert torch.equal(eng.forward_logits(x[b:b + 1], seq[b:b + 1], sch.t_freq[1]), both[b:b + 1]), b
+    out = eng.ddpm_sample(seq, sch, seed=2)
+    assert int((out == MASK).sum()) == 0
+    eng.close()
+
+
 def test_ddpm_step_margin_same_ids_and_flags():
     """esmdiff_ddpm_step_margin: the ids are esmdiff_ddpm_step's bit for bit; the per-sample flags follow the runner-up test
     (checked against a torch restatement of the race on the same Philox uniforms via explicit `u` on the plain step)."""
