@@ -330,7 +330,8 @@ def get_argparser(argv=None):
                         "reference's own float32 arithmetic on the f32-input MFMA (ids equal to a float32 run of the same seed; ~1/12 "
                         "of the throughput); f32_split = float32-grade linears as three f16 MFMA passes over split operands (~1/4); f16 = the "
                         "bf16 path with IEEE-half operands (same speed, 1/8 of the rounding error); certified = the f16 engine draws and only the "
-                        "samples with a close call are re-run on an f32_split engine for that update: the f32_split chain's ids at ~2x its rate")
+                        "samples with a close call are re-run on an f32_split engine for that update: the f32_split chain's ids at ~2x its rate "
+                        "(--mode ddpm; the gibbs mode has no certified form and runs on the f32_split engine)")
     p.add_argument("--head_precision", choices=["bf16", "f32"], default="bf16",
                    help="bf16 network only: final LayerNorm + output head in float32 grade (+1 %% time, fewer near-tie flips)")
     p.add_argument("--decoder_precision", choices=["f32", "f32_split", "bf16"], default="f32",
