@@ -1304,7 +1304,7 @@ int esmdiff_gibbs_step(esmdiff_engine* e, int64_t* x_inout, const int64_t* seq, 
   if (!e) return ESMDIFF_E_INVALID;
   if (!x_inout || !seq || !logits || !n_unmask) return fail(e, ESMDIFF_E_INVALID, "null pointer");
   if (!u && !rng) return fail(e, ESMDIFF_E_INVALID, "need explicit uniforms or an rng");
-  if (!(temperature > 0.f)) return fail(e, ESMDIFF_E_INVALID, "temperature must be > 0 (argmax decoding is not built)");
+  if (!(temperature >= 0.f)) return fail(e, ESMDIFF_E_INVALID, "temperature must be >= 0 (0 = arg-max of the filtered logits)");
   if (!(top_p > 0.f) || top_p > 1.f) return fail(e, ESMDIFF_E_INVALID, "top_p must be in (0, 1]");
   if (ld_logits < 4096 || e->cfg.vocab_out < 4096 || ld_logits < e->cfg.vocab_out) return fail(e, ESMDIFF_E_INVALID, "bad shape");
   if (int r = check_bl(e, B, L)) return r;
@@ -1327,7 +1327,7 @@ int esmdiff_gibbs_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout
   if (T <= 0 || T > e->tfreq_rows) return fail(e, ESMDIFF_E_INVALID, "num_steps %d out of range (1..%d)", T, e->tfreq_rows);
   if (int r = check_bl(e, B, L)) return r;
   hipStream_t st = (hipStream_t)stream;
-  if (!(temperature > 0.f)) return fail(e, ESMDIFF_E_INVALID, "temperature must be > 0 (argmax decoding is not built)");
+  if (!(temperature >= 0.f)) return fail(e, ESMDIFF_E_INVALID, "temperature must be >= 0 (0 = arg-max of the filtered logits)");
   if (!(top_p > 0.f) || top_p > 1.f) return fail(e, ESMDIFF_E_INVALID, "top_p must be in (0, 1]");
   HIP_TRY(e, hipMemcpyAsync(e->g_nunmask, n_unmask_table, (size_t)T * B * sizeof(int32_t), hipMemcpyHostToDevice, st));
   int shared = 0;

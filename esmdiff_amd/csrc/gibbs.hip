@@ -128,11 +128,16 @@ __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restric
     }
     const bool keep = (top_p >= 1.0f) || g_key(zz[j]) > tau || zz[j] == m;
     if (keep) {
-      const float w = ed_expf((zz[j] - m) * inv_temperature);
-      const float uu = use_philox ? ed_philox_uniform(seed, sample_offset + (uint64_t)b, (uint32_t)step, (uint32_t)l, (uint32_t)v)
-                                  : urow[v];
-      const float g = 1e-10f - ed_logf(uu + 1e-10f);
-      const float val = w / g;
+      float val;
+      if (inv_temperature == 0.0f) {   // temperature 0: arg-max of the kept valid logits, no noise (esm's sample_logits)
+        val = (zz[j] - m) + 2.0f;      // > the initial -1 for everything within 3 of the row maximum; the maximum itself is kept
+      } else {
+        const float w = ed_expf((zz[j] - m) * inv_temperature);
+        const float uu = use_philox ? ed_philox_uniform(seed, sample_offset + (uint64_t)b, (uint32_t)step, (uint32_t)l, (uint32_t)v)
+                                    : urow[v];
+        const float g = 1e-10f - ed_logf(uu + 1e-10f);
+        val = w / g;
+      }
       if (val > best) {
         best = val;
         best_i = v;
@@ -217,9 +222,9 @@ hipError_t launch_gibbs_step(int64_t* x, const int64_t* seq, const float* logits
                              uint64_t sample_offset, int step, int32_t* sampled, float* entropy, int B, int L,
                              hipStream_t stream, int logits_period, int strategy, const uint32_t* inv_mask) {
   if (B <= 0 || L <= 0) return hipSuccess;
-  if (L > 1280 || vocab < G_NVALID || vocab > G_PER * GNT || ld < vocab || !(temperature > 0.f)) return hipErrorInvalidValue;
+  if (L > 1280 || vocab < G_NVALID || vocab > G_PER * GNT || ld < vocab || !(temperature >= 0.f)) return hipErrorInvalidValue;
   if (strategy != 0 && (strategy != 1 || !use_philox)) return hipErrorInvalidValue;   // random positions need the Philox source
-  hipLaunchKernelGGL(gibbs_row_kernel, dim3(B * L), dim3(GNT), 0, stream, x, logits, ld, vocab, 1.0f / temperature, top_p, u,
+  hipLaunchKernelGGL(gibbs_row_kernel, dim3(B * L), dim3(GNT), 0, stream, x, logits, ld, vocab, temperature > 0.f ? 1.0f / temperature : 0.0f, top_p, u,
                      use_philox, seed, sample_offset, step, L, sampled, entropy, logits_period, strategy, inv_mask);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;

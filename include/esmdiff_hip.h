@@ -216,7 +216,8 @@ int esmdiff_get_counters(esmdiff_engine* eng, int64_t* forwards, int64_t* token_
  * it in "gibbs" mode (sample_esmdiff.py:114-122; [ESM-RECALL]): for every still-masked position
  * entropy of softmax(logits over the 4096 codebook ids), nucleus filter (top_p), temperature, categorical draw; then
  * per prompt the n_unmask[b] lowest-entropy masked positions (never BOS/EOS/PAD of `seq`) take their token.
- * n_unmask: [B] int32 DEVICE; u: explicit uniforms [B,L,4096] or NULL with rng; temperature > 0. */
+ * n_unmask: [B] int32 DEVICE; u: explicit uniforms [B,L,4096] or NULL with rng; temperature >= 0 (0: the arg-max
+ * of the filtered logits, no noise drawn — esm's sample_logits [ESM-RECALL]). */
 int esmdiff_gibbs_step(esmdiff_engine* eng, int64_t* x_inout, const int64_t* seq, const float* logits,
                        int32_t ld_logits, float temperature, float top_p, const int32_t* n_unmask, const float* u,
                        const esmdiff_rng* rng, int32_t step, int32_t B, int32_t L, void* stream);

@@ -57,9 +57,12 @@ def gibbs_step_ref(x, seq, logits, temperature, top_p, n_unmask, u, vocab: int =
     dead = torch.isinf(zp).all(-1, keepdim=True)
     best_valid = torch.nn.functional.one_hot(zv.argmax(-1), NVALID).bool()
     zp = torch.where(dead & best_valid, torch.zeros_like(zp), zp)
-    w = torch.softmax(zp / temperature, -1)
-    g = 1e-10 - (u + 1e-10).log()
-    sampled = (w / g).argmax(-1)
+    if temperature == 0:                                  # esm's sample_logits: arg-max of the filtered logits, no noise
+        sampled = zp.argmax(-1)
+    else:
+        w = torch.softmax(zp / temperature, -1)
+        g = 1e-10 - (u + 1e-10).log()
+        sampled = (w / g).argmax(-1)
     x = x.clone()
     for b in range(x.shape[0]):
         elig = (x[b] == MASK) & (seq[b] != 0) & (seq[b] != 1) & (seq[b] != 2)

@@ -61,6 +61,28 @@ def test_c_oracle_matches_torch_semantics(vocab):
         assert xc[changed].max() < 4096
 
 
+@pytest.mark.parametrize("vocab", [4096, 4101])
+def test_temperature_zero_is_argmax_of_the_filtered_logits(vocab):
+    """temperature = 0 [ESM-RECALL: esm's sample_logits takes the arg-max then]: the draw is the largest kept valid logit — no
+    noise enters (any uniforms, any seed: same ids), the nucleus cannot change it (the maximum is always kept) unless the
+    maximum is a special id, in which case the best valid id of the nucleus / of the row is taken; entropy ordering unchanged."""
+    for (B, L, seed, scale, top_p) in ((2, 9, 0, 2.0, 0.9), (3, 12, 1, 4.0, 0.3), (2, 8, 2, 1.0, 1.0)):
+        logits, u, seq, x = _case(B, L, seed, scale)
+        logits[:, 1::3, 4097] += 5.0 * scale
+        n_un = torch.tensor([3, 2, 4][:B], dtype=torch.int32)
+        xr, ent_r, smp_r = G.gibbs_step_ref(x, seq, logits, 0.0, top_p, n_un, u, vocab=vocab)
+        xc, ent_c, smp_c = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 0.0, top_p, n_un.numpy(), u=u.numpy(),
+                                               return_aux=True, vocab=vocab)
+        masked = (x == 4096).numpy()
+        assert np.array_equal(smp_c[masked], smp_r.numpy()[masked]) and np.array_equal(xc, xr.numpy())
+        assert np.array_equal(smp_c[masked], logits[..., :4096].argmax(-1).numpy()[masked])     # the best valid id, in every case
+        x2 = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 0.0, top_p, n_un.numpy(), seed=123, sample_offset=9, step=3,
+                                 vocab=vocab)
+        assert np.array_equal(x2, xc)                                                            # no noise: the seed does not matter
+        x14 = c_oracle.gibbs_step(x.numpy(), seq.numpy(), logits.numpy(), 1.4, top_p, n_un.numpy(), u=u.numpy(), vocab=vocab)
+        assert ((x14 != x.numpy()) == (xc != x.numpy())).all()                                   # same positions (entropy order), other ids
+
+
 def test_full_row_semantics_differ_from_truncated_row():
     """4101-way head: a heavy special id takes nucleus mass and entropy (esm runs top_p_logits and the entropy on the whole
     row and masks invalid ids afterwards), so fewer valid ids survive than on the truncated row; and when the special id

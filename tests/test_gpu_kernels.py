@@ -945,7 +945,7 @@ def test_gibbs_step_bit_exact(tiny, tiny_stock, vocab, B, L, temp, top_p):
 def test_gibbs_step_fuzz_vs_c_oracle(tiny, tiny_stock):
     """30 random cases of the entropy-ordered unmasking step against the C oracle restatement, ids bit for bit: logit scales
     0.05-100 (flat rows: huge nuclei; peaked rows: a nucleus of one), quantised logits (ties in the nucleus cut and in the
-    entropy ranking), temperatures 0.2-3, top-p 0.05-1.0, any number of positions to unmask including 0 and more than are
+    entropy ranking), temperatures 0 (arg-max) and 0.2-3, top-p 0.05-1.0, any number of positions to unmask including 0 and more than are
     masked, both head widths, both noise sources."""
     from oracle import c_oracle
     rng = np.random.default_rng(5)
@@ -966,7 +966,7 @@ def test_gibbs_step_fuzz_vs_c_oracle(tiny, tiny_stock):
         known[:, 0] = known[:, -1] = False
         x[known] = rng.integers(0, 4096, int(known.sum()))
         n_un = rng.integers(0, L + 2, B).astype(np.int32)
-        temp, top_p = float(rng.choice([0.2, 1.0, 1.4, 3.0])), float(rng.choice([0.05, 0.5, 0.9, 1.0]))
+        temp, top_p = float(rng.choice([0.0, 0.2, 1.0, 1.4, 3.0])), float(rng.choice([0.05, 0.5, 0.9, 1.0]))   # 0: arg-max
         xt, st, zt, nt = torch.from_numpy(x).cuda(), torch.from_numpy(seq).cuda(), torch.from_numpy(z).cuda(), torch.from_numpy(n_un)
         if case % 4 == 0:
             u = rng.random((B, L, 4096), dtype=np.float32)
