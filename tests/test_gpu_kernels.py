@@ -1221,8 +1221,8 @@ def test_engine_error_behaviour(tiny):
     with pytest.raises(ValueError):
         eng.ddpm_step(torch.full((1, 4), MASK, dtype=torch.int64).cuda(), lg, 0.5, 0.4)
     with pytest.raises(RuntimeError, match="temperature"):
-        eng.gibbs_step(torch.full((1, 4), MASK, dtype=torch.int64).cuda(), torch.zeros(1, 4, dtype=torch.int64), lg, 0.0, 0.9,
-                       torch.ones(1, dtype=torch.int32), seed=1)
+        eng.gibbs_step(torch.full((1, 4), MASK, dtype=torch.int64).cuda(), torch.zeros(1, 4, dtype=torch.int64), lg, -0.5, 0.9,
+                       torch.ones(1, dtype=torch.int32), seed=1)                 # (0 is arg-max decoding; negative is refused)
     # the engine keeps working after errors
     out = eng.ddpm_sample(torch.tensor([[0, 5, 6, 7, 2]]).cuda(), ddpm_schedule(2), seed=0)
     assert out.shape == (1, 5) and int((out == MASK).sum()) == 0
