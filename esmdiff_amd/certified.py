@@ -37,7 +37,8 @@ class CertifiedSampler:
     """fast: a reduced-precision Engine (f16 recommended: its logit error is 8x below bf16's, so 8x fewer close calls);
     exact: an f32-grade Engine of the same checkpoint (precision 'f32_split' or 'f32')."""
 
-    def __init__(self, fast: Engine, exact: Engine, eps: Optional[float] = None, safety: float = 2.0, eps_floor: float = 1e-5):
+    def __init__(self, fast: Engine, exact: Engine, eps: Optional[float] = None, safety: float = 2.0, eps_floor: float = 1e-5,
+                 fast_reruns: bool = False):
         if fast.device != exact.device:
             raise ValueError("both engines must live on the same GPU")
         if eps is not None and not eps > 0:
@@ -45,8 +46,12 @@ class CertifiedSampler:
         if not safety >= 1.0:
             raise ValueError("safety must be >= 1")
         self.fast, self.exact = fast, exact
-        if getattr(exact, "precision", None) == "f32_split":      # the re-runs are small batches: K-sliced residual linears
-            exact.set_small_batch_splitk(True)
+        # fast_reruns: the re-runs are small batches, and the F32_SPLIT engine can run their residual linears K-sliced
+        # (esmdiff_set_small_batch_splitk: 2.8 -> 2.6 s at configs[1]).  That is another float32-grade evaluation — its logits
+        # differ from the same engine's large-batch ones in the last bits (<= 1.1e-6) — so a draw tied to within that can come out
+        # differently: over 30 seeds at configs[1] one id of one run differed from the engine's own chain (and none with the
+        # option off, where the certified chain IS the exact engine's chain as long as eps holds).  Off by default.
+        self.fast_reruns = bool(fast_reruns)
         self.eps = None if eps is None else float(eps)          # None: safety x the largest error observed so far
         self.safety, self.eps_floor = float(safety), float(eps_floor)
         self.err_seen = 0.0                                     # largest |fast - exact| logit over masked rows, all calls
@@ -93,6 +98,8 @@ class CertifiedSampler:
                     input_prior: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Same arguments and result layout as Engine.ddpm_sample.  self.stats holds the re-run counts of the call."""
         fast, exact = self.fast, self.exact
+        if getattr(exact, "precision", None) == "f32_split":      # (per call: two samplers may share one f32-grade engine)
+            exact.set_small_batch_splitk(self.fast_reruns)
         B, L = sequence_tokens.shape
         dev = fast.device
         seq = sequence_tokens.to(device=dev, dtype=torch.int64).contiguous()
@@ -162,7 +169,7 @@ class CertifiedSampler:
         self.stats = {"samples": B, "updates": len(reruns), "eps": self.eps if self.eps is not None else "auto",
                       "safety": self.safety, "eps_min_used": min(used) if used else None, "eps_max_used": max(used) if used else None,
                       "rerun_per_update": reruns, "max_logit_err_observed": err_max, "max_logit_err_all_calls": self.err_seen,
-                      "eps_violations": violations, "first_update_shared": shared0,
+                      "eps_violations": violations, "first_update_shared": shared0, "fast_reruns": self.fast_reruns,
                       "sample_forwards_exact": int(sum(reruns)) + int(shared0) + probes_exact,
                       "sample_forwards_fast": B * (len(reruns) - int(shared0) - int(skipped_final)) + probes_fast}
         return x

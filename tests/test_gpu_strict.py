@@ -970,9 +970,10 @@ def test_certified_sampler_equals_float32_chain_configs1_full_batch():
     out = {"B": B, "L_tok": L, "steps": T, "referee": "exact-f32 engine chain", "f32_split_alone_seconds": round(t_split, 2),
            "f32_split_alone_equal": bool(torch.equal(sp, ref))}
     for name, kw, eps in (("f16", {"precision": "f16"}, 4e-3), ("f16_f32head", {"precision": "f16", "head_precision": "f32"}, 2.5e-3),
-                          ("f16_f32head_auto", {"precision": "f16", "head_precision": "f32"}, None), ("bf16", {}, 0.03)):
+                          ("f16_f32head_auto", {"precision": "f16", "head_precision": "f32"}, None),
+                          ("f16_f32head_auto_fast_reruns", {"precision": "f16", "head_precision": "f32"}, None), ("bf16", {}, 0.03)):
         fast = Engine(cfg, sd, max_batch=B, max_len=L, **kw)
-        cs = CertifiedSampler(fast, exact, eps=eps)
+        cs = CertifiedSampler(fast, exact, eps=eps, fast_reruns=name.endswith("_fast_reruns"))
         cold = cs.ddpm_sample(seq, sch, seed=23)                                   # warm-up (allocator, clocks); with eps auto
         cold_stats = cs.stats                                                      # also the call that starts the error estimate
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -994,6 +995,7 @@ def test_certified_sampler_equals_float32_chain_configs1_full_batch():
                      "max_logit_err_observed": st["max_logit_err_observed"], "eps_violations": st["eps_violations"],
 
                      "rerun_per_update": st["rerun_per_update"]}
+    exact.set_small_batch_splitk(False)
     exact.close()
     del sd
     _record("certified_configs1_full_batch", out)
@@ -1001,6 +1003,9 @@ def test_certified_sampler_equals_float32_chain_configs1_full_batch():
     for name in ("f16", "f16_f32head", "f16_f32head_auto", "bf16"):
         assert out[name]["ids_equal_to_f32_chain"] and out[name]["eps_violations"] == 0, out[name]
         assert out[name]["first_call"]["eps_violations"] == 0, out[name]
+    # K-sliced re-runs: another float32-grade evaluation of the flagged samples; a draw tied to ~1e-6 may differ from the referee
+    # (scratch/r04_certified_soak.py: one id of one run in 30 seeds) — this seed: none or one sample
+    assert out["f16_f32head_auto_fast_reruns"]["samples_identical"] >= 99, out["f16_f32head_auto_fast_reruns"]
     # measured: f16 14 % re-runs, largest logit error seen 2.1e-3 (eps 4e-3); with the float32 head 1.3e-3 (eps 2.5e-3)
     assert out["f16"]["rerun_share"] < 0.2 and out["f16"]["max_logit_err_observed"] < 3e-3, out["f16"]
     assert out["f16_f32head"]["max_logit_err_observed"] < 2e-3, out["f16_f32head"]
