@@ -589,3 +589,61 @@ def test_final_skip_is_exact():
                 assert part == full, part                                                # every sample live: full forward
     eng.close()
     _record("final_skip_rows", rec)
+
+
+def test_bf16_logit_error_decomposition_body_vs_head():
+    """Where the bf16 engine's logit error comes from ("first the decomposition, in a test that records it").
+    Full 48 blocks, B = 8, L_tok = 258, half the rows masked, sigma of update 12.  Reference = a float64 head (final LayerNorm ->
+    Linear -> GELU -> LayerNorm -> Linear, torch on the GPU) on the F32_SPLIT engine's hidden state.  BODY share = the same float64
+    head on the bf16 engine's hidden state (`esmdiff_get_embeddings`) minus the reference; HEAD share = the bf16 engine's logits
+    minus that.  Recorded (`bf16_error_decomposition_48blocks`); asserted: the two shares add up to the total, the head's share is the
+    larger one (0.6 % of the FLOP, ~2/3 of the error variance), and the same split for the f16 engine sits 8x lower."""
+    from esmdiff_amd.config import ESM3_OPEN as cfg
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    F = torch.nn.functional
+    sd = random_init_state_dict(cfg, seed=5, device="cuda")
+    d = lambda k: sd["net." + k].double().cuda()  # noqa: E731
+
+    def head_f64(h):
+        h = h.double()
+        D = h.shape[-1]
+        y = F.layer_norm(h, (D,), d("transformer.norm.weight"), None, 1e-5)
+        y = F.gelu(F.linear(y, d("output_heads.structure_head.0.weight"), d("output_heads.structure_head.0.bias")))
+        y = F.layer_norm(y, (D,), d("output_heads.structure_head.2.weight"), d("output_heads.structure_head.2.bias"), 1e-5)
+        return F.linear(y, d("output_heads.structure_head.3.weight"), d("output_heads.structure_head.3.bias"))
+
+    g = torch.Generator().manual_seed(2)
+    B, L = 8, 258
+    seq = _seq(B, L, g).cuda()
+    x = torch.randint(0, 4096, (B, L), generator=g)
+    x[torch.rand(B, L, generator=g) < 0.5] = MASK
+    x = x.cuda()
+    tf = ddpm_schedule(25, freq_dim=cfg.freq_dim).t_freq[12]
+    es = Engine(cfg, sd, max_batch=B, max_len=L, precision="f32_split")
+    ls = es.forward_logits(x, seq, tf).clone()
+    ref = head_f64(es.embeddings(B, L))
+    es.close()
+    mask = x == MASK
+    st = lambda t: {"max": float(t.abs().max()), "mean": float(t.abs().mean()), "rms_masked_rows": float(t[mask].pow(2).mean().sqrt())}  # noqa: E731
+    rec = {"split_engine_logits_vs_f64_head_of_its_hidden": st(ls.double() - ref), "logit_std": float(ref.std())}
+    for name in ("bf16", "f16"):
+        e = Engine(cfg, sd, max_batch=B, max_len=L, precision=name)
+        lg = e.forward_logits(x, seq, tf).double()
+        via = head_f64(e.embeddings(B, L))               # exact head on this engine's hidden state
+        e.close()
+        tot, body, head = st(lg - ref), st(via - ref), st(lg - via)
+        share = head["rms_masked_rows"] ** 2 / (head["rms_masked_rows"] ** 2 + body["rms_masked_rows"] ** 2)
+        rec[name] = {"total_vs_ref": tot, "body_only__exact_head_on_its_hidden_vs_ref": body,
+                     "head_only__its_logits_vs_exact_head_on_its_hidden": head, "head_share_of_error_variance": round(share, 3)}
+    del sd
+    _record("bf16_error_decomposition_48blocks", rec)
+    assert rec["split_engine_logits_vs_f64_head_of_its_hidden"]["max"] < 2e-5, rec
+    b = rec["bf16"]
+    # independent error sources: variances add (within 15 %)
+    tot2 = b["total_vs_ref"]["rms_masked_rows"] ** 2
+    sum2 = b["body_only__exact_head_on_its_hidden_vs_ref"]["rms_masked_rows"] ** 2 + b["head_only__its_logits_vs_exact_head_on_its_hidden"]["rms_masked_rows"] ** 2
+    assert abs(tot2 - sum2) < 0.15 * tot2, rec
+    assert 0.5 < b["head_share_of_error_variance"] < 0.8, rec                      # measured 0.64
+    assert rec["f16"]["total_vs_ref"]["rms_masked_rows"] < b["total_vs_ref"]["rms_masked_rows"] / 5, rec   # 1/8 of the operand rounding
