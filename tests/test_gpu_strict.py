@@ -995,10 +995,18 @@ def test_certified_sampler_equals_float32_chain_configs1_full_batch():
                      "max_logit_err_observed": st["max_logit_err_observed"], "eps_violations": st["eps_violations"],
 
                      "rerun_per_update": st["rerun_per_update"]}
+    # more seeds for the shipping configuration (f16 + f32-grade head, eps measured, unsliced re-runs): the certified chain must BE
+    # the F32_SPLIT engine's chain (scratch/r04_certified_soak.py ran 30 seeds: 30 identical)
+    fast = Engine(cfg, sd, max_batch=B, max_len=L, precision="f16", head_precision="f32")
+    cs = CertifiedSampler(fast, exact)
+    out["more_seeds_identical_to_f32_split_chain"] = [bool(torch.equal(cs.ddpm_sample(seq, sch, seed=s_), exact.ddpm_sample(seq, sch, seed=s_)))
+                                                      for s_ in (101, 102, 103)]
+    fast.close()
     exact.set_small_batch_splitk(False)
     exact.close()
     del sd
     _record("certified_configs1_full_batch", out)
+    assert all(out["more_seeds_identical_to_f32_split_chain"]), out["more_seeds_identical_to_f32_split_chain"]
     assert out["f32_split_alone_equal"], out
     for name in ("f16", "f16_f32head", "f16_f32head_auto", "bf16"):
         assert out[name]["ids_equal_to_f32_chain"] and out[name]["eps_violations"] == 0, out[name]
