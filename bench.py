@@ -353,6 +353,7 @@ def main():
     ap.add_argument("--head-precision", choices=["bf16", "f32"], default="bf16",
                     help="bf16 engine only: final LayerNorm + output head in float32 grade (esmdiff_config.head_precision)")
     ap.add_argument("--no-head-f32-leg", action="store_true", help="skip the second, labelled run with the float32-grade head")
+    ap.add_argument("--alt-steps", type=int, default=5, help="timed steps of every labelled extra leg (alt_precisions, certified); >= 5")
     ap.add_argument("--spawn", action="store_true",
                     help="go through the launcher path (torch.distributed.run, process group, RCCL gather) even at --gpus 1: the "
                          "multi-GPU code path on a one-GPU box")
@@ -410,7 +411,7 @@ def main():
         from esmdiff_amd.engine import Engine
         sd = random_init_state_dict(cfg, seed=args.seed, device=str(dev), with_geom=True)   # same weights on every rank (GPU generator)
         eng = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank, precision=args.precision,
-                     head_precision=args.head_precision)
+                     head_precision="f32" if args.head_precision == "f32" else None)
     create_s = time.perf_counter() - t_create
     g = torch.Generator().manual_seed(args.seed)
     seq1 = torch.cat([torch.tensor([0]), torch.randint(4, 24, (args.residues,), generator=g), torch.tensor([2])])
@@ -561,7 +562,7 @@ def main():
     alt_recs, alt_engines = {}, {}
     if world == 1 and not stub and args.precision == "bf16" and args.head_precision == "bf16" and not args.no_head_f32_leg:
         from esmdiff_amd.engine import Engine
-        ks = 2
+        ks = max(5, args.alt_steps)
 
         def timed(engine):
             sync_local()
@@ -589,56 +590,79 @@ def main():
                               "power": pw(pw_alt), "headline_engine_power": pw(pw_base),
                               "what": "same workload, labelled extra — NOT the headline value"}
 
-    # One more LABELLED figure: certified sampling (esmdiff_amd/certified.py) — the f16 engine (f32-grade head) draws, the sampler kernel flags
-    # the samples with a close call (winner within exp(2 eps) of the runner-up), those are re-run for that update on an
-    # F32_SPLIT engine.  Ids are compared here with the F32_SPLIT engine's own chain for the same seed.
+    # One more LABELLED figure: certified sampling (esmdiff_amd/certified.py, r05 form) — the f16 engine (f32-grade head) draws every
+    # update of every sample; the sampler kernel flags the samples with a close call (winner within exp(2 eps) of the runner-up);
+    # flagged sample-updates — and a random 2 % of the unflagged ones, the audit — are verified in batches of >= 32 on an F32_SPLIT
+    # engine while the flagged samples continue speculatively; a verification that disagrees rolls the sample back.  Ids are
+    # compared here with the F32_SPLIT engine's own chain for the same seeds (first and last timed step).
     cert_rec = None
     if alt_engines.get("f16_head_f32") is not None and args.mode == "ddpm" and not args.inpaint:
         from esmdiff_amd.certified import CertifiedSampler
         from esmdiff_amd.engine import Engine
         ex = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank, precision="f32_split")
         cs = CertifiedSampler(alt_engines["f16_head_f32"], ex)
-        cs.ddpm_sample(seq, sch, seed=args.seed + 1000, sample_offset=rank * B)
+        cs.ddpm_sample(seq, sch, seed=args.seed + 1000, sample_offset=rank * B)          # cold call: probe + allocations
+        cold = cs.stats
         sync_local()
-        ks, got = 2, []
+        ks, got, stats = max(5, args.alt_steps), [], []
+        psamp = PowerSampler(local_rank)
+        psamp.start()
         tc0 = time.perf_counter()
-        stats = []
         for k in range(ks):
             got.append(cs.ddpm_sample(seq, sch, seed=args.seed + k, sample_offset=rank * B))
             stats.append(cs.stats)
         sync_local()
         tc1 = time.perf_counter()
-        want = ex.ddpm_sample(seq, sch, seed=args.seed, sample_offset=rank * B)
+        pw_c = psamp.stop()
+        want = [ex.ddpm_sample(seq, sch, seed=args.seed + k, sample_offset=rank * B) for k in (0, ks - 1)]
         sync_local()
         tc2 = time.perf_counter()
-        # variant: the re-runs' residual linears K-sliced (esmdiff_set_small_batch_splitk) — faster, but another float32-grade
-        # evaluation: a draw tied to ~1e-6 can differ from the engine's own large-batch chain (1 id in 30 runs, EXPERIMENTS R4.8)
-        csf = CertifiedSampler(alt_engines["f16_head_f32"], ex, fast_reruns=True)
-        csf.err_seen, csf.n_seen = cs.err_seen, cs.n_seen
-        csf.ddpm_sample(seq, sch, seed=args.seed + 1000, sample_offset=rank * B)
-        sync_local()
-        tf0 = time.perf_counter()
-        gotf = [csf.ddpm_sample(seq, sch, seed=args.seed + k, sample_offset=rank * B) for k in range(ks)]
-        sync_local()
-        tf1 = time.perf_counter()
-        ex.set_small_batch_splitk(False)
         plain = alt_engines["f16_head_f32"].ddpm_sample(seq, sch, seed=args.seed, sample_offset=rank * B)
+        # the same ks x B samples as ONE stream (the CLI's batch loop handed to the sampler in one call): a fast forward always takes
+        # the B unfinished samples with the lowest indices, so the roll-back tail of one batch runs inside the next batch's forwards
+        seq_all = seq[:1].expand(ks * B, L).contiguous()
+        sync_local()
+        tsa = time.perf_counter()
+        got_stream = cs.ddpm_sample(seq_all, sch, seed=args.seed + 2000, sample_offset=rank * B)
+        sync_local()
+        tsb = time.perf_counter()
+        st_stream = cs.stats
+        stream_ok = all(bool(torch.equal(got_stream[k * B:(k + 1) * B],
+                                         ex.ddpm_sample(seq, sch, seed=args.seed + 2000, sample_offset=rank * B + k * B))) for k in (0, ks - 1))
+        tot = lambda key: sum(s_[key] for s_ in stats)    # noqa: E731
         cert_rec = {"value": round(B * ks / (tc1 - tc0), 3), "unit": "samples/s", "steps": ks,
-                    "eps": "auto: 2.0 x the largest logit error observed so far",
+                    "seconds_per_step": round((tc1 - tc0) / ks, 3), "tail_seconds_per_step": round(tot("tail_seconds") / ks, 3),
+                    "streamed": {"value": round(ks * B / (tsb - tsa), 3), "unit": "samples/s", "samples": ks * B, "lane_width": B,
+                                 "ids_equal_to_f32_split_chain": stream_ok, "audit_checked": st_stream["audit_checked"],
+                                 "audit_mismatches": st_stream["audit_mismatches"], "eps_violations": st_stream["eps_violations"],
+                                 "corrections": st_stream["corrections"], "tail_seconds": st_stream["tail_seconds"],
+                                 "what": f"the same {ks} x {B} samples handed to the sampler in ONE call (one seed, global sample "
+                                         "indices): no per-batch tail — roll-backs of one batch ride in the next batch's forwards"},
+                    "eps": f"auto: pair bound P = max({cs.k_sigma:g} x r.m.s. pair error, {cs.max_factor:g} x largest pair error seen), eps = P / 2",
                     "eps_used": [min(s_["eps_min_used"] for s_ in stats), max(s_["eps_max_used"] for s_ in stats)],
-                    "fast_engine": "f16 + f32-grade head", "exact_engine": "f32_split",
-                    "f32_split_engine_alone_same_session": round(B / (tc2 - tc1), 3),
-                    "ids_equal_to_f32_split_chain": bool(torch.equal(got[0], want)),
-                    "samples_identical_without_certification": int((plain == want).all(1).sum()),
-                    "rerun_share": round(sum(s_["sample_forwards_exact"] for s_ in stats) /
-                                         max(1, sum(s_["sample_forwards_fast"] for s_ in stats)), 4),
-                    "max_logit_err_observed": max(s_["max_logit_err_observed"] for s_ in stats),
-                    "eps_violations": sum(s_["eps_violations"] for s_ in stats),
-                    "fast_reruns": {"value": round(B * ks / (tf1 - tf0), 3), "ids_equal_to_f32_split_chain": bool(torch.equal(gotf[0], want)),
-                                    "what": "re-runs with K-sliced residual linears (CertifiedSampler(fast_reruns=True))"},
-                    "what": "same workload, ids of the float32-grade chain: f16 engine + re-runs of the close calls on the F32_SPLIT "
-                            "engine (tests/test_gpu_strict.py::test_certified_sampler_equals_float32_chain_configs1_full_batch "
-                            "checks the ids against the exact-f32 engine).  Labelled extra — NOT the headline value"}
+                    "sigma_pair_err": stats[-1]["sigma_pair_err"], "max_pair_err_seen": stats[-1]["max_pair_err_all_calls"],
+                    "max_logit_err_seen": stats[-1]["max_logit_err_all_calls"],
+                    "fast_engine": "f16 + f32-grade head", "exact_engine": "f32_split", "verify_batch": cs.verify_batch,
+                    "f32_split_engine_alone_same_session": round(2 * B / (tc2 - tc1), 3),
+                    "ids_equal_to_f32_split_chain": bool(torch.equal(got[0], want[0])) and bool(torch.equal(got[-1], want[1])),
+                    "ids_checked_steps": [0, ks - 1],
+                    "samples_identical_without_certification": int((plain == want[0]).all(1).sum()),
+                    "rerun_share": round(tot("flagged") / max(1, tot("sample_forwards_fast")), 4),
+                    "rerun_share_vs_eps": stats[-1]["rerun_share_vs_eps"],
+                    "sample_forwards_fast": tot("sample_forwards_fast"), "sample_forwards_exact": tot("sample_forwards_exact"),
+                    "corrections": tot("corrections"), "rollback_updates_discarded": tot("rollback_updates_discarded"),
+                    "verify_batch_sizes": [s_["verify_batch_sizes"] for s_ in stats],
+                    "eps_violations": tot("eps_violations"),
+                    "audit": {"rate": cs.audit_rate, "audit_checked": tot("audit_checked"), "audit_mismatches": tot("audit_mismatches"),
+                              "audit_eps_violations": tot("audit_eps_violations"),
+                              "audit_max_logit_err": max(s_["audit_max_logit_err"] for s_ in stats),
+                              "audit_max_pair_err": max(s_["audit_max_pair_err"] for s_ in stats)},
+                    "cold_call": {"eps_used": [cold["eps_min_used"], cold["eps_max_used"]], "eps_violations": cold["eps_violations"],
+                                  "audit_checked": cold["audit_checked"], "audit_mismatches": cold["audit_mismatches"]},
+                    "power": None if not pw_c else {"mean_w": pw_c["mean_w"], "mean_sclk_mhz": pw_c["mean_sclk_mhz"]},
+                    "what": "same workload, ids of the float32-grade chain (tests/test_gpu_strict.py::"
+                            "test_certified_sampler_equals_float32_chain_configs1_full_batch checks them against the exact-f32 engine "
+                            "too).  Labelled extra — NOT the headline value"}
         ex.close()
 
     if rank == 0:

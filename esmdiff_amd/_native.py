@@ -34,6 +34,10 @@ class Weight(ctypes.Structure):
                 ("ndim", ctypes.c_int32), ("shape", ctypes.c_int64 * 4)]
 
 
+# esmdiff_sample_step as a numpy record (one per sample; uploaded as raw bytes)
+SAMPLE_STEP_DTYPE = [("sample_index", "<u8"), ("move_chance_t", "<f4"), ("move_chance_s", "<f4"), ("step", "<i4"), ("final", "<i4")]
+
+
 class Rng(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("sample_offset", ctypes.c_uint64)]
 
@@ -49,6 +53,7 @@ EXPORTS = [
     "esmdiff_encoder_encode", "esmdiff_gemm_f32", "esmdiff_set_step0_sharing", "esmdiff_get_counters",
     "esmdiff_set_gibbs_options", "esmdiff_split_rows", "esmdiff_split_weight", "esmdiff_gemm_split",
     "esmdiff_get_embeddings", "esmdiff_set_final_skip", "esmdiff_gemm_f16", "esmdiff_ddpm_step_margin", "esmdiff_forward_logits_sigmas", "esmdiff_set_small_batch_splitk",
+    "esmdiff_ddpm_step_rows", "esmdiff_logit_error_stats",
 ]
 
 
@@ -86,6 +91,8 @@ def lib():
     L.esmdiff_ddpm_step.argtypes = [vp, vp, vp, i32, f32, f32, i32, vp, ctypes.POINTER(Rng), i32, i32, i32, vp]
     L.esmdiff_ddpm_step_margin.argtypes = [vp, vp, vp, i32, f32, f32, i32, ctypes.POINTER(Rng), i32, i32, i32, f32, vp, vp]
     L.esmdiff_ddpm_step_margin.restype = ctypes.c_int
+    L.esmdiff_ddpm_step_rows.argtypes = [vp, vp, vp, i32, vp, ctypes.c_uint64, i32, i32, f32, f32, vp, vp, vp]
+    L.esmdiff_logit_error_stats.argtypes = [vp, i32, vp, i32, vp, i32, i32, vp, vp]
     L.esmdiff_ddpm_sample.argtypes = [vp, vp, vp, i32, i32, i32, c_f32p, c_f32p, c_f32p, ctypes.POINTER(Rng), vp]
     L.esmdiff_gibbs_step.argtypes = [vp, vp, vp, vp, i32, f32, f32, vp, vp, ctypes.POINTER(Rng), i32, i32, i32, vp]
     L.esmdiff_gibbs_sample.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, ctypes.POINTER(i32), ctypes.POINTER(Rng), vp]
@@ -131,7 +138,7 @@ def lib():
     for n in EXPORTS:
         if n not in ("esmdiff_engine_destroy", "esmdiff_last_error", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error"):
             getattr(L, n).restype = ctypes.c_int
-    if L.esmdiff_abi_version() != 6:
+    if L.esmdiff_abi_version() != 7:
         raise RuntimeError("libesmdiff_hip.so ABI version mismatch")
     _lib = L
     return L

@@ -1239,6 +1239,29 @@ int esmdiff_ddpm_step_margin(esmdiff_engine* e, int64_t* x_inout, const float* l
   return 0;
 }
 
+int esmdiff_ddpm_step_rows(esmdiff_engine* e, int64_t* x_inout, const float* logits, int32_t ld_logits,
+                           const esmdiff_sample_step* params, uint64_t seed, int32_t B, int32_t L, float margin_ratio,
+                           float margin_diff, int32_t* sample_flags, float* sample_min_gap, void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!x_inout || !logits || !params) return fail(e, ESMDIFF_E_INVALID, "null pointer");
+  if (B <= 0 || L <= 0 || ld_logits < e->cfg.vocab_out) return fail(e, ESMDIFF_E_INVALID, "bad shape");
+  if (e->cfg.vocab_out <= ESMDIFF_MASK_ID) return fail(e, ESMDIFF_E_INVALID, "ddpm needs the 4101-way head (mask column)");
+  if ((sample_flags || sample_min_gap) && !(margin_ratio >= 1.f && margin_diff >= 0.f))
+    return fail(e, ESMDIFF_E_INVALID, "margins (%g, %g): a ratio >= 1 for updates, a difference >= 0 for final passes", margin_ratio, margin_diff);
+  Prof p{e, (hipStream_t)stream};
+  p.mark(S_SAMPLER);
+  HIP_TRY(e, launch_ddpm_step_rows(x_inout, logits, ld_logits, e->cfg.vocab_out, params, seed, B, L, margin_ratio, margin_diff,
+                                   sample_flags, sample_min_gap, (hipStream_t)stream));
+  p.mark(S_SAMPLER);
+  return 0;
+}
+
+int esmdiff_logit_error_stats(const float* a, int32_t ld_a, const float* b, int32_t ld_b, const int64_t* x, int32_t rows,
+                              int32_t vocab, float* out, void* stream) {
+  if (!a || !b || !x || !out || rows < 0 || vocab <= 0 || ld_a < vocab || ld_b < vocab) return ESMDIFF_E_INVALID;
+  return launch_logit_error_stats(a, ld_a, b, ld_b, x, rows, vocab, out, (hipStream_t)stream) == hipSuccess ? 0 : ESMDIFF_E_HIP;
+}
+
 int esmdiff_ddpm_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout, int32_t B, int32_t L, int32_t T,
                         const float* mc_t, const float* mc_s, const float* t_freq, const esmdiff_rng* rng,
                         void* stream) {

@@ -41,15 +41,35 @@ __device__ __forceinline__ float wave_max(float v) {
 // MARGIN (esmdiff_ddpm_step_margin): the same draw, plus the runner-up of the arg-max: sample_flags[b] is set when, for some
 // masked row of sample b, the winner does not beat the runner-up by the factor `margin` (final pass: by the difference
 // `margin`) — i.e. when a perturbation of the logits of that size could change the id.  The id written is the same bit for bit.
-template <int PER, bool MARGIN = false>
+//
+// ROWS (esmdiff_ddpm_step_rows): every sample of the batch carries its own update — Philox sample index, move chances, step
+// index, final flag — in `sp[b]`, so one launch serves samples that sit at DIFFERENT updates of their chains (the certified
+// sampler's verification batches and its fast lane after a roll-back).  Per sample the arithmetic is the plain kernel's, bit
+// for bit.  `margin` is then the ratio bound of the updates and `margin_fin` the difference bound of final passes;
+// sample_flags may be NULL; sample_gap[b] (optional, initialised to +inf by the caller) receives the smallest winner-to-
+// runner-up gap of the sample's masked rows in log units (log ratio for an update, log-probability difference for a final
+// pass) — a statistic for choosing eps, not part of the draw.
+template <int PER, bool MARGIN = false, bool ROWS = false>
 __global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, const float* __restrict__ logits,
                                                        int ld, int V, float mc_t, float mc_s, int final_,
                                                        const float* __restrict__ u, int use_philox,
                                                        uint64_t seed, uint64_t sample_offset, int step, int L,
                                                        int logits_period, float margin = 0.f,
-                                                       int32_t* __restrict__ sample_flags = nullptr) {
+                                                       int32_t* __restrict__ sample_flags = nullptr,
+                                                       const esmdiff_sample_step* __restrict__ sp = nullptr,
+                                                       float margin_fin = 0.f, float* __restrict__ sample_gap = nullptr) {
   const int row = blockIdx.x;
   if (x[row] != MASK_ID) return;  // carry-over: copy_flag * x  (model.py:606-607)
+  uint64_t sample_index = 0;
+  if constexpr (ROWS) {
+    const esmdiff_sample_step q = sp[row / L];
+    mc_t = q.move_chance_t;
+    mc_s = q.move_chance_s;
+    step = q.step;
+    final_ = q.final;
+    sample_index = q.sample_index;
+    if (final_) margin = margin_fin;
+  }
 
   __shared__ float s_red[8];
   __shared__ int s_idx[4];
@@ -109,7 +129,7 @@ __global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, 
         if (v == MASK_ID) q = mc_s;
         float uu;
         if (use_philox)
-          uu = ed_philox_uniform(seed, sample_offset + (uint64_t)b, (uint32_t)step, (uint32_t)l, (uint32_t)v);
+          uu = ed_philox_uniform(seed, ROWS ? sample_index : sample_offset + (uint64_t)b, (uint32_t)step, (uint32_t)l, (uint32_t)v);
         else
           uu = urow[v];
         const float g = 1e-10f - ed_logf(uu + 1e-10f);
@@ -161,7 +181,15 @@ __global__ __launch_bounds__(NT) void ddpm_step_kernel(int64_t* __restrict__ x, 
     if constexpr (MARGIN) {
       // non-final: values are q / g > 0, the criterion is a ratio; final: log-probabilities, a difference
       const bool safe = final_ ? (bb - ss > margin) : (bb > ss * margin);
-      if (!safe) sample_flags[row / L] = 1;    // (benign race: every writer stores 1)
+      if constexpr (ROWS) {
+        if (!safe && sample_flags) sample_flags[row / L] = 1;
+        if (sample_gap) {   // gaps are >= 0, so their float order is their bit order as signed integers
+          const float gap = final_ ? bb - ss : ed_logf(bb) - ed_logf(fmaxf(ss, 1e-37f));
+          atomicMin(reinterpret_cast<int*>(sample_gap) + row / L, __float_as_int(fmaxf(gap, 0.f)));
+        }
+      } else {
+        if (!safe) sample_flags[row / L] = 1;    // (benign race: every writer stores 1)
+      }
     }
   }
 }
@@ -188,6 +216,80 @@ hipError_t launch_ddpm_step(int64_t* x, const float* logits, int ld, int V, floa
   else if (per <= 17) ED_LAUNCH(17);
   else ED_LAUNCH(MAX_PER_THREAD);
 #undef ED_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t launch_ddpm_step_rows(int64_t* x, const float* logits, int ld, int V, const esmdiff_sample_step* sp, uint64_t seed,
+                                 int B, int L, float margin_ratio, float margin_diff, int32_t* sample_flags, float* sample_gap,
+                                 hipStream_t stream) {
+  const int rows = B * L;
+  if (rows <= 0) return hipSuccess;
+  const int per = (V + NT - 1) / NT;
+  if (per > MAX_PER_THREAD) return hipErrorInvalidValue;
+  dim3 grid(rows), block(NT);
+#define ED_LAUNCH(P)                                                                                                       \
+  hipLaunchKernelGGL((ddpm_step_kernel<P, true, true>), grid, block, 0, stream, x, logits, ld, V, 0.f, 0.f, 0, nullptr, 1,  \
+                     seed, (uint64_t)0, 0, L, 0, margin_ratio, sample_flags, sp, margin_diff, sample_gap)
+  if (per <= 1) ED_LAUNCH(1);
+  else if (per <= 4) ED_LAUNCH(4);
+  else if (per <= 17) ED_LAUNCH(17);
+  else ED_LAUNCH(MAX_PER_THREAD);
+#undef ED_LAUNCH
+  return hipGetLastError();
+}
+
+// Logit-error statistics of one engine against another on the same input (certified sampling: how far the fast engine's logits are
+// from the f32-grade ones).  One workgroup per token row; rows that are not MASK (their draw does not read the logits) give zeros.
+// e_v = a_v - b_v over the columns a draw can pick (all but the MASK column); d_v = e_v - e_{v+1}: the error of a logit DIFFERENCE,
+// which is what decides a draw between two tokens.  out[row] = { max |e|, sum e^2, max |d|, sum d^2 }.
+__global__ __launch_bounds__(NT) void logit_error_stats_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
+                                                               int ldb, const int64_t* __restrict__ x, int V,
+                                                               float* __restrict__ out) {
+  const int row = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  __shared__ float s_r[4][4];
+  if (x[row] != MASK_ID) {
+    if (t < 4) out[(int64_t)row * 4 + t] = 0.f;
+    return;
+  }
+  const float* za = a + (int64_t)row * lda;
+  const float* zb = b + (int64_t)row * ldb;
+  float me = 0.f, se = 0.f, md = 0.f, sd = 0.f;
+  for (int v = t; v < V; v += NT) {
+    if (v == MASK_ID) continue;
+    const float e = za[v] - zb[v];
+    me = fmaxf(me, fabsf(e));
+    se += e * e;
+    const int w = v + 1;
+    if (w < V && w != MASK_ID) {
+      const float d = e - (za[w] - zb[w]);
+      md = fmaxf(md, fabsf(d));
+      sd += d * d;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    me = fmaxf(me, __shfl_xor(me, off, 64));
+    md = fmaxf(md, __shfl_xor(md, off, 64));
+    se += __shfl_xor(se, off, 64);
+    sd += __shfl_xor(sd, off, 64);
+  }
+  if (lane == 0) {
+    s_r[wave][0] = me; s_r[wave][1] = se; s_r[wave][2] = md; s_r[wave][3] = sd;
+  }
+  __syncthreads();
+  if (t == 0) {
+    out[(int64_t)row * 4 + 0] = fmaxf(fmaxf(s_r[0][0], s_r[1][0]), fmaxf(s_r[2][0], s_r[3][0]));
+    out[(int64_t)row * 4 + 1] = (s_r[0][1] + s_r[1][1]) + (s_r[2][1] + s_r[3][1]);
+    out[(int64_t)row * 4 + 2] = fmaxf(fmaxf(s_r[0][2], s_r[1][2]), fmaxf(s_r[2][2], s_r[3][2]));
+    out[(int64_t)row * 4 + 3] = (s_r[0][3] + s_r[1][3]) + (s_r[2][3] + s_r[3][3]);
+  }
+}
+
+hipError_t launch_logit_error_stats(const float* a, int lda, const float* b, int ldb, const int64_t* x, int rows, int V, float* out,
+                                    hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(logit_error_stats_kernel, dim3(rows), dim3(NT), 0, stream, a, lda, b, ldb, x, V, out);
   return hipGetLastError();
 }
 

@@ -47,8 +47,8 @@ class Engine:
         _require_gpu()
         if precision not in N.PRECISION:
             raise ValueError(f"precision must be one of {sorted(N.PRECISION)}, got {precision!r}")
-        if head_precision not in (None, "bf16", "f16", "f32"):
-            raise ValueError(f"head_precision must be None (= precision) or 'f32', got {head_precision!r}")
+        if head_precision not in (None, "f32") and head_precision != precision:
+            raise ValueError(f"head_precision must be None / {precision!r} (the body's precision) or 'f32', got {head_precision!r}")
         self.precision = precision
         self.head_precision = "f32" if (head_precision == "f32" or precision in ("f32", "f32_split")) else precision
         self.cfg = cfg
@@ -206,6 +206,51 @@ class Engine:
                                                      ctypes.byref(rng), int(step), B, L, float(margin), _ptr(flags),
                                                      _stream()))
         return x
+
+    def sample_step_params(self, sample_index, mc_t, mc_s, step, final) -> torch.Tensor:
+        """Host sequences (one entry per sample) -> the device array of esmdiff_sample_step records ddpm_step_rows takes."""
+        import numpy as np
+        n = len(sample_index)
+        rec = np.zeros(n, dtype=N.SAMPLE_STEP_DTYPE)
+        rec["sample_index"], rec["step"], rec["final"] = sample_index, step, final
+        rec["move_chance_t"], rec["move_chance_s"] = mc_t, mc_s
+        return torch.from_numpy(rec.view(np.uint8).reshape(n, -1)).to(self.device, non_blocking=True)
+
+    def ddpm_step_rows(self, x: torch.Tensor, logits: torch.Tensor, params: torch.Tensor, *, seed: int,
+                       eps: Optional[float] = None, flags: Optional[torch.Tensor] = None,
+                       gaps: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ddpm_step with one parameter set per sample (esmdiff_ddpm_step_rows): params from sample_step_params.  With `eps`
+        (a bound on the logit error, certified.py) flags[b] (int32, zeroed by the caller) is set where a masked row of sample b
+        was decided by less than exp(2 eps) (final passes: 2 eps in log p), and gaps[b] (f32, +inf on entry) gets the sample's
+        smallest gap in log units."""
+        import math
+        B, L = x.shape
+        assert x.dtype == torch.int64 and x.is_cuda and x.is_contiguous()
+        assert logits.dtype == torch.float32 and logits.is_cuda and logits.stride(-1) == 1
+        ld = logits.stride(1)
+        assert logits.stride(0) == ld * L and ld >= STRUCTURE_VOCAB
+        assert params.dtype == torch.uint8 and params.is_cuda and params.shape == (B, 24) and params.is_contiguous()
+        for t_, dt in ((flags, torch.int32), (gaps, torch.float32)):
+            assert t_ is None or (t_.dtype == dt and t_.is_cuda and t_.numel() == B and t_.is_contiguous())
+        if (flags is not None or gaps is not None) and eps is None:
+            raise ValueError("flags / gaps need eps")
+        e2 = 0.0 if eps is None else 2.0 * float(eps)
+        self._chk(self._lib.esmdiff_ddpm_step_rows(self._h, _ptr(x), _ptr(logits), ld, _ptr(params), int(seed), B, L,
+                                                   math.exp(e2), e2, _ptr(flags), _ptr(gaps), _stream()))
+        return x
+
+    def logit_error_stats(self, a: torch.Tensor, b: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """(n, L, 4) f32 = per token row {max |a - b|, sum (a - b)^2, max |d|, sum d^2} over the drawable columns of the rows of
+        x (n, L) that are MASK (d = the error of adjacent logit differences), zeros elsewhere (esmdiff_logit_error_stats)."""
+        n, L = x.shape
+        for t_ in (a, b):
+            assert t_.dtype == torch.float32 and t_.is_cuda and t_.stride(-1) == 1 and t_.shape[:2] == (n, L)
+            assert t_.stride(0) == t_.stride(1) * L
+        assert x.dtype == torch.int64 and x.is_cuda and x.is_contiguous()
+        out = torch.empty(n, L, 4, dtype=torch.float32, device=self.device)
+        N.check(self._lib.esmdiff_logit_error_stats(_ptr(a), a.stride(1), _ptr(b), b.stride(1), _ptr(x), n * L,
+                                                    self.cfg.n_structure_heads, _ptr(out), _stream()))
+        return out
 
     def ddpm_sample(self, sequence_tokens: torch.Tensor, schedule: DDPMSchedule, *, seed: int,
                     sample_offset: int = 0, input_prior: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -208,6 +208,11 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
             {"sequence": sequence, "num_steps": num_steps, "num_samples": num_samples, "eps": eps, "seed": seed,
              "noise": noise, "world_size": world, "sampling_seconds": round(sample_t, 3),
              "precision": "certified" if getattr(model, "certified", None) is not None else getattr(getattr(model, "net", model), "precision", None),
+             "head_precision": getattr(getattr(model, "fast", None) or getattr(model, "net", model), "head_precision", None),
+             **({} if getattr(model, "certified", None) is None else {"certified": {
+                 k: model.certified.stats.get(k) for k in ("eps_min_used", "eps_max_used", "flagged", "corrections", "audit_checked",
+                                                           "audit_mismatches", "eps_violations", "sample_forwards_fast",
+                                                           "sample_forwards_exact")}}),
              "decoder_precision": getattr(decoder, "precision", None),
              **({} if ptm is None else {"ptm": [round(float(v), 4) for v in ptm.cpu()]})}, indent=1))
         if coords is not None:
@@ -332,8 +337,10 @@ def get_argparser(argv=None):
                         "bf16 path with IEEE-half operands (same speed, 1/8 of the rounding error); certified = the f16 engine draws and only the "
                         "samples with a close call are re-run on an f32_split engine for that update: the f32_split chain's ids at ~2x its rate "
                         "(--mode ddpm; the gibbs mode has no certified form and runs on the f32_split engine)")
-    p.add_argument("--head_precision", choices=["bf16", "f32"], default="bf16",
-                   help="bf16 network only: final LayerNorm + output head in float32 grade (+1 %% time, fewer near-tie flips)")
+    p.add_argument("--head_precision", choices=["body", "f32"], default=None,
+                   help="bf16 / f16 networks: 'f32' = final LayerNorm + output head in float32 grade (+1 %% time, fewer near-tie "
+                        "flips), 'body' = the head in the network's own precision.  Default: 'body', except --precision certified, "
+                        "whose fast engine gets the float32-grade head (the validated configuration)")
     p.add_argument("--decoder_precision", choices=["f32", "f32_split", "bf16"], default="f32",
                    help="arithmetic of the VQ-VAE structure decoder (and encoder): f32 (default, backbone within 1e-4 A of a float32 "
                         "decode, encoder codes equal to a float32 encoder's) or bf16")
@@ -343,6 +350,8 @@ def get_argparser(argv=None):
 
 def main(argv=None):
     args = get_argparser(argv)
+    if args.head_precision == "body":      # explicit: the head in the body's precision, also for the certified sampler's fast engine
+        args.head_precision = {"bf16": "bf16", "f16": "f16", "certified": "f16"}.get(args.precision)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESMDIFF_ABI_VERSION 6   /* 6: + esmdiff_ddpm_step_margin, esmdiff_forward_logits_sigmas, esmdiff_set_small_batch_splitk (additions only) */
+#define ESMDIFF_ABI_VERSION 7   /* 7: + esmdiff_ddpm_step_rows, esmdiff_logit_error_stats (additions only); 6: + esmdiff_ddpm_step_margin, esmdiff_forward_logits_sigmas, esmdiff_set_small_batch_splitk */
 
 /* structure-track vocabulary: esm constants mirrored at model.py:380-381 */
 #define ESMDIFF_VOCAB 4101
@@ -182,6 +182,37 @@ int esmdiff_ddpm_step(esmdiff_engine* eng, int64_t* x_inout, const float* logits
 int esmdiff_ddpm_step_margin(esmdiff_engine* eng, int64_t* x_inout, const float* logits, int32_t ld_logits,
                              float move_chance_t, float move_chance_s, int32_t final, const esmdiff_rng* rng,
                              int32_t step, int32_t B, int32_t L, float margin, int32_t* sample_flags, void* stream);
+
+/* esmdiff_ddpm_step_margin with ONE PARAMETER SET PER SAMPLE (ABI 7).  The reference's loop (model.py:570-573) moves the whole
+ * batch through the same update, but nothing couples its samples (model.py:583-607 is row-wise and `_sample_categorical` draws
+ * per element), so a batch may hold samples that sit at DIFFERENT updates of their chains: params[b] (DEVICE array of B entries)
+ * gives sample b its global Philox sample index (what esmdiff_rng.sample_offset + b is in the plain entry), its move chances,
+ * its Philox step index and whether its pass is the noise-removal one.  Per sample the ids written are those esmdiff_ddpm_step
+ * would write for that sample alone with the same scalars, bit for bit (tests/test_gpu_kernels.py).  margin_ratio (>= 1) is the
+ * bound of the updates, margin_diff (>= 0) of the final passes, as in esmdiff_ddpm_step_margin; sample_flags may be NULL (plain
+ * draws).  sample_min_gap (f32 [B], optional, set to +inf by the caller): the smallest winner-over-runner-up gap among the
+ * sample's masked rows in log units — log(winner / runner-up) of q_v / g_v for an update, the log-probability difference for a
+ * final pass; a sample is flagged exactly when that gap is <= log(margin_ratio) (resp. margin_diff), up to float rounding of the
+ * logarithm.  It is a statistic (the re-run share as a function of eps), not an input of the draw.
+ * Used by esmdiff_amd/certified.py: verification batches of the f32-grade engine and the fast lane after a roll-back. */
+typedef struct {
+  uint64_t sample_index;   /* Philox key: the sample's GLOBAL index */
+  float move_chance_t;     /* model.py:592-595; ignored when final != 0 */
+  float move_chance_s;
+  int32_t step;            /* Philox step index = index of the update in the sample's chain */
+  int32_t final;           /* != 0: noise-removal pass (model.py:575-579) */
+} esmdiff_sample_step;
+int esmdiff_ddpm_step_rows(esmdiff_engine* eng, int64_t* x_inout, const float* logits, int32_t ld_logits,
+                           const esmdiff_sample_step* params, uint64_t seed, int32_t B, int32_t L, float margin_ratio,
+                           float margin_diff, int32_t* sample_flags, float* sample_min_gap, void* stream);
+
+/* How far two engines' logits are apart on the same input (ABI 7; no reference counterpart — the reference has one precision).
+ * a, b: f32 [rows, ld_a / ld_b] raw logits of the same token rows; x: int64 [rows] the tokens that went in.  For every row that
+ * is MASK (the only rows whose draw reads the logits), over the vocab columns a draw can pick (all v < vocab but the MASK column):
+ * e_v = a_v - b_v and d_v = e_v - e_(v+1), the error of the logit DIFFERENCE of two tokens, which is what decides a draw between
+ * them.  out f32 [rows, 4] = { max |e|, sum e^2, max |d|, sum d^2 }; zeros for rows that are not MASK. */
+int esmdiff_logit_error_stats(const float* a, int32_t ld_a, const float* b, int32_t ld_b, const int64_t* x, int32_t rows,
+                              int32_t vocab, float* out, void* stream);
 
 /* Replaces MaskedDiffusionLanguageModeling.ddpm_sample (model.py:543-581) for one batch, entirely on
  * the device, Philox noise: T updates + the noise-removal pass.  x_inout holds the prior on entry

@@ -30,6 +30,7 @@ class _Net:
         self.table = np.random.default_rng(5).standard_normal((4102, 64)).astype(np.float32)
         self.proj = np.random.default_rng(6).standard_normal((64, V)).astype(np.float32)
         self.sample_forwards = 0
+        self.inject = None                      # optional hook (net, x, logits) -> logits: a targeted error
 
     def conditioning_rows(self, t_freq):
         return t_freq
@@ -38,7 +39,12 @@ class _Net:
         x = x.numpy()
         emb = self.table[np.minimum(x, 4101)] + 0.3 * self.table[seq.numpy() % 64]
         ctx = emb.mean(axis=1, keepdims=True)                      # couples the rows of a sample, like attention
-        h = np.tanh(emb + ctx + (0.0 if tf is None else float(tf[:8].sum()) * 0.05))
+        if tf is None:
+            cond = np.float32(0.0)
+        else:      # one sinusoid for the batch, or one per sample (esmdiff_forward_logits_sigmas): the same arithmetic per sample
+            t2 = tf.numpy().reshape(-1, tf.shape[-1])[:, :8].astype(np.float64).sum(1).astype(np.float32)
+            cond = (t2 * np.float32(0.05))[:, None, None]
+        h = np.tanh(emb + ctx + cond)
         return (h @ self.proj * self.scale / 8.0).astype(np.float32)
 
     def forward_logits(self, x, seq, tf, out=None):
@@ -47,6 +53,8 @@ class _Net:
             self.calls += 1
             rng = np.random.default_rng(self.seed * 7919 + self.calls)
             lg = lg + rng.uniform(-self.noise, self.noise, lg.shape).astype(np.float32)
+        if self.inject is not None:
+            lg = self.inject(self, x, lg)
         self.sample_forwards += x.shape[0]
         if out is None:
             out = torch.empty(x.shape[0], x.shape[1], self.ld_logits)
@@ -59,32 +67,60 @@ class _Net:
         x.copy_(torch.from_numpy(new))
         return x
 
-    def ddpm_step_margin(self, x, lg, mc_t, mc_s, *, final, seed, sample_offset, step, margin, flags):
-        """esmdiff_ddpm_step_margin restated: ids from the oracle's float32 step, the runner-up test in float64 on the same
-        Philox uniforms (made slightly wider than the kernel's, 1e-5 relative, so float32 / float64 rounding cannot un-flag)."""
-        xin = x.numpy().copy()
-        B, L = xin.shape
+    def sample_step_params(self, sample_index, mc_t, mc_s, step, final):
+        from esmdiff_amd import _native as N
+        n = len(sample_index)
+        rec = np.zeros(n, dtype=N.SAMPLE_STEP_DTYPE)
+        rec["sample_index"], rec["step"], rec["final"] = sample_index, step, final
+        rec["move_chance_t"], rec["move_chance_s"] = mc_t, mc_s
+        return torch.from_numpy(rec.view(np.uint8).reshape(n, -1))
+
+    def ddpm_step_rows(self, x, lg, params, *, seed, eps=None, flags=None, gaps=None):
+        """esmdiff_ddpm_step_rows restated: per sample the oracle's float32 step with that sample's own scalars; the runner-up
+        test in float64 on the same Philox uniforms (made slightly wider than the kernel's, 1e-5 relative, so float32 / float64
+        rounding cannot un-flag)."""
+        from esmdiff_amd import _native as N
+        rec = params.numpy().view(N.SAMPLE_STEP_DTYPE).reshape(-1)
+        B, L = x.shape
         z = lg.numpy().astype(np.float64).copy()
         z[..., MASK] -= 1e6
-        lp = z - np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1, keepdims=True)) - z.max(-1, keepdims=True)
+        mx = z.max(-1, keepdims=True)
+        lp = z - np.log(np.exp(z - mx).sum(-1, keepdims=True)) - mx
         for b in range(B):
+            r = rec[b]
+            fin, mct, mcs = bool(r["final"]), float(r["move_chance_t"]), float(r["move_chance_s"])
+            xin = x[b].numpy().copy()
             for l in range(L):
-                if xin[b, l] != MASK:
+                if xin[l] != MASK or (flags is None and gaps is None):
                     continue
-                if final:
+                if fin:
                     val = lp[b, l]
                     top = np.partition(val, -2)[-2:]
-                    close = top[1] - top[0] <= margin + 1e-5
+                    gap = top[1] - top[0]
                 else:
-                    u = c_oracle.philox_uniforms(seed, sample_offset + b, step, l, V).astype(np.float64)
-                    q = np.exp(lp[b, l]) * (mc_t - mc_s)
-                    q[MASK] = mc_s
+                    u = c_oracle.philox_uniforms(seed, int(r["sample_index"]), int(r["step"]), l, V).astype(np.float64)
+                    q = np.exp(lp[b, l]) * (np.float32(mct) - np.float32(mcs))
+                    q[MASK] = mcs
                     val = q / (1e-10 - np.log(u + 1e-10))
                     top = np.partition(val, -2)[-2:]
-                    close = top[1] <= top[0] * margin * (1 + 1e-5)
-                if close:
+                    gap = np.log(top[1]) - np.log(max(top[0], 1e-300))
+                if flags is not None and gap <= 2.0 * eps * (1 + 1e-5) + 1e-7:
                     flags[b] = 1
-        return self.ddpm_step(x, lg, mc_t, mc_s, final=final, seed=seed, sample_offset=sample_offset, step=step)
+                if gaps is not None:
+                    gaps[b] = min(float(gaps[b]), max(float(gap), 0.0))
+            new = c_oracle.ddpm_step(x[b:b + 1].numpy(), np.ascontiguousarray(lg[b:b + 1].numpy()), mct, mcs, final=fin, seed=seed,
+                                     sample_offset=int(r["sample_index"]), step=int(r["step"]))
+            x[b:b + 1].copy_(torch.from_numpy(new))
+        return x
+
+    def logit_error_stats(self, a, b, x):
+        e = (a[..., :V] - b[..., :V]).numpy().astype(np.float64)
+        e = np.delete(e, MASK, axis=-1)                      # drawable columns; pairs (4095, 4097) do not exist in the kernel
+        d = e[..., :-1] - e[..., 1:]
+        d = np.delete(d, MASK - 1, axis=-1)
+        m = (x.numpy() == MASK)[..., None]
+        out = np.stack([np.abs(e).max(-1), (e * e).sum(-1), np.abs(d).max(-1), (d * d).sum(-1)], -1) * m
+        return torch.from_numpy(out.astype(np.float32))
 
     def chain(self, seq, sch, seed, prior=None):
         B, L = seq.shape
@@ -114,42 +150,120 @@ def test_certified_chain_equals_exact_chain_under_bounded_logit_error(same_prote
     fast = _Net(noise=noise, seed=1)
     plain = fast.chain(seq, sch, seed=11)
     assert not torch.equal(plain, want), "the stand-in is too easy: the perturbed chain never leaves the exact one"
+    corrections = 0
     for trial in range(3):                                           # another perturbation every time
         fast = _Net(noise=noise, seed=10 + trial)
-        # eps=None: the bound is 2 x the largest error seen; the noise is uniform in +-0.05, so 2 x max is >= 0.05 after the probes
-        cs = CertifiedSampler(fast, _Net(), eps=eps_arg)
+        # eps = 0.05: the pair bound 2 eps = 0.1 is the largest difference two logits' errors can have (uniform in +-0.05);
+        # eps = None: 6 x the r.m.s. pair error (0.05 sqrt(2/3)) = 0.245 > 0.1, from the first probe on
+        cs = CertifiedSampler(fast, _Net(), eps=eps_arg, verify_batch=3, audit_rate=0.1, audit_seed=trial)
         got = cs.ddpm_sample(seq, sch, seed=11)
         st = cs.stats
         assert torch.equal(got, want), (trial, st)
-        assert st["eps_violations"] == 0 and st["max_logit_err_observed"] <= noise * 1.0001
-        assert st["first_update_shared"] == same_protein
-        assert 0 < st["sample_forwards_exact"] < st["sample_forwards_fast"] + B     # some close calls, not everything re-run
+        assert st["eps_violations"] == 0 and st["audit_mismatches"] == 0
+        assert st["max_logit_err_observed"] <= noise * 1.0001 and st["max_pair_err_observed"] <= 2 * noise * 1.0001
+        assert st["first_update_shared"] == same_protein and st["lane_width"] == 3      # 7 samples through a lane of 3 (max_batch)
+        assert st["flagged"] > 0 and st["verify_launches"] > 0 and max(st["verify_batch_sizes"]) <= 3     # exact.max_batch = 3
+        assert st["flagged"] < st["sample_forwards_fast"]                                # not everything re-run
+        corrections += st["corrections"]
         if eps_arg is None:
-            assert st["eps_min_used"] >= 0.05 * 0.9 and st["eps_max_used"] <= 2 * noise * 1.0001
+            assert 0.1 <= st["eps_min_used"] and st["eps_max_used"] <= 1.5 * 0.5 * 6 * 0.05 * 1.01
+            assert abs(st["sigma_pair_err"] - 0.05 * (2 / 3) ** 0.5) < 0.004
+    # speculation was wrong somewhere (the uncertified chain leaves the exact one) and the roll-back repaired it
+    assert corrections > 0
 
 
 def test_certified_with_prior_and_final_pass():
     """input_prior (inpainting: most rows given, a window masked): no step-0 sharing, carried rows untouched; one update only, so
-    MASKs survive into the noise-removal pass and its margin rule (difference of log-probabilities) is exercised."""
+    MASKs survive into the noise-removal pass and its margin rule (difference of log-probabilities) is exercised; a sample whose
+    prior holds no MASK at all is complete before the first forward."""
     B, L, T = 4, 10, 1
     sch = ddpm_schedule(T, freq_dim=256)
     seq = _seqs(B, L, True)
     g = torch.Generator().manual_seed(9)
     prior = torch.randint(0, 4096, (B, L), generator=g)
-    prior[:, 2:9] = MASK
+    prior[:3, 2:9] = MASK
     want = _Net().chain(seq, sch, seed=4, prior=prior)
     assert int((want == MASK).sum()) == 0
-    cs = CertifiedSampler(_Net(noise=0.05, seed=3), _Net(), eps=0.05)
+    fast = _Net(noise=0.05, seed=3)
+    cs = CertifiedSampler(fast, _Net(), eps=0.05, verify_batch=2)
     got = cs.ddpm_sample(seq, sch, seed=4, input_prior=prior)
     assert torch.equal(got, want) and not cs.stats["first_update_shared"]
-    assert torch.equal(got[:, :2], prior[:, :2]) and torch.equal(got[:, 9:], prior[:, 9:])
-    assert len(cs.stats["rerun_per_update"]) == T + 1
+    assert torch.equal(got[:, :2], prior[:, :2]) and torch.equal(got[:, 9:], prior[:, 9:]) and torch.equal(got[3], prior[3])
+    assert len(cs.stats["flagged_per_update"]) == T + 1
+    assert cs.stats["sample_forwards_fast"] <= 3 * (T + 1)            # the complete sample never entered a forward
     with pytest.raises(ValueError, match="input_prior shape"):
         cs.ddpm_sample(seq, sch, seed=4, input_prior=prior[:, :5])
+
+
+def _inject_big_error(target_calls):
+    """A fast-engine fault the margin test cannot see: at the given forward calls, +15 on one codebook logit of every masked row —
+    that token wins by a wide margin (unflagged), the exact engine draws something else."""
+    def hook(net, x, lg):
+        net.inject_calls = getattr(net, "inject_calls", 0) + 1
+        if net.inject_calls in target_calls:
+            lg = lg.copy()
+            m = x.numpy() == MASK
+            lg[..., 1234] = np.where(m, lg[..., 1234] + 15.0, lg[..., 1234])
+        return lg
+    return hook
+
+
+def test_audit_catches_an_error_above_eps_on_an_unflagged_sample():
+    """an error > eps on a sample the margin test did NOT flag.  With every unflagged sample-update audited
+    the mismatch is found, counted, repaired (the chain equals the exact one again) and eps is raised; with the audit off the
+    same fault silently leaves the exact chain — the audit is what catches it."""
+    B, L, T = 5, 8, 5
+    sch = ddpm_schedule(T, freq_dim=256)
+    seq = _seqs(B, L, False)
+    want = _Net().chain(seq, sch, seed=21)
+    fast = _Net(noise=0.01, seed=2)
+    fast.inject = _inject_big_error({2})
+    cs = CertifiedSampler(fast, _Net(), eps=0.01, audit_rate=1.0, verify_batch=4)
+    got = cs.ddpm_sample(seq, sch, seed=21)
+    st = cs.stats
+    assert torch.equal(got, want), st
+    assert st["audit_mismatches"] >= 1 and st["audit_eps_violations"] >= 1 and st["eps_violations"] >= st["audit_eps_violations"]
+    assert st["audit_max_pair_err"] > 14.9 and st["audit_checked"] >= B
+    assert st["eps_max_used"] > 7.0 and cs.pair_bound() > 15.0          # the bound was raised for the following updates
+    assert st["rollback_updates_discarded"] >= 0
+    fast = _Net(noise=0.01, seed=2)
+    fast.inject = _inject_big_error({2})
+    blind = CertifiedSampler(fast, _Net(), eps=0.01, audit_rate=0.0, verify_batch=4)
+    assert not torch.equal(blind.ddpm_sample(seq, sch, seed=21), want)
+    assert blind.stats["audit_checked"] == 0 and blind.stats["audit_mismatches"] == 0
+
+
+def test_rows_step_is_the_plain_step_per_sample():
+    """The stand-in's per-sample step (and with it the contract of esmdiff_ddpm_step_rows the GPU test checks against the kernel):
+    samples at different updates in one call = each sample alone through the plain step with its own scalars."""
+    net = _Net()
+    sch = ddpm_schedule(6, freq_dim=256)
+    B, L = 4, 7
+    seq = _seqs(B, L, False)
+    g = torch.Generator().manual_seed(1)
+    x = torch.full((B, L), MASK, dtype=torch.int64)
+    x[:, :2] = torch.randint(0, 4096, (B, 2), generator=g)
+    steps = np.array([0, 3, 6, 2])
+    tf = sch.t_freq[torch.from_numpy(steps)]
+    lg = net.forward_logits(x, seq, tf)
+    mc_t = np.array([float(sch.mc_t[k]) if k < 6 else 0.0 for k in steps], dtype=np.float32)
+    mc_s = np.array([float(sch.mc_s[k]) if k < 6 else 0.0 for k in steps], dtype=np.float32)
+    par = net.sample_step_params(10 + np.arange(B), mc_t, mc_s, steps, (steps == 6).astype(np.int32))
+    got = net.ddpm_step_rows(x.clone(), lg, par, seed=5)
+    for b in range(B):
+        one = net.forward_logits(x[b:b + 1], seq[b:b + 1], sch.t_freq[int(steps[b])])
+        assert torch.equal(one, lg[b:b + 1])                              # one sigma per sample = that sample alone
+        want = net.ddpm_step(x[b:b + 1].clone(), one, float(mc_t[b]), float(mc_s[b]), final=bool(steps[b] == 6), seed=5,
+                             sample_offset=10 + b, step=int(steps[b]))
+        assert torch.equal(got[b:b + 1], want)
 
 
 def test_certified_argument_checks():
     with pytest.raises(ValueError, match="eps"):
         CertifiedSampler(_Net(), _Net(), eps=0.0)
-    with pytest.raises(ValueError, match="safety"):
-        CertifiedSampler(_Net(), _Net(), safety=0.5)
+    with pytest.raises(ValueError, match="k_sigma"):
+        CertifiedSampler(_Net(), _Net(), k_sigma=0.0)
+    with pytest.raises(ValueError, match="audit_rate"):
+        CertifiedSampler(_Net(), _Net(), audit_rate=1.5)
+    with pytest.raises(ValueError, match="verify_batch"):
+        CertifiedSampler(_Net(), _Net(), verify_batch=0)

@@ -114,6 +114,99 @@ def test_sampler_fuzz_vs_c_oracle(tiny):
         assert np.array_equal(want[known], x[known])
 
 
+def test_sampler_rows_equals_plain_step_per_sample(tiny):
+    """esmdiff_ddpm_step_rows (ABI 7): a batch whose samples sit at different updates (own Philox index, move chances, step,
+    final flag) = every sample alone through esmdiff_ddpm_step with its scalars, ids bit for bit, and through the C oracle; the
+    per-sample flags are esmdiff_ddpm_step_margin's, and min_gap is the smallest log gap of the sample's masked rows (checked
+    in float64 from the oracle's uniforms)."""
+    from oracle import c_oracle
+    _, _, eng, _, _ = tiny
+    rng = np.random.default_rng(5)
+    for case in range(12):
+        B, L = int(rng.integers(1, 9)), int(rng.integers(1, 33))
+        ld = int(rng.choice([4104, 4352]))
+        z = rng.standard_normal((B, L, ld)).astype(np.float32) * float(rng.choice([0.5, 3.0, 40.0]))
+        x = np.full((B, L), MASK, dtype=np.int64)
+        known = rng.random((B, L)) < float(rng.choice([0.0, 0.4, 0.95]))
+        x[known] = rng.integers(0, 4096, int(known.sum()))
+        mct = rng.choice([0.999, 0.6, 0.04], B).astype(np.float32)
+        mcs = np.maximum(0, mct - rng.choice([0.04, 1e-4], B)).astype(np.float32)
+        steps = rng.integers(0, 50, B)
+        fin = (rng.random(B) < 0.3).astype(np.int32)
+        idx = rng.integers(0, 2 ** 40, B)
+        seed = int(rng.integers(0, 2 ** 31))
+        eps = float(rng.choice([1e-3, 0.05]))
+        zt = torch.from_numpy(z).cuda()
+        par = eng.sample_step_params(idx, mct, mcs, steps, fin)
+        flags = torch.zeros(B, dtype=torch.int32, device="cuda")
+        gaps = torch.full((B,), float("inf"), device="cuda")
+        got = eng.ddpm_step_rows(torch.from_numpy(x).cuda(), zt, par, seed=seed, eps=eps, flags=flags, gaps=gaps)
+        plain = eng.ddpm_step_rows(torch.from_numpy(x).cuda(), zt, par, seed=seed)          # no flags requested: same ids
+        assert torch.equal(got, plain)
+        for b in range(B):
+            kw = dict(final=bool(fin[b]), seed=seed, sample_offset=int(idx[b]), step=int(steps[b]))
+            one = eng.ddpm_step(torch.from_numpy(x[b:b + 1]).cuda(), zt[b:b + 1], float(mct[b]), float(mcs[b]), **kw)
+            assert torch.equal(got[b:b + 1], one), (case, b)
+            want = c_oracle.ddpm_step(x[b:b + 1], z[b:b + 1], float(mct[b]), float(mcs[b]), **kw)
+            assert np.array_equal(one.cpu().numpy(), want), (case, b)
+            f1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+            eng.ddpm_step_margin(torch.from_numpy(x[b:b + 1]).cuda(), zt[b:b + 1], float(mct[b]), float(mcs[b]),
+                                 margin=2 * eps if fin[b] else float(np.exp(2 * eps)), flags=f1, **kw)
+            assert int(f1[0]) == int(flags[b]), (case, b)
+            # the gap statistic against a float64 restatement
+            zz = z[b, :, :V].astype(np.float64).copy()
+            zz[:, MASK] -= 1e6
+            lp = zz - (np.log(np.exp(zz - zz.max(-1, keepdims=True)).sum(-1, keepdims=True)) + zz.max(-1, keepdims=True))
+            best = np.inf
+            for l in range(L):
+                if x[b, l] != MASK:
+                    continue
+                if fin[b]:
+                    val = lp[l]
+                    top = np.partition(val, -2)[-2:]
+                    gap = top[1] - top[0]
+                else:
+                    u = c_oracle.philox_uniforms(seed, int(idx[b]), int(steps[b]), l, V).astype(np.float64)
+                    q = np.exp(lp[l]) * (np.float64(mct[b]) - np.float64(mcs[b]))
+                    q[MASK] = mcs[b]
+                    val = q / (1e-10 - np.log(u + 1e-10))
+                    top = np.partition(val, -2)[-2:]
+                    gap = np.log(top[1]) - np.log(max(top[0], 1e-37))
+                best = min(best, gap)
+            g = float(gaps[b])
+            if np.isinf(best):
+                assert np.isinf(g) and int(flags[b]) == 0
+            else:
+                assert abs(g - best) <= 2e-5 * max(1.0, abs(best)) + 2e-6, (case, b, g, best)
+    with pytest.raises(RuntimeError, match="margin"):
+        eng.ddpm_step_rows(torch.from_numpy(x).cuda(), zt, par, seed=1, eps=-1.0, flags=flags)
+
+
+def test_logit_error_stats_vs_torch(tiny):
+    """esmdiff_logit_error_stats: per masked row max / sum of squares of the logit error and of the adjacent-pair error over the
+    drawable columns (all but MASK; the pair (4095, 4096) and (4096, 4097) do not exist), zeros for carried rows — vs float64."""
+    _, _, eng, _, _ = tiny
+    g = torch.Generator().manual_seed(8)
+    n, L = 5, 23
+    a = torch.randn(n, L, 4104, generator=g).cuda()
+    b = (a.cpu() + 1e-3 * torch.randn(n, L, 4104, generator=g)).cuda()
+    b[..., MASK] += 100.0                                        # the MASK column must not count
+    x = torch.full((n, L), MASK, dtype=torch.int64)
+    x[:, 3:9] = 7
+    x[2] = 5
+    got = eng.logit_error_stats(a[..., :V], b, x.cuda()).cpu().double()
+    e = (a[..., :V] - b[..., :V]).cpu().double()
+    keep = [v for v in range(V) if v != MASK]
+    d = e[..., :-1] - e[..., 1:]
+    dk = [v for v in range(V - 1) if v != MASK and v + 1 != MASK]
+    want = torch.stack([e[..., keep].abs().amax(-1), (e[..., keep] ** 2).sum(-1), d[..., dk].abs().amax(-1), (d[..., dk] ** 2).sum(-1)], -1)
+    want = want * (x == MASK)[..., None]
+    assert torch.equal(got[x != MASK], torch.zeros_like(got[x != MASK]))
+    assert float((got[..., 0] - want[..., 0]).abs().max()) == 0 and float((got[..., 2] - want[..., 2]).abs().max()) == 0
+    assert float(((got[..., 1] - want[..., 1]) / want[..., 1].clamp_min(1e-30)).abs().max()) < 1e-5
+    assert float(((got[..., 3] - want[..., 3]) / want[..., 3].clamp_min(1e-30)).abs().max()) < 1e-5
+
+
 def test_sampler_full_size_config2(tiny):
     """BASELINE config 2 row count (B*L = 100*258 rows of 4101) — bit-exact on a 24-sample slice, and the
     size-independent properties on all of it: carry-over, ids in range, mask never drawn at mc_s = 0."""

@@ -51,7 +51,7 @@ def test_library_exports_every_declared_symbol():
         assert f"_ZN2ed{len(fn)}{fn}" in syms and f"_ZN4ed16{len(fn)}{fn}" in syms, fn
     # the product library carries no debug exports
     assert not hasattr(L, "esmdiff_debug_graph_ab") and not hasattr(L, "esmdiff_gemm_bf16_timed")
-    assert L.esmdiff_abi_version() == 6
+    assert L.esmdiff_abi_version() == 7
 
 
 def test_config_dimensions():
