@@ -53,8 +53,9 @@ EXPORTS = [
     "esmdiff_encoder_encode", "esmdiff_gemm_f32", "esmdiff_set_step0_sharing", "esmdiff_get_counters",
     "esmdiff_set_gibbs_options", "esmdiff_split_rows", "esmdiff_split_weight", "esmdiff_gemm_split",
     "esmdiff_get_embeddings", "esmdiff_set_final_skip", "esmdiff_gemm_f16", "esmdiff_ddpm_step_margin", "esmdiff_forward_logits_sigmas", "esmdiff_set_small_batch_splitk",
-    "esmdiff_ddpm_step_rows", "esmdiff_logit_error_stats",
+    "esmdiff_ddpm_step_rows", "esmdiff_logit_error_stats", "esmdiff_get_build_info", "esmdiff_describe_plan", "esmdiff_set_option",
 ]
+OPT_STREAMS, OPT_DUAL_MIN_TOKENS = 1, 2      # esmdiff_option
 
 
 def lib_path() -> Path:
@@ -93,6 +94,9 @@ def lib():
     L.esmdiff_ddpm_step_margin.restype = ctypes.c_int
     L.esmdiff_ddpm_step_rows.argtypes = [vp, vp, vp, i32, vp, ctypes.c_uint64, i32, i32, f32, f32, vp, vp, vp]
     L.esmdiff_logit_error_stats.argtypes = [vp, i32, vp, i32, vp, i32, i32, vp, vp]
+    L.esmdiff_get_build_info.argtypes = [ctypes.c_char_p, i32]
+    L.esmdiff_describe_plan.argtypes = [vp, i32, i32, ctypes.c_char_p, i32]
+    L.esmdiff_set_option.argtypes = [vp, i32, ctypes.c_int64]
     L.esmdiff_ddpm_sample.argtypes = [vp, vp, vp, i32, i32, i32, c_f32p, c_f32p, c_f32p, ctypes.POINTER(Rng), vp]
     L.esmdiff_gibbs_step.argtypes = [vp, vp, vp, vp, i32, f32, f32, vp, vp, ctypes.POINTER(Rng), i32, i32, i32, vp]
     L.esmdiff_gibbs_sample.argtypes = [vp, vp, vp, i32, i32, i32, f32, f32, ctypes.POINTER(i32), ctypes.POINTER(Rng), vp]
@@ -142,6 +146,13 @@ def lib():
         raise RuntimeError("libesmdiff_hip.so ABI version mismatch")
     _lib = L
     return L
+
+
+def build_info() -> str:
+    """esmdiff_get_build_info: ABI, arch, whether this is a -DED_DEBUG build (the only kind that reads ESMDIFF_* tuning switches)."""
+    buf = ctypes.create_string_buffer(1024)
+    lib().esmdiff_get_build_info(buf, 1024)
+    return buf.value.decode()
 
 
 def check(code: int, eng=None):

@@ -23,7 +23,6 @@ INCLUDE = PKG.parent / "include"
 UNITS = {
     "engine": [],
     "gemm": [],
-    "gemm256": [],
     "gemm256w4": [],
     "gemm_split": [],
     "attention_split": [],
@@ -42,7 +41,7 @@ UNITS = {
 # The MFMA kernels, the row kernels that feed them and the weight conversion are compiled a SECOND time with f16 operands
 # (csrc/ed_half.h): -DED_F16 switches the conversion / MFMA primitives, -Ded=ed16 puts that build into namespace ed16
 # (every `ed` token of those sources is the namespace name).  precision="f16" engines call the ed16 kernels.
-F16_UNITS = ["gemm", "gemm256", "gemm256w4", "attention", "norm", "geom", "convert"]
+F16_UNITS = ["gemm", "gemm256w4", "attention", "norm", "geom", "convert"]
 F16_FLAGS = ["-DED_F16", "-Ded=ed16"]
 EXTRA = os.environ.get("ESMDIFF_EXTRA_CXXFLAGS", "").split()
 COMMON = EXTRA + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math",

@@ -167,6 +167,8 @@ class CertifiedSampler:
             if tuple(input_prior.shape) != (B, L):
                 raise ValueError(f"Invalid input_prior shape: {tuple(input_prior.shape)} v.s. (seq) {(B, L)}")
             x = input_prior.to(device=dev, dtype=torch.int64).contiguous().clone()
+        if hasattr(fast, "_check_ids"):
+            fast._check_ids(seq, x)                                # once: every later forward sees these ids or the kernels' own
         T = schedule.num_steps
         V = exact.cfg.n_structure_heads
         tf_fast = fast.conditioning_rows(schedule.t_freq)
@@ -195,6 +197,7 @@ class CertifiedSampler:
               "sample_forwards_fast": 0, "sample_forwards_exact": 0, "max_logit_err_observed": 0.0, "max_pair_err_observed": 0.0,
               "flagged_per_update": [0] * (T + 1), "eps_used": []}
         gap_log: List[float] = []                                  # min gap of every live sample-update / the eps it ran with
+        timers: list = []                                          # (lane, start event, end event) of every forward + draw
 
         def settle_final(s: int) -> None:
             # a sample without a MASK is carried through every remaining update and through the noise removal unchanged
@@ -230,28 +233,46 @@ class CertifiedSampler:
                 for s in range(B):
                     settle_final(s)
 
+        def up(a: np.ndarray) -> torch.Tensor:
+            """Host array -> device through pinned memory: never waits for the work already queued on the stream (a pageable
+            copy is performed synchronously BEHIND it, which would park the host for the length of a forward)."""
+            t = torch.from_numpy(a)
+            return t.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else t
+
+        def tick():
+            if dev.type != "cuda":
+                return None
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+
         def launch_fast(active: np.ndarray, which: int) -> None:
             n = len(active)
             full = n == B
             steps = step[active].copy()
+            # every upload first: nothing below waits for the host
+            par = up(fast.sample_step_params_host(sample_offset + active, mc_t[steps], mc_s[steps], steps, (steps == T).astype(np.int32)))
+            mixed = not (steps == steps[0]).all()
+            steps_d = up(steps) if (mixed and tf_fast_d is not None) else None
             if full:
                 xa, sa = x, seq
             else:
-                idx_d = torch.from_numpy(active).to(dev)
+                idx_d = up(active)
                 xa, sa = x[idx_d], seq[idx_d]
             prev = xa.clone()
             if tf_fast_d is None:
                 tf = None
-            elif (steps == steps[0]).all():
+            elif not mixed:
                 tf = tf_fast_d[int(steps[0])]
             else:
-                tf = tf_fast_d[torch.from_numpy(steps).to(dev)]
-            lg = fast.forward_logits(xa, sa, tf, out=lbuf[which][:n])
+                tf = tf_fast_d[steps_d]
+            e0 = tick()
+            lg = fast.forward_logits(xa, sa, tf, out=lbuf[which][:n], check_ids=False)    # ids checked once below
             eps_i = self._eps_now()
-            par = fast.sample_step_params(sample_offset + active, mc_t[steps], mc_s[steps], steps, (steps == T).astype(np.int32))
             flags = torch.zeros(n, dtype=torch.int32, device=dev)
             gaps = torch.full((n,), float("inf"), dtype=torch.float32, device=dev)
             fast.ddpm_step_rows(xa, lg, par, seed=seed, eps=eps_i, flags=flags, gaps=gaps)
+            timers.append(("fast", e0, tick()))
             if not full:
                 x[idx_d] = xa
             after = xa.clone() if full else xa
@@ -292,7 +313,7 @@ class CertifiedSampler:
                 take, pick = pick[:room], pick[room:]
                 tk, kinds = kinds[:room], kinds[room:]
                 lo = len(pool["items"])
-                jd = torch.tensor(take, dtype=torch.int64, device=dev)
+                jd = up(np.asarray(take, dtype=np.int64))
                 pool["before"][lo:lo + len(take)] = rec["prev"][jd]
                 pool["after"][lo:lo + len(take)] = rec["after"][jd]
                 pool["lg"][lo:lo + len(take)] = rec["lg"][jd]
@@ -312,15 +333,18 @@ class CertifiedSampler:
             items = pool["items"]
             ss = np.array([it["s"] for it in items], dtype=np.int64)
             ks = np.array([it["k"] for it in items], dtype=np.int64)
+            par = up(exact.sample_step_params_host(sample_offset + ss, mc_t[ks], mc_s[ks], ks, (ks == T).astype(np.int32)))
+            ss_d, ks_d = up(ss), up(ks)
             xs = pool["before"][:n].clone()
-            sq = seq[torch.from_numpy(ss).to(dev)]
-            tf = None if tf_exact_d is None else tf_exact_d[torch.from_numpy(ks).to(dev)]
+            sq = seq[ss_d]
+            tf = None if tf_exact_d is None else tf_exact_d[ks_d]
             if tf is not None and n == 1:
                 tf = tf[0]
-            lg2 = exact.forward_logits(xs, sq, tf)
+            e0 = tick()
+            lg2 = exact.forward_logits(xs, sq, tf, check_ids=False)
             stats = self._item_stats(pool["lg"][:n], lg2, pool["before"][:n])
-            par = exact.sample_step_params(sample_offset + ss, mc_t[ks], mc_s[ks], ks, (ks == T).astype(np.int32))
             exact.ddpm_step_rows(xs, lg2, par, seed=seed)
+            timers.append(("verify", e0, tick()))
             neq = (xs != pool["after"][:n]).any(1).to(torch.float32)
             hm = (xs == MASK).any(1).to(torch.float32)
             back = _Async(torch.cat([stats, neq[:, None], hm[:, None]], 1))
@@ -390,6 +414,9 @@ class CertifiedSampler:
         st["seconds"] = round(time.perf_counter() - t_call, 4)
         st["tail_seconds"] = 0.0 if t_tail is None else round(time.perf_counter() - t_tail, 4)     # after the last full-lane forward
         st["lane_width"] = W
+        if timers and timers[0][1] is not None:                   # device time inside the two lanes (HIP events on the stream)
+            for lane in ("fast", "verify"):
+                st[f"gpu_seconds_{lane}"] = round(sum(a.elapsed_time(b) for ln_, a, b in timers if ln_ == lane) * 1e-3, 4)
         gl = np.array(gap_log) if gap_log else np.zeros(0)
         n_upd = max(1, len(gl))
         used = st.pop("eps_used")

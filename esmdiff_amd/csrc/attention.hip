@@ -113,11 +113,11 @@ hipError_t launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* qkv,
                             int H, hipStream_t stream) {
   if (B <= 0 || L <= 0) return hipSuccess;
   static const int forced = [] {
-    const char* e = getenv("ESMDIFF_ATTN_WAVES");
+    const char* e = ed_dbg_env("ESMDIFF_ATTN_WAVES");
     return e ? atoi(e) : 0;
   }();
   static const int occ = [] {
-    const char* e = getenv("ESMDIFF_ATTN_OCC");
+    const char* e = ed_dbg_env("ESMDIFF_ATTN_OCC");
     return e && atoi(e) == 3 ? 3 : 4;
   }();
   const int W = forced > 0 ? std::min(forced, 10) : (forced < 0 ? attention_waves(L, occ) : std::min(4, (L + 31) / 32));

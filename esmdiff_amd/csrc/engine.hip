@@ -112,6 +112,7 @@ struct esmdiff_engine {
   float* sk_parts = nullptr;
   int64_t strict_dual_min_tokens = 8192;   // F32_SPLIT: two sub-batch streams from this many tokens (ESMDIFF_STRICT_DUAL_MIN_TOKENS)
   int64_t dual_min_tokens = 2200, dual_small_max_tokens = 1024;  // two streams from / small window up to (tokens), see forward()
+  int n_streams = 2;         // esmdiff_set_option(ESMDIFF_OPT_STREAMS): sub-batch launch queues of the 16-bit forward
   int stream_offset_us = 0;  // phase offset of the second sub-batch stream (ESMDIFF_STREAM_OFFSET_US), see forward()
   int debug_skip = 0;  // -DED_DEBUG builds only: ESMDIFF_DEBUG_SKIP bits (timing experiments, results are wrong): 1 rope, 2 attention, 4 / 8 the two add+LN; always 0 otherwise
   ed::GemmWorkspace gemm_ws[4] = {};  // split-K partials of the small-M GEMM path, one per launch queue
@@ -354,7 +355,7 @@ int plan_parts(const esmdiff_engine* e, int B, int L) {
   const int64_t tokens = (int64_t)B * L;
   if (!e->side.empty() && e->profiling != 1 && B >= 2 &&
       (tokens >= e->dual_min_tokens || (B >= 8 && tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(768, e->dual_min_tokens))))
-    return std::min<int>({(int)e->side.size() + 1, B, 4});
+    return std::min<int>({(int)e->side.size() + 1, e->n_streams, B, 4});
   return 1;
 }
 bool plan_small(const esmdiff_engine* e, int B, int L) {
@@ -648,6 +649,86 @@ int esmdiff_set_step0_sharing(esmdiff_engine* e, int32_t on) {
   return 0;
 }
 
+static int add_side_stream(esmdiff_engine* e) {
+  hipStream_t sd = nullptr;
+  hipEvent_t ev = nullptr;
+  if (hipStreamCreateWithFlags(&sd, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+    return fail(e, ESMDIFF_E_HIP, "side stream: %s", hipGetErrorString(hipGetLastError()));
+  e->side.push_back(sd);
+  e->ev_join.push_back(ev);
+  return 0;
+}
+
+int esmdiff_set_option(esmdiff_engine* e, int32_t option, int64_t value) {
+  if (!e) return ESMDIFF_E_INVALID;
+  switch (option) {
+    case ESMDIFF_OPT_STREAMS:
+      if (value < 1 || value > 4) return fail(e, ESMDIFF_E_INVALID, "ESMDIFF_OPT_STREAMS: 1 .. 4, got %lld", (long long)value);
+      HIP_TRY(e, hipSetDevice(e->device));
+      while ((int64_t)e->side.size() + 1 < value)
+        if (int r = add_side_stream(e)) return r;
+      e->n_streams = (int)value;
+      return 0;
+    case ESMDIFF_OPT_DUAL_MIN_TOKENS:
+      if (value < 1) return fail(e, ESMDIFF_E_INVALID, "ESMDIFF_OPT_DUAL_MIN_TOKENS must be positive");
+      e->dual_min_tokens = value;
+      return 0;
+    default:
+      return fail(e, ESMDIFF_E_INVALID, "unknown option %d", option);
+  }
+}
+
+int esmdiff_get_build_info(char* buf, int32_t cap) {
+#ifdef ED_DEBUG
+  const int dbg = 1;
+#else
+  const int dbg = 0;
+#endif
+  char tmp[512];
+  const int n = snprintf(tmp, sizeof tmp,
+                         "libesmdiff_hip abi=%d arch=gfx950 debug_env=%d (%s) operand_builds=bf16,f16 fp_contract_off=sampler,gibbs,metrics "
+                         "compiler=%s",
+                         ESMDIFF_ABI_VERSION, dbg,
+                         dbg ? "-DED_DEBUG: ESMDIFF_* tuning switches are read from the environment" : "product build: no ESMDIFF_* tuning switch is read",
+                         __VERSION__);
+  if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", tmp);
+  return n;
+}
+
+int esmdiff_describe_plan(const esmdiff_engine* e, int32_t B, int32_t L, char* buf, int32_t cap) {
+  if (!e || B <= 0 || L <= 0) return ESMDIFF_E_INVALID;
+  const esmdiff_config& c = e->cfg;
+  const int D = c.d_model, FH = c.ffn_hidden;
+  char tmp[1024];
+  int n = 0;
+  const char* prec = e->strict ? (e->split ? "f32_split" : "f32") : (e->f16 ? "f16" : "bf16");
+  n += snprintf(tmp + n, sizeof tmp - n, "precision=%s head=%s B=%d L=%d", prec, (e->strict || e->head_split) ? "f32-grade" : prec, B, L);
+  if (e->strict) {
+    const int64_t tokens = (int64_t)B * L;
+    const int np = (e->split && !e->side.empty() && B >= 2 && tokens >= e->strict_dual_min_tokens) ? 2 : 1;
+    n += snprintf(tmp + n, sizeof tmp - n, " streams=%d path=%s k_sliced_small_batches=%d", np,
+                  e->split ? "split(3 f16 MFMA passes, 256x256w4)" : "strict(f32 MFMA)", e->sk_parts && tokens <= e->splitk_max_rows ? 1 : 0);
+  } else {
+    const int np = plan_parts(e, B, L);
+    const bool small = plan_small(e, B, L);
+    const int m0 = (int)((int64_t)B / np) * L;
+    char g1[32], g2[32], g3[32], g4[32];
+    ed::describe_gemm(m0, 3 * D, D, e->gemm_ws[0].partial != nullptr, g1, sizeof g1);
+    ed::describe_gemm(m0, D, D, e->gemm_ws[0].partial != nullptr, g2, sizeof g2);
+    ed::describe_gemm(m0, 2 * FH, D, e->gemm_ws[0].partial != nullptr, g3, sizeof g3);
+    ed::describe_gemm(m0, D, FH, false, g4, sizeof g4);
+    n += snprintf(tmp + n, sizeof tmp - n, " streams=%d rows_per_stream=%d path=%s", np, m0, small ? "small-batch(K-slice planes summed by the LayerNorm)" : "regular");
+    if (small)
+      n += snprintf(tmp + n, sizeof tmp - n, " gemm[qkv]=%s gemm[out]=128x*/S%d gemm[ffn_up]=%s gemm[ffn_down]=128x*/S%d", g1, ed::gemm_partial_splits(D, D), g3,
+                    ed::gemm_partial_splits(D, FH));
+    else
+      n += snprintf(tmp + n, sizeof tmp - n, " gemm[qkv]=%s gemm[out]=%s gemm[ffn_up]=%s gemm[ffn_down]=%s", g1, g2, g3, g4);
+  }
+  n += snprintf(tmp + n, sizeof tmp - n, " step0_sharing=%d final_skip=%d small_max_rows=%d", e->step0_share, e->final_skip, ed::small_max_rows());
+  if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", tmp);
+  return n;
+}
+
 int esmdiff_set_final_skip(esmdiff_engine* e, int32_t on) {
   if (!e) return ESMDIFF_E_INVALID;
   e->final_skip = on ? 1 : 0;
@@ -657,7 +738,7 @@ int esmdiff_set_final_skip(esmdiff_engine* e, int32_t on) {
 int esmdiff_set_small_batch_splitk(esmdiff_engine* e, int32_t on) {
   if (!e) return ESMDIFF_E_INVALID;
   if (on && !e->split) return fail(e, ESMDIFF_E_INVALID, "K-sliced small batches exist for the F32_SPLIT precision only");
-  if (const char* mr = getenv("ESMDIFF_SPLITK_MAX_ROWS")) e->splitk_max_rows = atoi(mr);   // (experiments: K-sliced at every size)
+  if (const char* mr = ed_dbg_env("ESMDIFF_SPLITK_MAX_ROWS")) e->splitk_max_rows = atoi(mr);   // (experiments: K-sliced at every size)
   if (on && !e->sk_parts) {
     HIP_TRY(e, hipSetDevice(e->device));
     const int64_t rows = std::min<int64_t>(e->splitk_max_rows, (int64_t)e->cfg.max_batch * e->cfg.max_len);
@@ -795,7 +876,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     if (split) {
       // FFN-up with the SwiGLU fused into the split GEMM's epilogue (rows interleaved gate / up): the mid row is written with ONE
       // power-of-two scale per layer, from |mid| = |silu(g) u| <= |g| |u| <= B^2, B = (sqrt(D) max|ln2 g| + |ln2 b|_2) max_row |W row|_2
-      const bool fuse = FH % 32 == 0 && !getenv("ESMDIFF_SPLIT_UNFUSED_SWIGLU");
+      const bool fuse = FH % 32 == 0 && !ed_dbg_env("ESMDIFF_SPLIT_UNFUSED_SWIGLU");
       TRY(load_split(e, t, b + "ffn.1.weight", {2 * FH, D}, &ly.s_up, 0, fuse ? FH : 0));
       TRY(load_split(e, t, b + "ffn.3.weight", {D, FH}, &ly.s_down));
       if (fuse) {
@@ -1040,7 +1121,7 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(dalloc(e, &e->g_sampled, Mx));
     TRY(dalloc(e, &e->g_nunmask, (size_t)e->tfreq_rows * cfg->max_batch));
     {  // split-K workspaces: S * N <= 12288 for every shape the launcher splits; rows up to the small-batch switch
-      const char* sk = getenv("ESMDIFF_GEMM_SPLITK");
+      const char* sk = ed_dbg_env("ESMDIFF_GEMM_SPLITK");
       if (!(sk && sk[0] == '0') && !strict) {
         const size_t rows = (size_t)round_up((int)std::min<size_t>(Mx, ed::small_max_rows()), 128);
         for (int q = 0; q < 4; ++q) {
@@ -1055,8 +1136,9 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
 #undef TRY
   // second launch queue for the two-stream forward (ESMDIFF_DUAL_STREAM=0 disables, ESMDIFF_DUAL_STREAM_MIN_TOKENS tunes)
   {
-    int n_streams = 2;  // ESMDIFF_DUAL_STREAM = 0/1: one stream; 2 (default) .. 4: that many sub-batches
-    if (const char* ds = getenv("ESMDIFF_DUAL_STREAM")) n_streams = std::max(1, std::min(4, atoi(ds)));
+    int n_streams = 2;  // (-DED_DEBUG: ESMDIFF_DUAL_STREAM = 0/1: one stream; 2 (default) .. 4: that many sub-batches)
+    if (const char* ds = ed_dbg_env("ESMDIFF_DUAL_STREAM")) n_streams = std::max(1, std::min(4, atoi(ds)));
+    e->n_streams = n_streams;
     if (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess)
       return bail(fail(e, ESMDIFF_E_HIP, "engine create: fork event: %s", hipGetErrorString(hipGetLastError())));
     for (int i = 1; i < n_streams; ++i) {
@@ -1069,18 +1151,18 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
       e->ev_join.push_back(ev);
     }
 #ifdef ED_DEBUG
-    if (const char* ds = getenv("ESMDIFF_DEBUG_SKIP")) e->debug_skip = atoi(ds);
+    if (const char* ds = ed_dbg_env("ESMDIFF_DEBUG_SKIP")) e->debug_skip = atoi(ds);
 #else
     // the launch-skipping switch of the timing experiments (results are wrong by construction) exists in -DED_DEBUG builds only;
     // a product library that finds it in the environment refuses to start rather than silently ignore a request it once honoured
     if (getenv("ESMDIFF_DEBUG_SKIP"))
       return bail(fail(e, ESMDIFF_E_INVALID, "ESMDIFF_DEBUG_SKIP is set, but this libesmdiff_hip.so was built without -DED_DEBUG: unset it"));
 #endif
-    if (const char* so = getenv("ESMDIFF_STREAM_OFFSET_US")) e->stream_offset_us = atoi(so);
-    if (const char* sf = getenv("ESMDIFF_SMALL_FUSED")) e->small_fused = atoi(sf);
-    if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_MIN_TOKENS")) e->dual_min_tokens = atoll(mt);
-    if (const char* mt = getenv("ESMDIFF_STRICT_DUAL_MIN_TOKENS")) e->strict_dual_min_tokens = atoll(mt);
-    if (const char* mt = getenv("ESMDIFF_DUAL_STREAM_SMALL_MAX_TOKENS")) e->dual_small_max_tokens = atoll(mt);
+    if (const char* so = ed_dbg_env("ESMDIFF_STREAM_OFFSET_US")) e->stream_offset_us = atoi(so);
+    if (const char* sf = ed_dbg_env("ESMDIFF_SMALL_FUSED")) e->small_fused = atoi(sf);
+    if (const char* mt = ed_dbg_env("ESMDIFF_DUAL_STREAM_MIN_TOKENS")) e->dual_min_tokens = atoll(mt);
+    if (const char* mt = ed_dbg_env("ESMDIFF_STRICT_DUAL_MIN_TOKENS")) e->strict_dual_min_tokens = atoll(mt);
+    if (const char* mt = ed_dbg_env("ESMDIFF_DUAL_STREAM_SMALL_MAX_TOKENS")) e->dual_small_max_tokens = atoll(mt);
   }
   if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "engine create: %s", hipGetErrorString(hipGetLastError())));
   *out = e;
@@ -1510,7 +1592,7 @@ int esmdiff_branch_linear_layernorm(esmdiff_engine* e, const void* A, const void
                                     const float* b, void* y, int32_t M, int32_t N, int32_t K, int32_t* splits_out,
                                     void* stream) {
   if (!e || !A || !W || !x || !w || !y) return ESMDIFF_E_INVALID;
-  if (!e->gemm_ws[0].partial) return fail(e, ESMDIFF_E_INVALID, "engine has no split-K workspace (ESMDIFF_GEMM_SPLITK=0)");
+  if (!e->gemm_ws[0].partial) return fail(e, ESMDIFF_E_INVALID, "engine has no split-K workspace (f32 / f32_split engines have none)");
   ed::GemmPartials P{};
   hipError_t s = launch_gemm_partials((const bf16_t*)A, (const bf16_t*)W, &e->gemm_ws[0], M, N, K, (hipStream_t)stream, &P);
   if (s == hipSuccess) s = launch_add_partials_layernorm_bf16(x, P, N, alpha, w, b, (bf16_t*)y, M, N, (hipStream_t)stream);

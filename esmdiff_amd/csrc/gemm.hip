@@ -35,6 +35,7 @@
 #include <stdlib.h>
 
 #include "ed_half.h"
+#include <stdio.h>
 #include "kernels.h"
 
 namespace ed {
@@ -407,7 +408,7 @@ static hipError_t launch_tiles(const bf16_t* A, const bf16_t* W, void* out, cons
 // ESMDIFF_GEMM_SMALL_BM=64|128 forces one (A/B runs).
 static int small_tile_mi(int M, int N, int S) {
   static const int forced = [] {
-    const char* e = getenv("ESMDIFF_GEMM_SMALL_BM");
+    const char* e = ed_dbg_env("ESMDIFF_GEMM_SMALL_BM");
     return e ? atoi(e) : 0;
   }();
   if (forced == 64) return 1;
@@ -427,19 +428,23 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
   // (Measured and rejected: splitting the rows so that 256-row tiles fill whole 256-CU rounds and the leftover
   // rows go through this kernel — 93 + 29 us apart, 138 us back to back, vs 132 us unsplit at N = K = 1536.)
   static const int forced = [] {
-    const char* e = getenv("ESMDIFF_GEMM_TILE");
+    const char* e = ed_dbg_env("ESMDIFF_GEMM_TILE");
     return e ? atoi(e) : 0;
   }();
   static const int min_tiles = [] {
-    const char* e = getenv("ESMDIFF_GEMM_256_MIN_TILES");
+    const char* e = ed_dbg_env("ESMDIFF_GEMM_256_MIN_TILES");
     return e ? atoi(e) : 128;
   }();
   // (r02, inside the two-stream forward: the N = 1536 linears of a 2 817 .. 5 376-row sub-batch — 72 .. 126 tiles — also
   // run better on the persistent 256x256 kernel, which leaves the other CUs to the other stream: B = 24 .. 40 at L_tok = 258
   // +1 .. 3 %; at 7 - 8 row tiles (QKV of a 1 548-row sub-batch, 126 tiles) the 128-column kernel still wins, B = 12 -3 %)
+  // The 256x256 kernel (gemm256w4.hip) walks K in pairs of 64-wide tiles and needs >= 6 of them; other K (none in ESM3-open, the
+  // decoder or the encoder: 1536, 4096, 1280, 3584, 768) stay on this kernel.  (The r01 eight-wave 256x256 kernel that used to
+  // take those shapes left the product in r05: scratch/gemm256_8wave_kernel.hip.txt.)
   const int t256m = (M + 255) / 256, t256 = t256m * (N / 256);
-  if (N % 256 == 0 && (forced == 256 || (forced == 0 && (t256 >= min_tiles || (t256 >= 72 && t256m >= 12)))))
-    return launch_gemm256_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
+  if (N % 256 == 0 && K % (2 * BK) == 0 && K >= 6 * BK &&
+      (forced == 256 || (forced == 0 && (t256 >= min_tiles || (t256 >= 72 && t256m >= 12)))))
+    return launch_gemm256w4_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
   const int tiles_n = N / BN;
   // split-K factor, a function of (N, K) only: for K >= 2048 (FFN-down) the largest divisor of K/64 that is <= 8 and
   // keeps tiles_n * S <= 96.  Measured (us per launch, M = 240 / 774): FFN-down K = 4096 S = 8: 42 -> 17 / 41 -> 35;
@@ -461,6 +466,28 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
                       S > 1 ? ws->partial : nullptr, pstride, false);
 }
 
+// Which kernel launch_gemm_bf16 picks for a shape, as text (esmdiff_describe_plan): "256x256w4" or "128x<rows>[/S<k-slices>]".
+void describe_gemm(int M, int N, int K, bool ws, char* out, size_t cap) {
+  const int t256m = (M + 255) / 256, t256 = t256m * (N / 256);
+  if (N % 256 == 0 && K % (2 * BK) == 0 && K >= 6 * BK && (t256 >= 128 || (t256 >= 72 && t256m >= 12))) {
+    snprintf(out, cap, "256x256w4");
+    return;
+  }
+  int S = 1;
+  const int tiles_n = N / BN;
+  if (M < small_max_rows() && ws && K >= 2048) {
+    const int nk = K / BK;
+    for (int c = 8; c >= 2; --c)
+      if (nk % c == 0 && tiles_n * c <= 96) {
+        S = c;
+        break;
+      }
+  }
+  const int mi = M < small_max_rows() ? small_tile_mi(M, N, S) : 2;
+  if (S > 1) snprintf(out, cap, "128x%d/S%d", 64 * mi, S);
+  else snprintf(out, cap, "128x%d", 64 * mi);
+}
+
 // ---- residual-branch linears of the small-batch path ------------------------------------------------------------
 // Below small_max_rows() (1 152) rows the out-projection and FFN-down products are left as S raw f32 K-slice planes; the add+LayerNorm
 // kernel that consumes them (norm.hip: launch_add_partials_layernorm_bf16) sums the planes in the order s = 0..S-1,
@@ -470,7 +497,7 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
 // K = 4096 -> 8).  ESMDIFF_GEMM_PSPLIT=<S> overrides (A/B runs; must divide K/64).
 int gemm_partial_splits(int N, int K) {
   static const int forced = [] {
-    const char* e = getenv("ESMDIFF_GEMM_PSPLIT");
+    const char* e = ed_dbg_env("ESMDIFF_GEMM_PSPLIT");
     return e ? atoi(e) : 0;
   }();
   const int nk = K / BK, tiles_n = N / BN;

@@ -13,6 +13,16 @@
 
 typedef uint16_t bf16_t;  // raw bfloat16 bits
 
+// Tuning switches of the A/B experiments (tile shapes, stream counts, K-slice factors ...; several of them change the K summation
+// order and with it the last bits of the logits) are read from the environment in -DED_DEBUG builds ONLY.  The product library
+// reads no ESMDIFF_* variable except ESMDIFF_DEBUG_SKIP, and that one only to refuse to start (engine.hip); what callers may
+// legitimately choose is an explicit esmdiff_set_option field.  tests/test_host_cpu.py checks the binary's strings.
+#ifdef ED_DEBUG
+inline const char* ed_dbg_env(const char* name) { return getenv(name); }
+#else
+inline const char* ed_dbg_env(const char*) { return nullptr; }
+#endif
+
 // Types shared by the two operand-type builds of the kernels (namespace ed = bf16, ed16 = f16, see ed_half.h).
 struct EdGemmWorkspace {
   float* partial;

@@ -141,14 +141,15 @@ class Engine:
         return zero.expand(t_freq.shape[0], -1).contiguous() if t_freq.dim() == 2 else zero[0]
 
     def forward_logits(self, x: torch.Tensor, sequence_tokens: torch.Tensor, t_freq: Optional[torch.Tensor],
-                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       out: Optional[torch.Tensor] = None, check_ids: bool = True) -> torch.Tensor:
         """x, sequence_tokens: (B,L) int64.  t_freq: (freq_dim,) f32 sinusoid of the sigma all samples share, (B, freq_dim) for
         one sigma per sample (esmdiff_forward_logits_sigmas), or None.
         Returns raw structure logits, a (B,L,4101) view of a (B,L,ld) float32 buffer."""
         B, L = x.shape
         x = self._tok(x, B, L)
         seq = self._tok(sequence_tokens, B, L)
-        self._check_ids(seq, x)
+        if check_ids:      # (a device -> host read-back: loops that feed the engine its own output skip it after the first call)
+            self._check_ids(seq, x)
         if out is None:
             out = torch.empty(B, L, self.ld_logits, dtype=torch.float32, device=self.device)
         tf = None if t_freq is None else t_freq.to(device=self.device, dtype=torch.float32).contiguous()
@@ -207,14 +208,19 @@ class Engine:
                                                      _stream()))
         return x
 
-    def sample_step_params(self, sample_index, mc_t, mc_s, step, final) -> torch.Tensor:
-        """Host sequences (one entry per sample) -> the device array of esmdiff_sample_step records ddpm_step_rows takes."""
+    @staticmethod
+    def sample_step_params_host(sample_index, mc_t, mc_s, step, final):
+        """Host sequences (one entry per sample) -> the esmdiff_sample_step records as a uint8 numpy array (n, 24)."""
         import numpy as np
         n = len(sample_index)
         rec = np.zeros(n, dtype=N.SAMPLE_STEP_DTYPE)
         rec["sample_index"], rec["step"], rec["final"] = sample_index, step, final
         rec["move_chance_t"], rec["move_chance_s"] = mc_t, mc_s
-        return torch.from_numpy(rec.view(np.uint8).reshape(n, -1)).to(self.device, non_blocking=True)
+        return rec.view(np.uint8).reshape(n, -1)
+
+    def sample_step_params(self, sample_index, mc_t, mc_s, step, final) -> torch.Tensor:
+        """... as the device array ddpm_step_rows takes."""
+        return torch.from_numpy(self.sample_step_params_host(sample_index, mc_t, mc_s, step, final)).to(self.device)
 
     def ddpm_step_rows(self, x: torch.Tensor, logits: torch.Tensor, params: torch.Tensor, *, seed: int,
                        eps: Optional[float] = None, flags: Optional[torch.Tensor] = None,
@@ -350,6 +356,21 @@ class Engine:
         ids = [int(v) for v in invalid_ids]
         arr = (ctypes.c_int32 * max(1, len(ids)))(*ids)
         self._chk(self._lib.esmdiff_set_gibbs_options(self._h, 1 if strategy == "random" else 0, arr if ids else None, len(ids)))
+
+    def set_streams(self, n_streams: int, min_tokens: Optional[int] = None) -> None:
+        """Sub-batch launch queues of the 16-bit forward (esmdiff_set_option: 1 .. 4, default 2) and the token count from which a
+        batch is cut into sub-batches (default 2200).  No result bit depends on either (test_stream_counts_bit_identical)."""
+        self._chk(self._lib.esmdiff_set_option(self._h, N.OPT_STREAMS, int(n_streams)))
+        if min_tokens is not None:
+            self._chk(self._lib.esmdiff_set_option(self._h, N.OPT_DUAL_MIN_TOKENS, int(min_tokens)))
+
+    def describe_plan(self, B: int, L: int) -> str:
+        """How a (B, L) forward will be dispatched on this engine, as text (esmdiff_describe_plan)."""
+        buf = ctypes.create_string_buffer(2048)
+        n = self._lib.esmdiff_describe_plan(self._h, int(B), int(L), buf, 2048)
+        if n < 0:
+            self._chk(n)
+        return buf.value.decode()
 
     def set_step0_sharing(self, on: bool) -> None:
         """Exact step-0 sharing (esmdiff_set_step0_sharing): when every sample of a ddpm_sample / gibbs_sample call starts

@@ -202,6 +202,12 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
         coords, plddt, ptm = decode_shard_and_gather(local[:, 1:-1], decoder, num_samples, return_ptm=True)
     if rank == 0:
         print(f"Sampling token time: {sample_t:.2f}s")
+        eng_ = getattr(model, "fast", None) or getattr(model, "net", None)
+        if hasattr(eng_, "describe_plan"):       # what produced these ids: the library build and the dispatch plan of the last batch
+            from . import _native
+            print(f"Engine: {_native.build_info()}")
+            if outs:
+                print(f"Plan:   {eng_.describe_plan(int(outs[-1].shape[0]), int(local.shape[1]))}")
         output_dir.mkdir(parents=True, exist_ok=True)
         np.save(save_to, tokens.cpu().numpy().astype(np.int16))
         (output_dir / f"{sample_basename}.json").write_text(json.dumps(

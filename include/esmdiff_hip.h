@@ -119,6 +119,26 @@ typedef struct esmdiff_engine esmdiff_engine;
 
 int esmdiff_abi_version(void);
 
+/* What this library is and how an engine will run a batch — for logs (the CLI prints both beside "Sampling token time").
+ * The product library reads NO ESMDIFF_* environment variable (one exception: it refuses to create an engine while
+ * ESMDIFF_DEBUG_SKIP is set); the tuning switches of the A/B experiments exist in -DED_DEBUG builds only, and
+ * esmdiff_get_build_info says which kind this is.  Both write a NUL-terminated text into buf [host, cap bytes] and return
+ * the length the full text needs (excluding the NUL), or < 0.
+ *   esmdiff_get_build_info   "abi=7 arch=gfx950 debug_env=0 ..."
+ *   esmdiff_describe_plan    the dispatch plan of a (B, L) forward on this engine: precision, head precision, number of
+ *                            sub-batch streams and their sizes, regular / small-batch path, the GEMM kernel of each block
+ *                            linear, the exact shortcuts that are on. */
+int esmdiff_get_build_info(char* buf, int32_t cap);
+int esmdiff_describe_plan(const esmdiff_engine* eng, int32_t B, int32_t L, char* buf, int32_t cap);
+
+/* Explicit dispatch options (ABI 7) — what used to be environment switches and may legitimately be chosen by a caller.  Neither
+ * changes a result bit (tests/test_gpu_kernels.py::test_stream_counts_bit_identical): on the regular path a row's K order
+ * depends on (N, K) only, and sub-batches of one forward always take the same path.
+ *   ESMDIFF_OPT_STREAMS           sub-batch launch queues of the 16-bit forward: 1 .. 4 (default 2)
+ *   ESMDIFF_OPT_DUAL_MIN_TOKENS   batches of at least this many tokens are cut into sub-batches (default 2200) */
+typedef enum { ESMDIFF_OPT_STREAMS = 1, ESMDIFF_OPT_DUAL_MIN_TOKENS = 2 } esmdiff_option;
+int esmdiff_set_option(esmdiff_engine* eng, int32_t option, int64_t value);
+
 /* Replaces load_state_dict_from_lightning_ckpt (checkpoint_utils.py:41-74) + hydra instantiate
  * of mdlm.yaml:26-58: builds bf16 device copies (SwiGLU rows interleaved, head padded) of the
  * weights in `table` [host array of n entries] on `device` and allocates the workspace.

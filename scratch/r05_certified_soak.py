@@ -17,7 +17,7 @@ exact = Engine(cfg, sd, max_batch=B, max_len=L, precision="f32_split")
 fast = Engine(cfg, sd, max_batch=B, max_len=L, precision="f16", head_precision="f32")
 cs = CertifiedSampler(fast, exact)
 bad, tot, t_cert = 0, {}, 0.0
-print("seed ids_equal seconds flagged corrections audit_checked audit_mismatches eps_violations eps_used max_pair_err")
+print("seed ids_equal seconds gpu_fast gpu_verify tail fast_launches flagged corrections audit_checked audit_mismatches eps_violations eps_used max_pair_err")
 for k in range(n_seeds):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     got = cs.ddpm_sample(seq, sch, seed=100 + k)
@@ -33,7 +33,7 @@ for k in range(n_seeds):
         tot[key] = tot.get(key, 0) + st[key]
     tot["audit_max_logit_err"] = max(tot.get("audit_max_logit_err", 0.0), st["audit_max_logit_err"])
     tot["audit_max_pair_err"] = max(tot.get("audit_max_pair_err", 0.0), st["audit_max_pair_err"])
-    print(100 + k, ok, round(dt, 3), st["flagged"], st["corrections"], st["audit_checked"], st["audit_mismatches"], st["eps_violations"],
+    print(100 + k, ok, round(dt, 3), st.get("gpu_seconds_fast"), st.get("gpu_seconds_verify"), st["tail_seconds"], st["fast_launches"], st["flagged"], st["corrections"], st["audit_checked"], st["audit_mismatches"], st["eps_violations"],
           f"{st['eps_max_used']:.3e}", f"{st['max_pair_err_observed']:.3e}", flush=True)
 print(f"certified soak: {n_seeds} seeds x {B} samples, mismatching runs: {bad}; totals {tot}")
 N5 = 5 * B

@@ -47,7 +47,7 @@ class _Net:
         h = np.tanh(emb + ctx + cond)
         return (h @ self.proj * self.scale / 8.0).astype(np.float32)
 
-    def forward_logits(self, x, seq, tf, out=None):
+    def forward_logits(self, x, seq, tf, out=None, check_ids=True):
         lg = self._clean(x, seq, tf)
         if self.noise:
             self.calls += 1
@@ -67,13 +67,12 @@ class _Net:
         x.copy_(torch.from_numpy(new))
         return x
 
+    def sample_step_params_host(self, sample_index, mc_t, mc_s, step, final):
+        from esmdiff_amd.engine import Engine
+        return Engine.sample_step_params_host(sample_index, mc_t, mc_s, step, final)
+
     def sample_step_params(self, sample_index, mc_t, mc_s, step, final):
-        from esmdiff_amd import _native as N
-        n = len(sample_index)
-        rec = np.zeros(n, dtype=N.SAMPLE_STEP_DTYPE)
-        rec["sample_index"], rec["step"], rec["final"] = sample_index, step, final
-        rec["move_chance_t"], rec["move_chance_s"] = mc_t, mc_s
-        return torch.from_numpy(rec.view(np.uint8).reshape(n, -1))
+        return torch.from_numpy(self.sample_step_params_host(sample_index, mc_t, mc_s, step, final))
 
     def ddpm_step_rows(self, x, lg, params, *, seed, eps=None, flags=None, gaps=None):
         """esmdiff_ddpm_step_rows restated: per sample the oracle's float32 step with that sample's own scalars; the runner-up

@@ -627,10 +627,9 @@ def test_forward_with_coordinates_vs_oracle(monkeypatch):
         ref = net(structure_tokens=x, sequence_tokens=seq, structure_coords=xyz).structure_logits
         ref0 = net(structure_tokens=x, sequence_tokens=seq).structure_logits
     assert float((ref - ref0).abs().max()) > 5e-2
-    for streams in ("1", "2"):
-        monkeypatch.setenv("ESMDIFF_DUAL_STREAM", streams)
-        monkeypatch.setenv("ESMDIFF_DUAL_STREAM_MIN_TOKENS", "1")
+    for streams in (1, 2):
         eng = Engine(TINY, sd, max_batch=B, max_len=L)
+        eng.set_streams(streams, min_tokens=1)
         base = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu().clone()
         eng.set_frames(*build_affine3d_from_coordinates(xyz))
         got = eng.forward_logits(x.cuda(), seq.cuda(), None).float().cpu().clone()
@@ -771,10 +770,10 @@ def test_two_stream_forward_is_bitwise_identical(tiny, monkeypatch):
     x = x.cuda()
     sch = ddpm_schedule(6)
     outs = []
-    for dual in ("1", "2", "3"):
-        monkeypatch.setenv("ESMDIFF_DUAL_STREAM", dual)
-        monkeypatch.setenv("ESMDIFF_DUAL_STREAM_MIN_TOKENS", "1")
+    for dual in (1, 2, 3):
         eng = Engine(cfg, sd, max_batch=B, max_len=L)
+        eng.set_streams(dual, min_tokens=1)
+        assert f"streams={dual}" in eng.describe_plan(B, L)
         lg = eng.forward_logits(x, seq, sch.t_freq[2]).clone()
         ids = eng.ddpm_sample(seq, sch, seed=5, sample_offset=0).clone()
         torch.cuda.synchronize()

@@ -86,6 +86,25 @@ def test_no_silent_cpu_fallback():
         gemm_bf16(torch.zeros(2, 64, dtype=torch.bfloat16), torch.zeros(128, 64, dtype=torch.bfloat16), 0)
 
 
+def test_product_library_reads_no_tuning_environment():
+    """every ESMDIFF_* switch that can change a dispatch path (and with it the last bits of the logits) lives
+    behind -DED_DEBUG; the product library's strings hold no ESMDIFF_* name except the C enum constants that appear in mangled
+    template names / messages and ESMDIFF_DEBUG_SKIP, which it reads only to REFUSE to create an engine.  Callers choose the
+    legitimate knobs through esmdiff_set_option, and esmdiff_get_build_info says which kind of build this is."""
+    import re
+    import subprocess
+    from esmdiff_amd import _native as N
+    out = subprocess.run(["strings", str(N.lib_path())], capture_output=True, text=True, check=True).stdout
+    names = set(re.findall(r"ESMDIFF_[A-Z0-9_]+", out))
+    enum_like = re.compile(r"ESMDIFF_(EPI|F32EPI|PRECISION|OPT|E|F32|BF16|OK|ABI|VOCAB|MASK|STRUCT)_?[A-Z0-9_]*$")
+    stray = {n for n in names if not enum_like.match(n)} - {"ESMDIFF_DEBUG_SKIP", "ESMDIFF_"}
+    assert not stray, f"the product library mentions environment switches: {sorted(stray)}"
+    info = N.build_info()
+    assert "abi=7" in info and "arch=gfx950" in info and "debug_env=0" in info, info
+    for sym in ("esmdiff_set_option", "esmdiff_describe_plan", "esmdiff_get_build_info"):
+        assert hasattr(N.lib(), sym)
+
+
 def test_hand_placed_gemm_has_no_sgpr_reload_hazard():
     """tools/check_asm_hazards.py on the hand-placed GEMM (csrc/gemm256w4.hip), both operand-type builds: hipcc may reload a
     spilled SGPR with v_readlane directly in front of an inline-asm LDS-DMA that uses it as scalar base — a VALU-writes-SGPR ->
