@@ -28,16 +28,19 @@ What happens to a sample with a close call (r05: speculative, batched, audited).
               raises eps.  stats carries audit_checked / audit_mismatches / audit_max_logit_err / audit_max_pair_err.
 
 `eps` (eps=None, the default) is chosen from the error DISTRIBUTION, not from a maximum: every verified item yields both
-engines' logits for the same input, esmdiff_logit_error_stats reduces them per sample-update to the r.m.s. and the maximum of the
-logit error e_v and of the pair error d_v = e_v - e_(v+1) over the masked rows (4 099 pairs per row).  The pair bound in use is
+engines' logits for the same input, esmdiff_logit_error_stats reduces them per token row to the r.m.s. and the maximum of the
+logit error e_v and of the pair error d_v = e_v - e_(v+1) (4 099 pairs per masked row).  Within one row the errors are the
+projections of ONE hidden-state error onto 4 101 head rows — Gaussian-like with a scale that belongs to the row — so the
+statistic is the per-row r.m.s., and the bound takes the largest one seen (a pooled r.m.s. is a scale mixture: on weights with
+trained statistics its tail reached 7 sigma, per row it stays at 5-5.5).  The pair bound in use is
 
-    P = max(k_sigma * (largest per-item r.m.s. of d seen so far), max_factor * (largest |d| seen so far)),   eps = P / 2
+    P = max(k_sigma * (largest per-row r.m.s. of d seen so far), max_factor * (largest |d| seen so far)),   eps = P / 2
 
 Measured at configs[1] (f16 body + f32-grade head against F32_SPLIT): sigma_d = 3.1e-4, the largest |d| of ~1e6 pairs per item
-sits at 5.3-5.7 sigma, as a Gaussian's does.  With k_sigma = 6.5 and Gaussian pair errors a draw whose gap is just outside the
-flagged band flips with probability 2 Q(6.5) = 8e-11; integrated over the gap density rho (0.13 per unit log gap and masked row,
-measured: stats["rerun_share_vs_eps"]) the miss probability is 4 rho sigma_d phi(k) / k^2 ~ 1e-15 per draw, ~4e-10 per
-100-sample job of 335 000 draws — and the audit watches the assumption.  (r04 used 2 x the largest |e| = ~16 sigma_d: 2.5x the
+sits at 5.3-5.7 sigma, as a Gaussian's does.  With k_sigma = 6 on the LARGEST row sigma (3.6e-4; the typical row's is 15 % smaller)
+and Gaussian pair errors a draw whose gap is just outside the flagged band flips with probability <= 2 Q(6) = 2e-9; integrated
+over the gap density rho (0.13 per unit log gap and masked row, measured: stats["rerun_share_vs_eps"]) the miss probability is
+<= 4 rho sigma_d phi(k) / k^2 ~ 3e-14 per draw, ~1e-8 per 100-sample job of 335 000 draws — and the audit watches the assumption.  (r04 used 2 x the largest |e| = ~16 sigma_d: 2.5x the
 re-runs for no measurable gain in safety; its rule is still available as a fixed `eps`.)  Until `n_boot` items have been seen the bound is
 widened by `boot_factor` and at least two samples per update are audited; the very first call starts from a probe of two samples
 on both engines.  A verified item whose largest |d| exceeds the P its update was certified with is an `eps_violation`; it raises
@@ -86,7 +89,7 @@ class CertifiedSampler:
     """fast: a reduced-precision Engine (f16 with the f32-grade head recommended: its logit error is 8x below bf16's, so 8x
     fewer close calls); exact: an f32-grade Engine of the same checkpoint (precision 'f32_split' or 'f32')."""
 
-    def __init__(self, fast: Engine, exact: Engine, eps: Optional[float] = None, *, k_sigma: float = 6.5,
+    def __init__(self, fast: Engine, exact: Engine, eps: Optional[float] = None, *, k_sigma: float = 6.0,
                  max_factor: float = 1.05, eps_floor: float = 1e-5, audit_rate: float = 0.02, verify_batch: int = 32,
                  n_boot: int = 8, boot_factor: float = 1.5, audit_seed: int = 0):
         if fast.device != exact.device:
@@ -106,7 +109,8 @@ class CertifiedSampler:
         self.n_boot, self.boot_factor = int(n_boot), float(boot_factor)
         self._audit_rng = np.random.default_rng(audit_seed)
         # running error estimate of this engine pair (all calls): per-item r.m.s. and maxima
-        self.sigma_d_seen = 0.0      # largest per-item r.m.s. of the pair error d
+        self.sigma_d_seen = 0.0      # largest per-ROW r.m.s. of the pair error d (what k_sigma multiplies)
+        self.sigma_d_item_seen = 0.0 # largest per-item (sample-update) r.m.s. of d, for the reports
         self.sigma_e_seen = 0.0      # largest per-item r.m.s. of the logit error e
         self.max_d_seen = 0.0
         self.err_seen = 0.0          # largest |e| (r04's statistic, kept for the reports)
@@ -128,21 +132,23 @@ class CertifiedSampler:
         return 0.5 * self.pair_bound()
 
     def _observe_items(self, st: np.ndarray, V: int) -> None:
-        """st (n, 5): per item max |e|, sum e^2, max |d|, sum d^2, masked rows."""
-        for me, se, md, sd, rows in st:
+        """st (n, 6): per item max |e|, sum e^2, max |d|, sum d^2, masked rows, largest per-row sum d^2."""
+        for me, se, md, sd, rows, sd_row in st:
             if rows <= 0:
                 continue
             self.n_seen += 1
             self.err_seen = max(self.err_seen, float(me))
             self.max_d_seen = max(self.max_d_seen, float(md))
             self.sigma_e_seen = max(self.sigma_e_seen, math.sqrt(float(se) / (rows * (V - 1))))
-            self.sigma_d_seen = max(self.sigma_d_seen, math.sqrt(float(sd) / (rows * (V - 2))))
+            self.sigma_d_item_seen = max(self.sigma_d_item_seen, math.sqrt(float(sd) / (rows * (V - 2))))
+            self.sigma_d_seen = max(self.sigma_d_seen, math.sqrt(float(sd_row) / (V - 2)))
 
     def _item_stats(self, lg_fast: torch.Tensor, lg_exact: torch.Tensor, x_in: torch.Tensor) -> torch.Tensor:
-        """(n, 5) on the device: max |e|, sum e^2, max |d|, sum d^2, masked rows — per sample over its masked rows."""
+        """(n, 6) on the device: max |e|, sum e^2, max |d|, sum d^2, masked rows, largest per-row sum d^2 — per sample over its
+        masked rows."""
         st = self.exact.logit_error_stats(lg_fast, lg_exact, x_in)
         rows = (x_in == STRUCTURE_MASK_TOKEN).sum(1).to(torch.float32)
-        return torch.stack([st[..., 0].amax(1), st[..., 1].sum(1), st[..., 2].amax(1), st[..., 3].sum(1), rows], 1)
+        return torch.stack([st[..., 0].amax(1), st[..., 1].sum(1), st[..., 2].amax(1), st[..., 3].sum(1), rows, st[..., 3].amax(1)], 1)
 
     # ---- the loop ---------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -357,9 +363,9 @@ class CertifiedSampler:
 
         def process_verify(rec) -> None:
             res = rec["back"].get()
-            self._observe_items(res[:, :5], V)
+            self._observe_items(res[:, :6], V)
             for j, it in enumerate(rec["items"]):
-                me, md, neq, hm = float(res[j, 0]), float(res[j, 2]), res[j, 5] > 0, res[j, 6] > 0
+                me, md, neq, hm = float(res[j, 0]), float(res[j, 2]), res[j, 6] > 0, res[j, 7] > 0
                 st["max_logit_err_observed"] = max(st["max_logit_err_observed"], me)
                 st["max_pair_err_observed"] = max(st["max_pair_err_observed"], md)
                 audit = it["kind"] == "audit"
@@ -424,7 +430,7 @@ class CertifiedSampler:
             "eps": self.eps if self.eps is not None else "auto", "k_sigma": self.k_sigma, "max_factor": self.max_factor,
             "audit_rate": self.audit_rate, "verify_batch": self.verify_batch,
             "eps_min_used": min(used) if used else None, "eps_max_used": max(used) if used else None,
-            "sigma_pair_err": self.sigma_d_seen, "sigma_logit_err": self.sigma_e_seen, "max_pair_err_all_calls": self.max_d_seen,
+            "sigma_pair_err": self.sigma_d_seen, "sigma_pair_err_per_item": self.sigma_d_item_seen, "sigma_logit_err": self.sigma_e_seen, "max_pair_err_all_calls": self.max_d_seen,
             "max_logit_err_all_calls": self.err_seen, "items_seen_all_calls": self.n_seen, "first_update_shared": shared0,
             # share of sample-updates whose smallest gap is within 2 * (m * eps): what a bound of m x the eps in use would re-run
             "rerun_share_vs_eps": {str(m): round(float((gl <= m).sum()) / n_upd, 5) for m in _GAP_GRID},

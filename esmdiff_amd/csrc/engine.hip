@@ -51,7 +51,7 @@ struct Layer {
   // ... and the power-of-two operand scales of the split attention (attention_split.hip), from rigorous bounds at create
   float att_qk = 1.f, att_v = 1.f;
   // ... and of the FFN mid row written by the fused SwiGLU epilogue of the split FFN-up (0: unfused, per-row scales)
-  float mid_scale = 0.f;
+  bool up_fused = false;   // F32_SPLIT: FFN-up weight rows interleaved gate / up, SwiGLU in the GEMM's epilogue
 };
 
 }  // namespace
@@ -455,16 +455,17 @@ static int strict_part(esmdiff_engine* e, const SPart& w, const float* cond, int
     }
     if (sp) RUN(S_LN, launch_layernorm_split(w.x, ly.ln2_w, ly.ln2_b, a2, rs, nullptr, M, D, 0, st));
     else RUN(S_LN, launch_layernorm_f32(w.x, ly.ln2_w, ly.ln2_b, w.fh, M, D, st));
-    if (sp && ly.mid_scale > 0.f) {
-      // split FFN-up with the SwiGLU in its epilogue: reads the LayerNorm's split row (a2: [M, 3 D]) and writes the mid row as
-      // the next split row (w.a2b: [M, 3 FH], one scale per layer) — then FFN-down with that constant folded into its weight scale
-      RUN(S_FFN_UP, launch_gemm256w4_split(a2, rs, ly.s_up.w, ly.s_up.inv, reinterpret_cast<float*>(w.a2b), nullptr, M, 2 * FH, D, 3 * FH,
-                                           ly.mid_scale, 4, st));
+    if (sp && ly.up_fused) {
+      // split FFN-up with the SwiGLU in its epilogue: reads the LayerNorm's split row (a2: [M, 3 D]), writes mid as f32 [M, FH];
+      // split_rows then makes the FFN-down operand with every row's own power-of-two scale (r05: not a per-layer bound, see
+      // gemm256w4.hip) — [M, 2 FH] of gate / up values never exist in memory
+      RUN(S_FFN_UP, launch_gemm256w4_split(a2, rs, ly.s_up.w, ly.s_up.inv, w.fmid, nullptr, M, 2 * FH, D, FH, 1.f, 4, st));
+      RUN(S_FFN_UP, launch_split_rows(w.fmid, FH, a2, rs, M, FH, st));
       if (sk) {
-        RUN(S_FFN_DOWN, launch_gemm256w4_splitk(w.a2b, ly.s_down.w, ly.s_down.inv / ly.mid_scale, skp, M, D, FH, 4, st));
-        RUN(S_FFN_DOWN, launch_splitk_reduce_resid(skp, nullptr, w.x, M, D, 4, c.residue_scale, st));
+        RUN(S_FFN_DOWN, launch_gemm256w4_splitk(a2, ly.s_down.w, ly.s_down.inv, skp, M, D, FH, 4, st));
+        RUN(S_FFN_DOWN, launch_splitk_reduce_resid(skp, rs, w.x, M, D, 4, c.residue_scale, st));
       } else {
-        RUN(S_FFN_DOWN, launch_gemm256w4_split(w.a2b, nullptr, ly.s_down.w, ly.s_down.inv / ly.mid_scale, w.x, nullptr, M, D, FH, D,
+        RUN(S_FFN_DOWN, launch_gemm256w4_split(a2, rs, ly.s_down.w, ly.s_down.inv, w.x, nullptr, M, D, FH, D,
                                                c.residue_scale, ESMDIFF_F32EPI_RESID_DIV, st));
       }
     } else {
@@ -874,28 +875,12 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(load_f32(e, t, b + "ffn.0.weight", {D}, &ly.ln2_w));
     TRY(load_f32(e, t, b + "ffn.0.bias", {D}, &ly.ln2_b));
     if (split) {
-      // FFN-up with the SwiGLU fused into the split GEMM's epilogue (rows interleaved gate / up): the mid row is written with ONE
-      // power-of-two scale per layer, from |mid| = |silu(g) u| <= |g| |u| <= B^2, B = (sqrt(D) max|ln2 g| + |ln2 b|_2) max_row |W row|_2
+      // FFN-up with the SwiGLU fused into the split GEMM's epilogue (rows interleaved gate / up; mid leaves it as f32 and is split
+      // with its row's own scale, forward_strict)
       const bool fuse = FH % 32 == 0 && !ed_dbg_env("ESMDIFF_SPLIT_UNFUSED_SWIGLU");
       TRY(load_split(e, t, b + "ffn.1.weight", {2 * FH, D}, &ly.s_up, 0, fuse ? FH : 0));
       TRY(load_split(e, t, b + "ffn.3.weight", {D, FH}, &ly.s_down));
-      if (fuse) {
-        if (hipDeviceSynchronize() != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "weight conversion failed"));
-        std::vector<float> hg(D), hb(D);
-        hipMemcpy(hg.data(), ly.ln2_w, (size_t)D * 4, hipMemcpyDeviceToHost);
-        hipMemcpy(hb.data(), ly.ln2_b, (size_t)D * 4, hipMemcpyDeviceToHost);
-        float gmax = 0.f, b2 = 0.f, rn = 0.f;
-        for (int d = 0; d < D; ++d) {
-          gmax = std::max(gmax, fabsf(hg[d]));
-          b2 += hb[d] * hb[d];
-        }
-        const esmdiff_weight* wu;
-        TRY(need(e, t, b + "ffn.1.weight", {2 * FH, D}, &wu));
-        if (weight_rownorm_max(wu->data, wu->dtype, 0, 2 * FH, D, e->scratch_bits, &rn) != hipSuccess)
-          return bail(fail(e, ESMDIFF_E_HIP, "row-norm reduction of the FFN-up weight failed"));
-        const float Bg = (sqrtf((float)D) * gmax + sqrtf(b2)) * rn, B2 = Bg * Bg;
-        ly.mid_scale = (B2 > 0.f && std::isfinite(B2)) ? exp2f(floorf(log2f(30000.f / B2))) : 1.f;
-      }
+      ly.up_fused = fuse;
     } else if (strict) {
       TRY(load_f32(e, t, b + "ffn.1.weight", {2 * FH, D}, &ly.fw_up));
       TRY(load_f32(e, t, b + "ffn.3.weight", {D, FH}, &ly.fw_down));

@@ -16,7 +16,7 @@ B.build()
 obj = B.OBJDIR / f"{unit}_{tag}.o"
 cmd = [B._hipcc(), *B.COMMON, *B.UNITS[unit], *flags, "-c", str(B.CSRC / f"{unit}.hip"), "-o", str(obj)]
 subprocess.run(cmd, check=True)
-objs = [str(obj if n == unit else B.OBJDIR / f"{n}.o") for n in B.UNITS]
+objs = [str(obj if n == unit else B.OBJDIR / f"{n}.o") for n in B.UNITS] + [str(B.OBJDIR / f"{n}_f16.o") for n in B.F16_UNITS]
 out = B.LIBDIR / f"libesmdiff_hip_{tag}.so"
 subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(out)], check=True)
 print(out)
