@@ -148,6 +148,9 @@ class MaskedDiffusionLanguageModeling:
         sigma_s = self.noise(t - dt)[0].squeeze(-1)
         mc_t, mc_s = 1 - torch.exp(-sigma_t), 1 - torch.exp(-sigma_s)
         shared = bool((t == t[0]).all())
+        if t_freq is not None and not shared and torch.as_tensor(t_freq).dim() != 2:
+            # one conditioning row for samples at different noise levels: the network would see one sigma, the draws another
+            raise ValueError("_ddpm_update: t differs between samples, so t_freq must hold one row per sample (B, freq_dim) or be None")
         if t_freq is None:
             tf = self.net.conditioning_rows(timestep_embedding(sigma_t[:1] if shared else sigma_t, self.cfg.freq_dim))
             t_freq = None if tf is None else (tf[0] if shared else tf)

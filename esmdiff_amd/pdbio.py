@@ -143,6 +143,12 @@ def merge_pdbfiles(input, save_to: Path, verbose: bool = True) -> None:
         print(f"Merged {len(pdb_files)} PDB files into {save_to} with {n_model} models.")
 
 
+# residue names biotite's filter_amino_acids accepts that occur in practice: the 20 standard ones, SEC / PYL, the ambiguity codes
+# and the common modified L-peptide residues (the full list is the Chemical Component Dictionary's "L-peptide linking" class)
+_AMINO_ACID_RESNAMES = frozenset("""ALA ARG ASN ASP CYS GLN GLU GLY HIS ILE LEU LYS MET PHE PRO SER THR TRP TYR VAL SEC PYL ASX GLX UNK
+MSE HYP SEP TPO PTR CSO CSD CME CSX OCS KCX LLP MLY M3L MLZ ALY PCA NLE ABA AIB ORN DAL HIC HID HIE HIP CYX ASH GLH LYN""".split())
+
+
 def _backbone_coords_from_pdb(pdb_path, target_atoms=("N", "CA", "C")) -> np.ndarray:
     """models/utils.py:240-267 without biotite: the backbone atoms named in `target_atoms` of every MODEL of a PDB file (a file
     without MODEL records is one model) -> (n_models, L, len(target_atoms), 3), or (n_models, L, 3) for a single atom name.
@@ -160,12 +166,22 @@ def _backbone_coords_from_pdb(pdb_path, target_atoms=("N", "CA", "C")) -> np.nda
             for c in cur:
                 c.clear()
 
+    # biotite's reader as the reference uses it (models/utils.py:240-249: PDBFile.get_structure() -> struct.filter_backbone): N / CA /
+    # C atoms of AMINO-ACID residues, ATOM and HETATM records alike (selenomethionine and other modified residues are HETATM),
+    # nothing of ligands, waters or nucleic acids; of alternate locations the first one seen in each residue (altloc="first").
+    first_alt = {}
     with open(pdb_path) as fh:
         for line in fh:
             name = line[:6].strip()
             if name in ("MODEL", "ENDMDL"):
                 close()
-            elif name == "ATOM" and line[16] in (" ", "A"):
+                first_alt.clear()
+            elif name in ("ATOM", "HETATM") and len(line) >= 54 and line[17:20].strip() in _AMINO_ACID_RESNAMES:
+                alt = line[16]
+                if alt != " ":
+                    res = (line[21], line[22:27])                      # chain, residue number + insertion code
+                    if first_alt.setdefault(res, alt) != alt:
+                        continue
                 j = want.get(line[12:16].strip())
                 if j is not None:
                     cur[j].append((float(line[30:38]), float(line[38:46]), float(line[46:54])))

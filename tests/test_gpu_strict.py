@@ -341,8 +341,10 @@ def test_bf16_trajectory_agreement_configs1_shape(full48):
         assert rec[name]["final_agreement"] == 1.0, rec[name]
         assert rec[name]["max_abs_logit_err_teacher_forced"] < 5e-5, rec[name]
     # the throughput path: logits within the bf16 bar at every step of the trajectory, flips rare per step
-    assert rec["bf16"]["max_abs_logit_err_teacher_forced"] < 0.04, rec["bf16"]
-    assert rec["bf16"]["teacher_forced_flips_total"] <= 0.02 * rec["bf16"]["draws_total"], rec["bf16"]
+    # (r05, VERDICT r04 item 9: bars at ~2x the measured values — 0.013 logit error, 1.4e-4 flips per draw; with 13 416 draws here
+    #  that is ~2 expected flips, so the count bar is 3e-4 x draws + a Poisson allowance of 6)
+    assert rec["bf16"]["max_abs_logit_err_teacher_forced"] < 0.03, rec["bf16"]
+    assert rec["bf16"]["teacher_forced_flips_total"] <= 3e-4 * rec["bf16"]["draws_total"] + 6, rec["bf16"]
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -660,7 +662,7 @@ def test_strict_forward_ragged_shapes(B, L, precision):
     err = float((got - ref).abs().max())
     out = eng.ddpm_sample(seq.cuda(), sch, seed=1).cpu()
     eng.close()
-    assert err < {"f16": 0.01, "bf16": 0.08}.get(precision, 5e-5), (precision, err)
+    assert err < {"f16": 0.0045, "bf16": 0.03}.get(precision, 5e-5), (precision, err)     # r05: ~2x measured
     assert out.shape == (B, L) and int((out == MASK).sum()) == 0
 
 
@@ -738,7 +740,7 @@ def test_bf16_vs_float32_chain_configs1_full_batch():
     # f16 operands: 1/8 of the operand rounding -> an order of magnitude fewer flips than bf16 (VERDICT r03's bar for the headline
     # path was <= 5e-5 per draw and >= 85 / 100 samples identical; bf16 with the float32 head alone reaches 1.0e-4 / 73)
     assert out["f16"]["flip_rate_per_masked_draw"] <= 5e-5 and out["f16"]["samples_fully_identical"] >= 85, out["f16"]
-    assert out["f16_f32head"]["flip_rate_per_masked_draw"] <= 5e-5 and out["f16_f32head"]["samples_fully_identical"] >= 85, out["f16_f32head"]
+    assert out["f16_f32head"]["flip_rate_per_masked_draw"] <= 5e-5 and out["f16_f32head"]["samples_fully_identical"] >= 90, out["f16_f32head"]   # measured 94
     # F32_SPLIT: float32-grade arithmetic end to end
     assert out["f32_split"]["flip_rate_per_masked_draw"] < 1e-5 and out["f32_split"]["samples_fully_identical"] >= 97, out["f32_split"]
 
@@ -832,6 +834,13 @@ def test_ddpm_update_method_and_per_sample_t():
     assert torch.equal(got[:, 5:20], x0[:, 5:20]) and int((got == MASK).sum()) < int((x0 == MASK).sum())
     with pytest.raises(ValueError, match="uniforms"):
         model._ddpm_update(x0.clone(), t, seq, dt)
+    # a single conditioning row with samples at different noise levels would condition the network on one sigma and draw with
+    # another: refused; one row per sample is what the call computes itself
+    from esmdiff_amd.schedule import timestep_embedding
+    with pytest.raises(ValueError, match="one row per sample"):
+        model._ddpm_update(x0.clone(), t, seq, dt, seed=3, t_freq=timestep_embedding(torch.tensor([1.0]), TINY.freq_dim)[0])
+    rows = timestep_embedding(model.noise(t)[0].squeeze(-1), TINY.freq_dim)
+    assert torch.equal(model._ddpm_update(x0.clone(), t, seq, dt, seed=3, sample_offset=20, step=2, t_freq=rows).cpu(), got)
     model.net.close()
 
 

@@ -117,6 +117,41 @@ def test_load_coords_reads_back_what_the_cli_writes(tmp_path):
         load_coords(tmp_path / "bad.pdb", verbose=False)
 
 
+def test_load_coords_filters_like_biotite(tmp_path):
+    """The reference reads ensembles with biotite (models/utils.py:240-249: get_structure -> filter_backbone): backbone atoms of
+    AMINO ACIDS only — HETATM selenomethionine counts, ligand / water / nucleotide atoms named N / CA / C do not — the first
+    alternate location seen per residue, and a short or ragged ATOM line is not an IndexError."""
+    from esmdiff_amd.pdbio import load_coords
+
+    def atom(rec, serial, name, alt, res, chain, num, x):
+        return f"{rec:<6}{serial:>5} {name:<4}{alt}{res:>3} {chain}{num:>4}    {x:8.3f}{0.0:8.3f}{0.0:8.3f}  1.00  0.00\n"
+
+    lines = ["MODEL        1\n"]
+    k = 0
+    for num, (rec, res) in enumerate([("ATOM", "ALA"), ("HETATM", "MSE"), ("ATOM", "GLY")], start=1):
+        for nm in ("N", "CA", "C", "O"):
+            k += 1
+            lines.append(atom(rec, k, nm, " ", res, "A", num, float(k)))
+    # residue 4: altlocs B first, then A -> the B atoms are the ones kept
+    for alt, base in (("B", 100.0), ("A", 200.0)):
+        for j, nm in enumerate(("N", "CA", "C")):
+            k += 1
+            lines.append(atom("ATOM", k, nm, alt, "SER", "A", 4, base + j))
+    lines.append(atom("HETATM", 90, "CA", " ", " CA", "A", 201, 555.0))      # a calcium ion
+    lines.append(atom("HETATM", 91, "N", " ", "HOH", "A", 301, 666.0))
+    lines.append(atom("ATOM", 92, "C", " ", " DA", "B", 1, 777.0))           # a nucleotide
+    lines.append("ATOM     93  CA  ALA A   9\n")                             # truncated record
+    lines.append("ENDMDL\nEND\n")
+    p = tmp_path / "mixed.pdb"
+    p.write_text("".join(lines))
+    full = load_coords(p, ca_only=False, verbose=False)
+    assert full.shape == (1, 4, 3, 3)
+    assert np.allclose(full[0, :3, :, 0], [[1, 2, 3], [5, 6, 7], [9, 10, 11]])
+    assert np.allclose(full[0, 3, :, 0], [100, 101, 102])
+    ca = load_coords(p, verbose=False)
+    assert ca.shape == (1, 4, 3) and np.allclose(ca[0, :, 0], [2, 6, 10, 101])
+
+
 def test_merge_pdbfiles_matches_reference_golden(golden_dir, tmp_path):
     from esmdiff_amd.pdbio import merge_pdbfiles
     g = json.loads((golden_dir / "g8_merge_pdb.json").read_text())
