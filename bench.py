@@ -259,16 +259,25 @@ def roofline_report(args, cfg, B, L, n_fwd_sample, prof_dom, prof):
                                         + 2 * cfg.ffn_hidden * cfg.d_model)
                         + 2 * cfg.d_model * cfg.d_model + 2 * cfg.d_model * cfg.n_structure_heads)
     n_fwd = n_fwd_sample                                        # the breakdown pass is one step
-    traffic, traffic_note = None, "no PMC pass on record"
-    for name in ("r03_gemm_traffic.json", "r02_gemm_traffic.json"):
-        tp = ROOT / "profiles" / name
-        if tp.exists() and not args.tiny:                       # separate rocprofv3 --pmc passes of this same kernel at this M
-            rec = json.loads(tp.read_text()).get("by_rows", {}).get(str(M // parts))
-            if rec:
-                traffic = rec["traffic_bytes_per_launch"]
-                traffic_note = f"profiles/{name}: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, fabric-level" + (
-                    "; " + rec["note"] if "note" in rec else "")
+    # roofline.traffic: the newest profiles/r*_gemm_traffic.json written by tools/pmc_traffic.py (separate rocprofv3 --pmc passes of
+    # this kernel at this M) — reported only while the kernel source it was measured on is the source of the library in use
+    traffic, traffic_note = None, "no PMC pass on record (tools/pmc_traffic.py measures it on the GPU box)"
+    if not args.tiny:
+        import hashlib
+        src_hash = hashlib.sha256((ROOT / "esmdiff_amd" / "csrc" / "gemm256w4.hip").read_bytes()).hexdigest()
+        for tp in sorted((ROOT / "profiles").glob("r*_gemm_traffic.json"), reverse=True):
+            doc = json.loads(tp.read_text())
+            rec = doc.get("by_rows", {}).get(str(M // parts))
+            if not rec:
+                continue
+            if doc.get("kernel_source_sha256") != src_hash:
+                traffic_note = (f"stale: profiles/{tp.name} was measured on another version of csrc/gemm256w4.hip "
+                                f"({str(doc.get('kernel_source_sha256'))[:12]} vs {src_hash[:12]} now); re-run tools/pmc_traffic.py")
                 break
+            traffic = rec["traffic_bytes_per_launch"]
+            traffic_note = (f"profiles/{tp.name} (tools/pmc_traffic.py; kernel source sha256 {src_hash[:12]} = the library's): "
+                            "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, fabric level, Infinity Cache hits included")
+            break
     passes = 3 if args.precision == "f32_split" else 1      # f32_split: three f16 MFMA products per split operand pair
     kname = {"bf16": "g4::gemm256w4_kernel<SWIGLU, 0>", "f16": "ed16::g4::gemm256w4_kernel<SWIGLU, 0>",
              "f32_split": "g4::gemm256w4_kernel<4, SPLIT> (fused SwiGLU, 3 f16 MFMA passes)", "f32": "gemm_f32_kernel<STORE>"}[args.precision]
@@ -353,6 +362,10 @@ def main():
     ap.add_argument("--head-precision", choices=["bf16", "f32"], default="bf16",
                     help="bf16 engine only: final LayerNorm + output head in float32 grade (esmdiff_config.head_precision)")
     ap.add_argument("--no-head-f32-leg", action="store_true", help="skip the second, labelled run with the float32-grade head")
+    ap.add_argument("--checkpoint-fanout", choices=["auto", "on", "off"], default="auto",
+                    help="load the weights the way a real run does: rank 0 writes the synthetic state dict to a file (untimed), then "
+                         "rank 0 READS it and every rank receives the tensors by one broadcast (esmdiff_amd.dist.broadcast_state_dict); "
+                         "per_rank reports load_s next to create_s.  auto: on under a launcher (N > 1 or --spawn), off otherwise")
     ap.add_argument("--alt-steps", type=int, default=5, help="timed steps of every labelled extra leg (alt_precisions, certified); >= 5")
     ap.add_argument("--spawn", action="store_true",
                     help="go through the launcher path (torch.distributed.run, process group, RCCL gather) even at --gpus 1: the "
@@ -402,6 +415,7 @@ def main():
     cfg = TINY if args.tiny else ESM3_OPEN
     B, L, T = args.samples_per_gpu, args.residues + 2, args.num_steps
     numa = pin_to_gpu_numa(None if stub else local_rank) if world > 1 else None   # host threads next to the rank's GPU
+    load_rec = None
     t_create = time.perf_counter()
     if stub:
         from tests.standin_engine import StandinEngine
@@ -410,9 +424,32 @@ def main():
     else:
         from esmdiff_amd.engine import Engine
         sd = random_init_state_dict(cfg, seed=args.seed, device=str(dev), with_geom=True)   # same weights on every rank (GPU generator)
+        fanout = args.checkpoint_fanout == "on" or (args.checkpoint_fanout == "auto" and launched)
+        if fanout:
+            # The start-up cost of a real run (SURVEY 8e names it THE scaling risk): the 5.5 GB float32 checkpoint of
+            # checkpoint_utils.py:59-73.  Rank 0 writes the synthetic weights in that file format (untimed), then the weights are
+            # loaded as the CLI loads them: one reader, one broadcast.
+            import tempfile
+            from esmdiff_amd.dist import broadcast_state_dict
+            from esmdiff_amd.weights import load_checkpoint_state_dict
+            ck = Path(tempfile.gettempdir()) / f"esmdiff_bench_ckpt_{os.environ.get('MASTER_PORT', 'solo')}_{cfg.n_layers}.pt"
+            if rank == 0:
+                torch.save({"module": {k: v.cpu() for k, v in sd.items()}}, ck)
+            del sd
+            if use_dist:
+                dist.barrier(device_ids=[local_rank])
+            torch.cuda.empty_cache()
+            t_create = time.perf_counter()
+            sd, load_rec = broadcast_state_dict(lambda: load_checkpoint_state_dict(ck), dev)
+            t_create2 = time.perf_counter()
+            if use_dist:
+                dist.barrier(device_ids=[local_rank])
+            if rank == 0:
+                ck.unlink(missing_ok=True)
+            t_create += time.perf_counter() - t_create2      # (the clean-up barrier is not part of create_s)
         eng = Engine(cfg, sd, max_batch=B, max_len=L, device=local_rank, precision=args.precision,
                      head_precision="f32" if args.head_precision == "f32" else None)
-    create_s = time.perf_counter() - t_create
+    create_s = time.perf_counter() - t_create - (load_rec["load_s"] if load_rec else 0.0)
     g = torch.Generator().manual_seed(args.seed)
     seq1 = torch.cat([torch.tensor([0]), torch.randint(4, 24, (args.residues,), generator=g), torch.tensor([2])])
     seq = seq1[None].repeat(B, 1).to(dev)
@@ -450,16 +487,35 @@ def main():
         ev.record()
         return ev
 
+    # samples/s = N / wall-time(tokenise -> final ids on HOST).  A timed step therefore starts from the residue
+    # STRING (tokenised on the host, sdk.encode_sequence, repeated over the batch and uploaded) and ends with the ids in pinned
+    # host memory (an asynchronous D2H copy on the launch stream; the synchronisation that closes the region waits for it).
+    seq_string = None
+    if not stub and not args.inpaint:
+        from esmdiff_amd import constants as C_
+        from esmdiff_amd.sdk import encode_sequence
+        seq_string = "".join(C_.SEQUENCE_VOCAB[int(i)] for i in seq1[1:-1])
+        assert torch.equal(encode_sequence(seq_string), seq1)
+    ids_host = None if stub else torch.empty(B * (world if use_dist else 1), L, dtype=torch.int16, pin_memory=True)
+
     def one_step(step_idx, engine=None, timed=False):
         e_ = eng if engine is None else engine
         m0 = mark() if timed else None
+        seq_ = seq
+        if timed and seq_string is not None:
+            seq_ = encode_sequence(seq_string)[None].repeat(B, 1).pin_memory().to(dev, non_blocking=True)
         if args.mode == "gibbs":
-            ids = e_.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=args.seed + step_idx, sample_offset=rank * B)
+            ids = e_.gibbs_sample(seq_, x0, table, 1.4, 0.9, seed=args.seed + step_idx, sample_offset=rank * B)
         else:
-            ids = e_.ddpm_sample(seq, sch, seed=args.seed + step_idx, sample_offset=rank * B, input_prior=prior)
+            ids = e_.ddpm_sample(seq_, sch, seed=args.seed + step_idx, sample_offset=rank * B, input_prior=prior)
         m1 = mark() if timed else None
         if use_dist:                                             # one exchange at the end: int16 ids over RCCL
             dist.all_gather(gathered, ids.to(torch.int16).view(torch.uint8))
+        if timed and ids_host is not None:                       # ... and the ids to the host
+            if use_dist:
+                ids_host.copy_(torch.cat(gathered, 0).view(torch.int16), non_blocking=True)
+            else:
+                ids_host.copy_(ids.to(torch.int16), non_blocking=True)
         if timed:
             phase_marks.append((m0, m1, mark()))
         return ids
@@ -496,7 +552,8 @@ def main():
     else:
         sample_ms = [a.elapsed_time(b) for a, b, _ in phase_marks]
         gather_ms = [b.elapsed_time(c) for _, b, c in phase_marks]
-    rank_rec = {"rank": rank, "create_s": round(create_s, 2), "elapsed_s": round(t1 - t0, 4),
+    rank_rec = {"rank": rank, "create_s": round(create_s, 2), "load_s": None if load_rec is None else load_rec["load_s"],
+                "load": load_rec, "elapsed_s": round(t1 - t0, 4),
                 "sample_ms_per_step": round(sum(sample_ms) / max(len(sample_ms), 1), 2),
                 "gather_ms_per_step": round(sum(gather_ms) / max(len(gather_ms), 1), 3),
                 "power_mean_w": None if not power_rec else power_rec["mean_w"],
@@ -685,12 +742,12 @@ def main():
                                        "single process, one GPU, no process group (nothing crosses RCCL at N=1)")},
             "flop_per_sample": f_sample,
             "mfma_frac_whole_job": round(value / world * f_sample / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "timed_region": ("t0: tokens (sequence ids, all-MASK start) resident in HBM on every rank, engines created, warm-up done, "
-                             "device synchronised + barrier.  Inside: K x [whole sampling loop on the device (T + 1 forwards + "
-                             "fused sampler launches)" + (", one RCCL all_gather of the int16 ids" if use_dist else "") +
-                             "].  t1: after device synchronise (+ barrier); ids are on the DEVICE.  Not inside: tokenising the one "
-                             "sequence (microseconds, host), the D2H copy of the ids (51.6 KB per 100 samples), VQ-VAE decode, PDB I/O "
-                             "(BASELINE.md section 4 counts tokenise -> ids on host; the difference is < 0.1 ms per step)"),
+            "timed_region": ("BASELINE.md section 4, tokenise -> final ids on host.  t0: engines created, warm-up done, device synchronised "
+                             "+ barrier; the input is the residue STRING.  Inside: K x [tokenise on the host, repeat over the batch, "
+                             "upload; whole sampling loop on the device (T + 1 forwards + fused sampler launches)" +
+                             (", one RCCL all_gather of the int16 ids" if use_dist else "") +
+                             "; asynchronous D2H copy of the int16 ids into pinned host memory].  t1: after device synchronise "
+                             "(+ barrier): the ids of every step are on the HOST.  Not inside: VQ-VAE decode, PDB I/O"),
             "environment": {"lib_path": None if stub else str(__import__("esmdiff_amd._native", fromlist=["lib_path"]).lib_path()),
                             "esmdiff_env": env_seen, "precision": args.precision, "head_precision": args.head_precision},
             "per_rank": per_rank,

@@ -247,11 +247,16 @@ def load_state_dict_from_lightning_ckpt(ckpt_path, device="cuda", max_batch: int
     else:
         print("Config file not found next to the checkpoint. Use default config (configs/experiment/mdlm.yaml).")
     print(f"Loaded experiment config: {exp_cfg_path or 'mdlm.yaml defaults'}...")
-    sd = load_checkpoint_state_dict(ckpt_path)
+    # one process per GPU: rank 0 reads the file, the others get the tensors by one broadcast (dist.broadcast_state_dict)
+    from .dist import broadcast_state_dict
     dev = torch.device(device).index or 0
+    sd, load_t = broadcast_state_dict(lambda: load_checkpoint_state_dict(ckpt_path), torch.device("cuda", dev))
     model = MaskedDiffusionLanguageModeling(sd, cfg, noise, max_batch, max_len, dev, noise_removal=True, precision=precision,
                                             head_precision=head_precision)
-    print(f"Sucessfully loaded model from {ckpt_path}...")
+    model.load_timings = load_t
+    del sd
+    print(f"Sucessfully loaded model from {ckpt_path}... (rank {load_t['rank']}: {load_t['load_s']} s, {load_t['bytes'] / 1e9:.2f} GB, "
+          f"{load_t['path']})")
     return model
 
 

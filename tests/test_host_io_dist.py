@@ -304,6 +304,96 @@ def test_cli_drivers_shard_decode_gather_gloo_world2(tmp_path):
                 assert abs(float(ln[60:66]) - float(toks[i, j] % 100) / 100) < 6e-3
 
 
+def _cli_worker_800(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from esmdiff_amd.sample_esmdiff import ddpm_sample_by_esm
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = _StubModel()
+    model.net.max_batch = 128                                   # configs[2]: 100 samples per rank in one batch
+    ddpm_sample_by_esm("ACDEFGHIKLMNPQRS", model, Path(tmp) / f"w{world}", "t", num_samples=800, num_steps=3, seed=4, timestamp=False,
+                       decoder=_StubDecoder())
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def test_cli_configs2_split_world_1_2_8_gloo(tmp_path):
+    """BASELINE configs[2]'s split without the node: 800 samples through the reference's driver (sample_esmdiff.py:137-233)
+    at world sizes 1, 2 and 8 on gloo with the stand-in engine (ids a pure function of the GLOBAL sample index, like the Philox
+    noise) — 100 samples per rank at world 8, one int16 all_gather, every rank decodes its shard, rank 0 writes ONE file with 800
+    MODELs.  The token files and the PDB files of the three runs must be identical byte for byte."""
+    import torch.multiprocessing as mp
+    outs = {}
+    for world in (1, 2, 8):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        if world == 1:
+            _cli_worker_800(0, 1, port, str(tmp_path))
+            for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                os.environ.pop(k, None)
+        else:
+            mp.spawn(_cli_worker_800, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+        d = tmp_path / f"w{world}" / "step3_eps1e-05_N800"
+        toks = np.load(d / "t.tokens.npy")
+        pdb = (d / "t.pdb").read_bytes()
+        meta = json.loads((d / "t.json").read_text())
+        assert toks.shape == (800, 16) and meta["world_size"] == world and pdb.count(b"MODEL ") == 800
+        assert len(list(d.glob("*.pdb"))) == 1                  # one multi-MODEL file, written by rank 0 only
+        outs[world] = (toks, pdb)
+    want = _StubEngine.ids(800, 18, 4, 0)[:, 1:-1].numpy()
+    for world in (1, 2, 8):
+        assert np.array_equal(outs[world][0], want), world
+        assert outs[world][1] == outs[1][1], world
+
+
+def _fanout_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from esmdiff_amd.dist import broadcast_state_dict
+    from esmdiff_amd.weights import load_checkpoint_state_dict
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def loader():
+        calls.append(rank)
+        return load_checkpoint_state_dict(Path(tmp) / "ck.pt")
+
+    sd, t = broadcast_state_dict(loader, "cpu")
+    assert calls == ([0] if rank == 0 else []), calls           # only the reader opened the file
+    assert t["rank"] == rank and t["reader_rank"] == 0 and t["bytes"] >= 4 * (7 * 5 + 3) + 2 * 4 and t["load_s"] >= 0
+    torch.save({k: v.clone() for k, v in sd.items()}, Path(tmp) / f"got{rank}.pt")
+    dist.destroy_process_group()
+
+
+def test_checkpoint_fanout_one_reader_gloo_world3(tmp_path):
+    """dist.broadcast_state_dict: rank 0 reads the checkpoint (checkpoint_utils.py:59-64's file format), the other ranks never
+    touch it and receive names, shapes, dtypes and values — mixed dtypes, a 0-d tensor, an odd-sized one (256-byte aligned flat
+    buffer) — bit for bit."""
+    import torch.multiprocessing as mp
+    g = torch.Generator().manual_seed(0)
+    sd = {"net.a.weight": torch.randn(7, 5, generator=g), "net.b.bias": torch.randn(3, generator=g).to(torch.bfloat16),
+          "sigma_embedder.mlp.0.weight": torch.randn(2, 2, generator=g), "net.count": torch.tensor(5, dtype=torch.int64),
+          "net.half": torch.randn(129, generator=g).half()}
+    torch.save({"module": sd}, tmp_path / "ck.pt")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_fanout_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        got = torch.load(tmp_path / f"got{r}.pt", weights_only=True)
+        assert list(got) == list(sd)
+        for k in sd:
+            assert got[k].dtype == sd[k].dtype and got[k].shape == sd[k].shape and torch.equal(got[k], sd[k]), (r, k)
+    from esmdiff_amd.dist import broadcast_state_dict
+    alone, t = broadcast_state_dict(lambda: sd, "cpu")          # no process group: loader + copy
+    assert t["path"] == "single process" and all(torch.equal(alone[k], sd[k]) for k in sd)
+
+
 def test_engine_capacity_covers_every_issued_batch():
     """max_batch must come from the batches the splitters really issue (per target, per mode, remainder batch
     included), and any batch can be chunked to a smaller engine."""
