@@ -753,6 +753,21 @@ def main():
             "per_rank": per_rank,
             "slowest_rank": max(per_rank, key=lambda r: r["elapsed_s"])["rank"],
         }
+        # What the per-rank figures PREDICT for the scaling efficiency the driver computes from the per-N values (weak scaling,
+        # no data-path collective): inside the timed region only the gather and rank skew can cost anything; start-up (checkpoint
+        # fan-out + engine create) is outside it and is reported as the job-level figure a user of the CLI would see.
+        slow = max(per_rank, key=lambda r: r["elapsed_s"])
+        samp = [r["sample_ms_per_step"] for r in per_rank]
+        startup = max((r["create_s"] or 0.0) + (r["load_s"] or 0.0) for r in per_rank)
+        out["scaling_prediction"] = {
+            "timed_region_efficiency": round(min(samp) / max(1e-9, slow["sample_ms_per_step"] + slow["gather_ms_per_step"]), 4),
+            "gather_share_of_step": round(slow["gather_ms_per_step"] / max(1e-9, slow["sample_ms_per_step"] + slow["gather_ms_per_step"]), 5),
+            "rank_skew": round(max(samp) / max(1e-9, min(samp)) - 1.0, 4),
+            "startup_s_max_rank": round(startup, 2),
+            "job_efficiency_incl_startup_at_these_steps": round(elapsed / (elapsed + startup), 4),
+            "what": "timed_region_efficiency = fastest rank's sampling time / (slowest rank's sampling + gather time): the efficiency "
+                    "value_N / (N x value_1) should show if every GPU holds the clock the N = 1 run held; startup = load_s "
+                    "(one reader + one broadcast of the 5.5 GB checkpoint) + create_s, outside the timed region"}
         out["config"]["precision"] = args.precision
         out["config"]["head_precision"] = args.head_precision
         if stub:
