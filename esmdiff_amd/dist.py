@@ -62,7 +62,7 @@ def broadcast_state_dict(loader, device, src: int = 0):
     import time
     device = torch.device(device)
     t0 = time.perf_counter()
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    multi = dist.is_available() and dist.is_initialized()      # (a world of 1 still goes through the collectives: same code path)
     rank = dist.get_rank() if multi else src
     sd = loader() if rank == src else None
     t_read = time.perf_counter()
@@ -95,7 +95,8 @@ def broadcast_state_dict(loader, device, src: int = 0):
     t_end = time.perf_counter()
     return out, {"read_s": round(t_read - t0, 3), "upload_s": round(t_up - t_read, 3), "broadcast_s": round(t_bc - t_up, 3),
                  "load_s": round(t_end - t0, 3), "bytes": int(tot), "reader_rank": src, "rank": rank,
-                 "path": "single process" if not multi else ("gloo via host memory" if via_host or device.type == "cpu" else "RCCL from the reader's GPU")}
+                 "world": dist.get_world_size() if multi else 1,
+                 "path": "no process group" if not multi else ("gloo via host memory" if via_host or device.type == "cpu" else "RCCL from the reader's GPU")}
 
 
 def pin_to_gpu_numa(local_rank):

@@ -391,7 +391,7 @@ def test_checkpoint_fanout_one_reader_gloo_world3(tmp_path):
             assert got[k].dtype == sd[k].dtype and got[k].shape == sd[k].shape and torch.equal(got[k], sd[k]), (r, k)
     from esmdiff_amd.dist import broadcast_state_dict
     alone, t = broadcast_state_dict(lambda: sd, "cpu")          # no process group: loader + copy
-    assert t["path"] == "single process" and all(torch.equal(alone[k], sd[k]) for k in sd)
+    assert t["path"] == "no process group" and all(torch.equal(alone[k], sd[k]) for k in sd)
 
 
 def test_engine_capacity_covers_every_issued_batch():
