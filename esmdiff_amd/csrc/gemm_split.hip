@@ -94,6 +94,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
   }
 }
 
+// The same for rows that fit the register file (K = 512 NV: 1536 -> 3, 4096 -> 8): ONE pass — a lane holds 8 consecutive elements per
+// slab (two 16-byte loads), so every plane gets 16-byte stores.  r05: the FFN mid rows (K = 4096) go through here once per block.
+template <int NV>
+__global__ __launch_bounds__(256) void split_rows_reg_kernel(const float* __restrict__ src, int ld, uint16_t* __restrict__ dst,
+                                                             float* __restrict__ rs, int M) {
+  constexpr int K = 512 * NV;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* x = src + (int64_t)row * ld + lane * 8;
+  f32x4 v[NV][2];
+  float amax = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) v[j][q] = *reinterpret_cast<const f32x4*>(x + j * 512 + q * 4);
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v[j][q][0]), fabsf(v[j][q][1]))), fmaxf(fabsf(v[j][q][2]), fabsf(v[j][q][3])));
+  amax = wmax64(amax);
+  float s, inv;
+  row_scale(amax, s, inv);
+  if (lane == 0) rs[row] = inv;
+  uint16_t* d = dst + (int64_t)row * 3 * K + lane * 8;
+  typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    f16x4 h0, l0, h1, l1;
+    split4(v[j][0], s, h0, l0);
+    split4(v[j][1], s, h1, l1);
+    const f16x8 hi = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    const f16x8 lo = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    *reinterpret_cast<f16x8*>(d + j * 512) = hi;
+    *reinterpret_cast<f16x8*>(d + K + j * 512) = lo;
+    *reinterpret_cast<f16x8*>(d + 2 * K + j * 512) = hi;
+  }
+}
+
 // y = LayerNorm(GELU_IN ? gelu(x) : x) * w (+ b) in the strict path's arithmetic (strict.hip::layernorm_f32_kernel: two-pass
 // statistics, 1 / sqrtf(var + 1e-5), correctly rounded), written as a split row.  One wave per row, D <= 2048.
 // FULL: D == 256 NV exactly (every d_model the engine accepts): no per-lane column test, hence no divergent branch per slab
@@ -329,7 +369,11 @@ hipError_t launch_splitk_reduce_resid(const float* parts, const float* rs, float
 hipError_t launch_split_rows(const float* src, int ld, uint16_t* dst, float* rs, int M, int K, hipStream_t stream) {
   if (M <= 0) return hipSuccess;
   if (K % 4 || ld % 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(split_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, src, ld, dst, rs, M, K);
+  // rows of 1536 / 4096 (d_model and the FFN width of ESM3-open): the one-pass register form; identical values (same scale rule,
+  // same rounding), so which kernel ran never shows in a result
+  if (K == 4096) hipLaunchKernelGGL(split_rows_reg_kernel<8>, dim3((M + 3) / 4), dim3(256), 0, stream, src, ld, dst, rs, M);
+  else if (K == 1536) hipLaunchKernelGGL(split_rows_reg_kernel<3>, dim3((M + 3) / 4), dim3(256), 0, stream, src, ld, dst, rs, M);
+  else hipLaunchKernelGGL(split_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, src, ld, dst, rs, M, K);
   return hipGetLastError();
 }
 

@@ -1,6 +1,6 @@
 """Certified sampling at the other BASELINE configs (run on the GPU box): ids against the F32_SPLIT engine's own chain, re-run
 share and rate.  configs[3]: 32 samples x 1024 residues, 25 updates; configs[4]: 100 x 256, 50 updates, residues 96..159 masked
-(inpainting prior); configs[0]: 4 x 58.  -> gpurun_out/r04_certified_configs.json"""
+(inpainting prior); configs[0]: 4 x 58.  -> gpurun_out/r05_certified_configs.json (r05 sampler: speculative lane, batched verification, audit)"""
 import json
 import os
 import sys
@@ -46,9 +46,12 @@ for name, B, R, T, window in (("configs0", 4, 58, 25, None), ("configs3", 32, 10
                  "samples_identical_without_certification": int((plain == want).all(1).sum()),
                  "certified_samples_per_s": round(B / (t1 - t0), 2), "f32_split_samples_per_s": round(B / (t2 - t1), 2),
                  "f16_head_f32_samples_per_s": round(B / (t3 - t2), 2),
-                 "rerun_share": round(st["sample_forwards_exact"] / max(1, st["sample_forwards_fast"]), 4),
+                 "rerun_share": st["rerun_share"], "exact_per_fast_sample_forwards": round(st["sample_forwards_exact"] / max(1, st["sample_forwards_fast"]), 4),
                  "eps_used": [st["eps_min_used"], st["eps_max_used"]], "max_logit_err_observed": st["max_logit_err_observed"],
-                 "eps_violations": st["eps_violations"], "first_update_shared": st["first_update_shared"]}
+                 "eps_violations": st["eps_violations"], "first_update_shared": st["first_update_shared"],
+                 "flagged": st["flagged"], "corrections": st["corrections"], "audit_checked": st["audit_checked"],
+                 "audit_mismatches": st["audit_mismatches"], "verify_batch_sizes": st["verify_batch_sizes"], "tail_seconds": st["tail_seconds"],
+                 "gpu_seconds_fast": st.get("gpu_seconds_fast"), "gpu_seconds_verify": st.get("gpu_seconds_verify")}
     print(name, json.dumps(out[name]), flush=True)
     fast.close(); exact.close()
-json.dump(out, open("gpurun_out/r04_certified_configs.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r05_certified_configs.json", "w"), indent=1)

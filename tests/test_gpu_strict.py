@@ -105,6 +105,11 @@ def test_gemm_split_vs_float64(M, N, K, scale):
     rep = ((hi + lo) * rs.cpu().double()[:, None] - A.double()).abs().amax(1) / A.double().abs().amax(1)
     assert float(rep.max()) < 2.0 ** -21, float(rep.max())
     assert float(a3[:, :K].float().abs().amax(1).min()) >= 2.0 ** 14 and float(a3.float().abs().max()) < 2.0 ** 15
+    if K in (1536, 4096):      # r05: these widths take the one-pass register kernel; the generic two-pass kernel (any other K) must agree bit for bit
+        wide = torch.cat([A, torch.zeros(M, 256)], 1).cuda()
+        b3, brs = split_rows(wide)
+        Kw = K + 256
+        assert torch.equal(brs, rs) and torch.equal(b3[:, :K], a3[:, :K]) and torch.equal(b3[:, Kw:Kw + K], a3[:, K:2 * K])
     got = gemm_split(a3, rs, w3, inv, N).cpu()
     rel = float(((got.double() - ref).abs() / mag).max())
     rel32 = float(((gemm_f32(A.cuda(), W.cuda()).cpu().double() - ref).abs() / mag).max()) if K % 32 == 0 else None
