@@ -54,6 +54,7 @@ EXPORTS = [
     "esmdiff_set_gibbs_options", "esmdiff_split_rows", "esmdiff_split_weight", "esmdiff_gemm_split",
     "esmdiff_get_embeddings", "esmdiff_set_final_skip", "esmdiff_gemm_f16", "esmdiff_ddpm_step_margin", "esmdiff_forward_logits_sigmas", "esmdiff_set_small_batch_splitk",
     "esmdiff_ddpm_step_rows", "esmdiff_logit_error_stats", "esmdiff_get_build_info", "esmdiff_describe_plan", "esmdiff_set_option",
+    "esmdiff_get_sequence_logits",
 ]
 OPT_STREAMS, OPT_DUAL_MIN_TOKENS = 1, 2      # esmdiff_option
 
@@ -135,6 +136,7 @@ def lib():
     L.esmdiff_get_counters.argtypes = [vp, c_i64p, c_i64p, i32]
     L.esmdiff_gemm_f32.argtypes = [vp, i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, i32, vp]
     L.esmdiff_get_embeddings.argtypes = [vp, vp, i32, i32, vp]
+    L.esmdiff_get_sequence_logits.argtypes = [vp, vp, i32, i32, i32, vp]
     L.esmdiff_split_rows.argtypes = [vp, i32, vp, vp, i32, i32, vp]
     L.esmdiff_split_weight.argtypes = [vp, vp, i32, i32, i32, c_f32p]
     L.esmdiff_gemm_split.argtypes = [vp, vp, vp, f32, vp, vp, i32, i32, i32, i32, f32, i32, vp]

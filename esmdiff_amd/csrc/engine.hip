@@ -910,28 +910,36 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(dalloc(e, &e->head_b3, (size_t)e->vocab_pad, true));
     if (launch_to_f32(w->data, w->dtype, e->head_b3, V, 0) != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "to_f32 failed"));
   }
-  if (kind == 1) {
-    TRY(load_f32(e, t, "embed.weight", {ESMDIFF_VOCAB, D}, &e->e_struct));
-    if (const esmdiff_weight* pw = t.find("plddt_head.3.weight")) {   // RegressionHead(d, 50): Linear, GELU, LayerNorm, Linear
+  if (kind == 1) TRY(load_f32(e, t, "embed.weight", {ESMDIFF_VOCAB, D}, &e->e_struct));
+  {
+    // A second RegressionHead(d, n) (Linear, GELU, LayerNorm, Linear) on the same normalised hidden state: the decoder's pLDDT
+    // head (n = 50 bins), or — r05 — the reference's optional SEQUENCE head of the ESMDiff network (net.py:299-311:
+    // StructureOutputHeads(d_model, n_structure_heads, n_sequence_heads > 0), read by _model_wrapper when sequence_prediction is
+    // on, model.py:488-490).  Same buffers, same launches; esmdiff_get_sequence_logits copies the valid columns out.
+    const std::string sh = kind == 1 ? "plddt_head." : "output_heads.sequence_head.";
+    if (const esmdiff_weight* pw = t.find(sh + "3.weight")) {
       const int nb = pw->ndim == 2 ? (int)pw->shape[0] : 0;
-      if (nb <= 0 || nb > 128) return bail(fail(e, ESMDIFF_E_INVALID, "plddt_head.3.weight: %d bins unsupported (1..128)", nb));
+      if (nb <= 0 || nb > 128) return bail(fail(e, ESMDIFF_E_INVALID, "%s3.weight: %d outputs unsupported (1..128)", sh.c_str(), nb));
+      if (head_split) return bail(fail(e, ESMDIFF_E_INVALID, "a sequence head and head_precision = 1 together are not built: use precision f32 / f32_split or head_precision 0"));
       e->plddt_bins = nb;
       e->ld_plddt = split ? 256 : round_up(nb, 4);   // the split GEMM has no column bound: its output row holds all N_pad columns
-      if (split) TRY(load_split(e, t, "plddt_head.0.weight", {D, D}, &e->s_pl0));
-      else if (strict) TRY(load_f32(e, t, "plddt_head.0.weight", {D, D}, &e->fpl_w0));
-      else TRY(load_bf16(e, t, "plddt_head.0.weight", {D, D}, &e->pl_w0));
-      TRY(load_f32(e, t, "plddt_head.0.bias", {D}, &e->pl_b0));
-      TRY(load_f32(e, t, "plddt_head.2.weight", {D}, &e->pl_ln_w));
-      TRY(load_f32(e, t, "plddt_head.2.bias", {D}, &e->pl_ln_b));
-      if (split) TRY(load_split(e, t, "plddt_head.3.weight", {nb, D}, &e->s_pl3, 256));
-      else if (strict) TRY(load_f32(e, t, "plddt_head.3.weight", {nb, D}, &e->fpl_w3));
-      else TRY(load_bf16(e, t, "plddt_head.3.weight", {nb, D}, &e->pl_w3, 128));
+      if (split) TRY(load_split(e, t, sh + "0.weight", {D, D}, &e->s_pl0));
+      else if (strict) TRY(load_f32(e, t, sh + "0.weight", {D, D}, &e->fpl_w0));
+      else TRY(load_bf16(e, t, sh + "0.weight", {D, D}, &e->pl_w0));
+      TRY(load_f32(e, t, sh + "0.bias", {D}, &e->pl_b0));
+      TRY(load_f32(e, t, sh + "2.weight", {D}, &e->pl_ln_w));
+      TRY(load_f32(e, t, sh + "2.bias", {D}, &e->pl_ln_b));
+      if (split) TRY(load_split(e, t, sh + "3.weight", {nb, D}, &e->s_pl3, 256));
+      else if (strict) TRY(load_f32(e, t, sh + "3.weight", {nb, D}, &e->fpl_w3));
+      else TRY(load_bf16(e, t, sh + "3.weight", {nb, D}, &e->pl_w3, 128));
       const esmdiff_weight* w;
-      TRY(need(e, t, "plddt_head.3.bias", {nb}, &w));
+      TRY(need(e, t, sh + "3.bias", {nb}, &w));
       TRY(dalloc(e, &e->pl_b3, (size_t)128, true));
       if (launch_to_f32(w->data, w->dtype, e->pl_b3, nb, 0) != hipSuccess) return bail(fail(e, ESMDIFF_E_HIP, "to_f32 failed"));
       e->has_plddt = true;
     }
+  }
+  if (kind == 1) {
     if (t.find("pairwise_classification_head.linear2.weight")) {
       const std::string ph = "pairwise_classification_head.";
       if (strict) TRY(load_f32(e, t, ph + "downproject.weight", {128, D}, &e->fpw_down));
@@ -1273,6 +1281,17 @@ int esmdiff_get_embeddings(esmdiff_engine* e, float* out, int32_t B, int32_t L, 
   if (e->last_pending_delta)
     HIP_TRY(e, e->f16 ? ed16::launch_add_layernorm_bf16(out, e->dlt, nullptr, 1, e->final_ln_w, nullptr, e->q, (int)M, (int)D, st)
                       : ed::launch_add_layernorm_bf16(out, e->dlt, nullptr, 1, e->final_ln_w, nullptr, e->q, (int)M, (int)D, st));
+  return 0;
+}
+
+int esmdiff_get_sequence_logits(esmdiff_engine* e, float* out, int32_t ld_out, int32_t B, int32_t L, void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (e->kind != 0 || !e->has_plddt) return fail(e, ESMDIFF_E_MISSING, "no output_heads.sequence_head.* tensors were in the weight table");
+  if (!out || ld_out < e->plddt_bins) return fail(e, ESMDIFF_E_INVALID, "bad output");
+  if (B != e->last_B || L != e->last_L || B <= 0)
+    return fail(e, ESMDIFF_E_INVALID, "sequence logits of a (%d, %d) forward requested, the last forward was (%d, %d)", B, L, e->last_B, e->last_L);
+  HIP_TRY(e, hipMemcpy2DAsync(out, (size_t)ld_out * 4, e->pl_logits, (size_t)e->ld_plddt * 4, (size_t)e->plddt_bins * 4, (size_t)B * L,
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 

@@ -81,6 +81,7 @@ class Engine:
         self.ld_logits = (cfg.n_structure_heads + 3) // 4 * 4
         self.has_geom = any(k.endswith("transformer.blocks.0.geom_attn.proj.weight") for k in state_dict)
         self.has_sigma_embedder = any(k.startswith("sigma_embedder.mlp.0.") for k in state_dict)
+        self.n_sequence_heads = next((int(v.shape[0]) for k, v in state_dict.items() if k.endswith("output_heads.sequence_head.3.weight")), 0)
         self._frames = None
 
     def branch_linear_layernorm(self, A: torch.Tensor, W: torch.Tensor, x: torch.Tensor, alpha: float, w: torch.Tensor,
@@ -166,6 +167,16 @@ class Engine:
         """ESMOutput.embeddings of the forward that just ran (net.py:468-469): the pre-norm hidden state, (B, L, d) f32."""
         out = torch.empty(B, L, self.cfg.d_model, dtype=torch.float32, device=self.device)
         self._chk(self._lib.esmdiff_get_embeddings(self._h, _ptr(out), B, L, _stream()))
+        return out
+
+    def sequence_logits(self, B: int, L: int) -> torch.Tensor:
+        """ESMOutput.sequence_logits of the forward that just ran (net.py:310-311; esmdiff_get_sequence_logits): (B, L,
+        n_sequence_heads) f32.  Needs output_heads.sequence_head.* in the state dict."""
+        n = self.n_sequence_heads
+        if not n:
+            raise RuntimeError("this engine was built without output_heads.sequence_head.* weights")
+        out = torch.empty(B, L, n, dtype=torch.float32, device=self.device)
+        self._chk(self._lib.esmdiff_get_sequence_logits(self._h, _ptr(out), n, B, L, _stream()))
         return out
 
     def ddpm_step(self, x: torch.Tensor, logits: torch.Tensor, mc_t: float, mc_s: float, *, final: bool = False,

@@ -78,7 +78,8 @@ class MaskedDiffusionLanguageModeling:
     def _sample_prior(self, *batch_dims):
         return self.mask_index * torch.ones(*batch_dims, dtype=torch.int64)
 
-    sequence_prediction = False      # the reference's flag (model.py:487-490); this engine builds the structure head only
+    sequence_prediction = False      # the reference's flag (model.py:332, 366, 487-490): also return the sequence head's logits; needs
+                                     # output_heads.sequence_head.* in the state dict (net.py:299-311), as the reference asserts (:374-375)
 
     def logits_parameterization(self, logits: torch.Tensor, xt: torch.Tensor) -> torch.Tensor:
         """model.py:527-533 on the device, in the reference's operation order (torch ops on the logits tensor: the loops use the
@@ -96,10 +97,11 @@ class MaskedDiffusionLanguageModeling:
         """The reference's `_model_wrapper` (model.py:464-492): log-probabilities (B, L, 4101) of the SUBS parameterisation at
         noise level `sigma` ((B,) or (B, 1): one value per sample as in the reference, or a single value; None = no time
         conditioning at all), optionally with the five special ids shielded (:484-486).
-        Returns (logits, None) like the reference with sequence_prediction off; sequence_prediction is not built."""
+        Returns (logits, None) like the reference with sequence_prediction off, (logits, sequence_logits (B, L, n_sequence_heads))
+        with it on (:488-490: the raw output of the network's sequence head for the same forward)."""
         from .schedule import timestep_embedding
-        if self.sequence_prediction:
-            raise NotImplementedError("sequence_prediction: the engine has no sequence head (the reference's sampler never uses it)")
+        if self.sequence_prediction and not getattr(self.net, "n_sequence_heads", 0):
+            raise AssertionError("Sequence head not found in tbe network, but sequence_prediction is True.")      # model.py:375
         xt = xt.to(self.device)
         B, L = xt.shape
         if sequence_tokens is None:     # net.py:412-416: the sequence track defaults to all-mask
@@ -119,6 +121,8 @@ class MaskedDiffusionLanguageModeling:
         logits = self.logits_parameterization(raw.float(), xt)
         if shield_special_tokens:
             logits[..., STRUCTURE_MASK_TOKEN:STRUCTURE_MASK_TOKEN + 5] += self.neg_infinity
+        if self.sequence_prediction:
+            return logits, self.net.sequence_logits(B, L)
         return logits, None
 
     def _process_sigma(self, sigma):

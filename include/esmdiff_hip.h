@@ -182,6 +182,13 @@ int esmdiff_set_small_batch_splitk(esmdiff_engine* eng, int32_t on);
  * state, the second value `self.transformer(...)` returns): out f32 [B,L,d_model].  (B, L) must be the last forward's. */
 int esmdiff_get_embeddings(esmdiff_engine* eng, float* out, int32_t B, int32_t L, void* stream);
 
+/* ESMOutput.sequence_logits of the forward that just ran, for networks built with a sequence head (net.py:299-311:
+ * StructureOutputHeads(..., n_sequence_heads > 0), a RegressionHead on the same normalised hidden state as the structure head;
+ * what _model_wrapper returns next to the structure logits when sequence_prediction is on, model.py:488-490).  The head is
+ * created when the weight table holds output_heads.sequence_head.{0,2,3}.{weight,bias} (1 .. 128 outputs) and then runs with
+ * every forward; out f32 [B, L, ld_out], ld_out >= n_sequence_heads.  ESMDIFF_E_MISSING without those weights.  (ABI 7) */
+int esmdiff_get_sequence_logits(esmdiff_engine* eng, float* out, int32_t ld_out, int32_t B, int32_t L, void* stream);
+
 /* Replaces logits_parameterization + the sampling half of _ddpm_update + _sample_categorical
  * (model.py:527-533, 602-607, 24-28): given RAW network logits, writes x' in place.
  *   final == 0: x' = where(x != MASK, x, argmax_v q_v / (1e-10 - log(u_v + 1e-10)))

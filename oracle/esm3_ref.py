@@ -142,20 +142,23 @@ class TransformerRef(nn.Module):
 class OutputHeadsRef(nn.Module):
     """StructureOutputHeads (net.py:298-308): RegressionHead = Linear -> GELU -> LayerNorm -> Linear."""
 
-    def __init__(self, d_model, n_out):
+    def __init__(self, d_model, n_out, n_sequence_heads=0):
         super().__init__()
         self.structure_head = nn.Sequential(nn.Linear(d_model, d_model), nn.GELU(), nn.LayerNorm(d_model),
                                             nn.Linear(d_model, n_out))
+        if n_sequence_heads:       # net.py:302-303: the optional sequence head is the same RegressionHead
+            self.sequence_head = nn.Sequential(nn.Linear(d_model, d_model), nn.GELU(), nn.LayerNorm(d_model),
+                                               nn.Linear(d_model, n_sequence_heads))
 
 
 class ESM3Ref(nn.Module):
-    def __init__(self, cfg, with_geom=False):
+    def __init__(self, cfg, with_geom=False, n_sequence_heads=0):
         super().__init__()
         self.cfg = cfg
         self.encoder = EncodeInputsRef(cfg.d_model)
         self.transformer = TransformerRef(cfg.d_model, cfg.n_heads, cfg.n_layers, cfg.ffn_hidden,
                                           cfg.v_heads if with_geom else 0)
-        self.output_heads = OutputHeadsRef(cfg.d_model, cfg.n_structure_heads)
+        self.output_heads = OutputHeadsRef(cfg.d_model, cfg.n_structure_heads, n_sequence_heads)
 
     def embed(self, structure_tokens, sequence_tokens, auxiliary_embeddings=None):
         """net.py:410-466 with every optional track at its default."""
@@ -184,7 +187,9 @@ class ESM3Ref(nn.Module):
             from .geom_ref import build_affine3d_from_coordinates
             frames = build_affine3d_from_coordinates(structure_coords)
         x, emb = self.transformer(x, frames)
-        return SimpleNamespace(structure_logits=self.output_heads.structure_head(x), embeddings=emb)
+        seq_head = getattr(self.output_heads, "sequence_head", None)       # net.py:310-311 (a dummy zero tensor without the head)
+        return SimpleNamespace(structure_logits=self.output_heads.structure_head(x), embeddings=emb,
+                               sequence_logits=None if seq_head is None else seq_head(x))
 
 
 def build_from_state_dict(cfg, state_dict, prefix="net."):
@@ -192,7 +197,8 @@ def build_from_state_dict(cfg, state_dict, prefix="net."):
     from .sampler_ref import TimestepEmbedderRef
 
     sub = {k[len(prefix):]: v.float() for k, v in state_dict.items() if k.startswith(prefix)}
-    net = ESM3Ref(cfg, with_geom=any("geom_attn" in k for k in sub))
+    n_seq = sub["output_heads.sequence_head.3.weight"].shape[0] if "output_heads.sequence_head.3.weight" in sub else 0
+    net = ESM3Ref(cfg, with_geom=any("geom_attn" in k for k in sub), n_sequence_heads=n_seq)
     missing, unexpected = net.load_state_dict(sub, strict=False)
     assert not missing, missing
     unexpected = [k for k in unexpected if "geom_attn" not in k and "function_embed" not in k

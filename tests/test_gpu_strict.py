@@ -1073,5 +1073,27 @@ def test_model_wrapper_semantics_vs_reference_parameterization():
     with pytest.raises(ValueError):                                   # B = 3: a sigma vector must hold 1 or 3 values
         model._model_wrapper(xt, seq, torch.tensor([0.1, 0.2]))
     model.sequence_prediction = True
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(AssertionError, match="Sequence head not found"):      # the reference's own assertion (model.py:374-375)
         model._model_wrapper(xt, seq, sigma)
+    model.net.close()
+    # ... and with the head (net.py:299-311: StructureOutputHeads(d, 4101, n_sequence_heads = 64), a RegressionHead on the same
+    # normalised hidden state): (logits, sequence_logits) as model.py:488-490 returns them, every precision of the engine
+    g2 = torch.Generator().manual_seed(8)
+    sd2 = dict(sd)
+    h = "net.output_heads.sequence_head."
+    sd2[h + "0.weight"], sd2[h + "0.bias"] = torch.randn(512, 512, generator=g2) / 512 ** 0.5, 0.1 * torch.randn(512, generator=g2)
+    sd2[h + "2.weight"], sd2[h + "2.bias"] = 1 + 0.1 * torch.randn(512, generator=g2), 0.05 * torch.randn(512, generator=g2)
+    sd2[h + "3.weight"], sd2[h + "3.bias"] = torch.randn(64, 512, generator=g2) / 512 ** 0.5, 0.1 * torch.randn(64, generator=g2)
+    net2, emb2 = build_from_state_dict(TINY, sd2)
+    with torch.no_grad():
+        cond = torch.tile(emb2(sigma.squeeze(-1))[:, None, :], (1, L, 1))
+        ref2 = net2(structure_tokens=xt, sequence_tokens=seq, auxiliary_embeddings=cond)
+    assert ref2.sequence_logits.shape == (B, L, 64)
+    for prec, tol in (("f32_split", 5e-5), ("f32", 5e-5), ("f16", 0.01), ("bf16", 0.05)):
+        m2 = MaskedDiffusionLanguageModeling(sd2, TINY, LogLinearNoise(), max_batch=3, max_len=40, device=0, precision=prec)
+        m2.sequence_prediction = True
+        lg2, sq2 = m2._model_wrapper(xt, seq, sigma)
+        assert sq2.shape == (B, L, 64) and float((sq2.cpu() - ref2.sequence_logits).abs().max()) < tol, (prec, float((sq2.cpu() - ref2.sequence_logits).abs().max()))
+        assert float((lg2.cpu()[masked] - want[masked])[..., :4096].abs().max()) < max(tol, 5e-5) * 4, prec     # the structure side is unchanged
+        m2.net.close()
+
