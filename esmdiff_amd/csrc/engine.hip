@@ -700,14 +700,17 @@ int esmdiff_describe_plan(const esmdiff_engine* e, int32_t B, int32_t L, char* b
   if (!e || B <= 0 || L <= 0) return ESMDIFF_E_INVALID;
   const esmdiff_config& c = e->cfg;
   const int D = c.d_model, FH = c.ffn_hidden;
-  char tmp[1024];
+  char tmp[1536];
   int n = 0;
+  // (every piece is appended through `add`, which never writes past tmp and keeps counting the length the full text needs)
+  auto room = [&]() { return n < (int)sizeof tmp ? sizeof tmp - (size_t)n : (size_t)0; };
+  auto at = [&]() { return tmp + (n < (int)sizeof tmp ? n : (int)sizeof tmp - 1); };
   const char* prec = e->strict ? (e->split ? "f32_split" : "f32") : (e->f16 ? "f16" : "bf16");
-  n += snprintf(tmp + n, sizeof tmp - n, "precision=%s head=%s B=%d L=%d", prec, (e->strict || e->head_split) ? "f32-grade" : prec, B, L);
+  n += snprintf(at(), room(), "precision=%s head=%s B=%d L=%d", prec, (e->strict || e->head_split) ? "f32-grade" : prec, B, L);
   if (e->strict) {
     const int64_t tokens = (int64_t)B * L;
     const int np = (e->split && !e->side.empty() && B >= 2 && tokens >= e->strict_dual_min_tokens) ? 2 : 1;
-    n += snprintf(tmp + n, sizeof tmp - n, " streams=%d path=%s k_sliced_small_batches=%d", np,
+    n += snprintf(at(), room(), " streams=%d path=%s k_sliced_small_batches=%d", np,
                   e->split ? "split(3 f16 MFMA passes, 256x256w4)" : "strict(f32 MFMA)", e->sk_parts && tokens <= e->splitk_max_rows ? 1 : 0);
   } else {
     const int np = plan_parts(e, B, L);
@@ -718,14 +721,14 @@ int esmdiff_describe_plan(const esmdiff_engine* e, int32_t B, int32_t L, char* b
     ed::describe_gemm(m0, D, D, e->gemm_ws[0].partial != nullptr, g2, sizeof g2);
     ed::describe_gemm(m0, 2 * FH, D, e->gemm_ws[0].partial != nullptr, g3, sizeof g3);
     ed::describe_gemm(m0, D, FH, false, g4, sizeof g4);
-    n += snprintf(tmp + n, sizeof tmp - n, " streams=%d rows_per_stream=%d path=%s", np, m0, small ? "small-batch(K-slice planes summed by the LayerNorm)" : "regular");
+    n += snprintf(at(), room(), " streams=%d rows_per_stream=%d path=%s", np, m0, small ? "small-batch(K-slice planes summed by the LayerNorm)" : "regular");
     if (small)
-      n += snprintf(tmp + n, sizeof tmp - n, " gemm[qkv]=%s gemm[out]=128x*/S%d gemm[ffn_up]=%s gemm[ffn_down]=128x*/S%d", g1, ed::gemm_partial_splits(D, D), g3,
+      n += snprintf(at(), room(), " gemm[qkv]=%s gemm[out]=128x*/S%d gemm[ffn_up]=%s gemm[ffn_down]=128x*/S%d", g1, ed::gemm_partial_splits(D, D), g3,
                     ed::gemm_partial_splits(D, FH));
     else
-      n += snprintf(tmp + n, sizeof tmp - n, " gemm[qkv]=%s gemm[out]=%s gemm[ffn_up]=%s gemm[ffn_down]=%s", g1, g2, g3, g4);
+      n += snprintf(at(), room(), " gemm[qkv]=%s gemm[out]=%s gemm[ffn_up]=%s gemm[ffn_down]=%s", g1, g2, g3, g4);
   }
-  n += snprintf(tmp + n, sizeof tmp - n, " step0_sharing=%d final_skip=%d small_max_rows=%d", e->step0_share, e->final_skip, ed::small_max_rows());
+  n += snprintf(at(), room(), " step0_sharing=%d final_skip=%d small_max_rows=%d", e->step0_share, e->final_skip, ed::small_max_rows());
   if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", tmp);
   return n;
 }
