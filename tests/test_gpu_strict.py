@@ -1035,6 +1035,46 @@ def test_certified_sampler_equals_float32_chain_configs1_full_batch():
     assert ship["samples_per_s"] > 1.6 * B / out["f32_split_alone_seconds"], ship      # measured 2.4x the F32_SPLIT engine alone
 
 
+@pytest.mark.parametrize("streamed", [False, True])
+def test_certified_sampler_inpainting_prior_small_batches_and_streaming(streamed):
+    """The certified sampler's other paths on the real engines (TINY model): an inpainting prior (no shared first update; samples
+    whose window is empty are complete before the first forward; MASKs that survive the last update go through the final-pass
+    margin rule), verification batches of 3, every unflagged sample-update audited, and — streamed — more samples than the fast
+    engine's max_batch in one call (lane width 4 of 10).  Bar: every id equal to the F32_SPLIT engine's own chain, 0 audit
+    mismatches; with the audit at 100 % every sample-update was verified one way or the other."""
+    from esmdiff_amd.certified import CertifiedSampler
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    sd = random_init_state_dict(TINY, seed=6)
+    B, L, T = 10, 40, 6
+    g = torch.Generator().manual_seed(40)
+    seq = _seq(B, L, g).cuda()
+    prior = torch.randint(0, 4096, (B, L), generator=g)
+    prior[:, 0], prior[:, -1] = 4098, 4097
+    prior[:8, 9:31] = MASK                                     # samples 8 and 9 hold no MASK at all
+    prior = prior.cuda()
+    sch = ddpm_schedule(T, freq_dim=TINY.freq_dim)
+    exact = Engine(TINY, sd, max_batch=B, max_len=L, precision="f32_split")
+    fast = Engine(TINY, sd, max_batch=4 if streamed else B, max_len=L, precision="f16", head_precision="f32")
+    want = exact.ddpm_sample(seq, sch, seed=3, input_prior=prior)
+    cs = CertifiedSampler(fast, exact, verify_batch=3, audit_rate=1.0)
+    got = cs.ddpm_sample(seq, sch, seed=3, input_prior=prior)
+    st = cs.stats
+    assert torch.equal(got, want), st
+    assert torch.equal(got[8:], prior[8:]) and int((got == MASK).sum()) == 0
+    assert not st["first_update_shared"] and st["lane_width"] == (4 if streamed else B)
+    assert st["audit_mismatches"] == 0 and st["audit_checked"] + st["flagged"] >= 8 * T        # everything that drew was verified
+    assert st["sample_forwards_fast"] <= 8 * (T + 1) + 2 + 8        # the two complete samples never entered a forward (+ probe, roll-backs)
+    assert max(st["verify_batch_sizes"]) <= B
+    # the same call with the noise of a second seed and no prior: shared first update, plain path
+    got2 = cs.ddpm_sample(seq[:1].repeat(B, 1), sch, seed=4)
+    assert torch.equal(got2, exact.ddpm_sample(seq[:1].repeat(B, 1), sch, seed=4)) and cs.stats["first_update_shared"]
+    fast.close()
+    exact.close()
+
+
 def test_model_wrapper_semantics_vs_reference_parameterization():
     """`MaskedDiffusionLanguageModeling._model_wrapper` (model.py:464-492) as a standalone call: network at sigma -> SUBS
     log-probabilities -> optional shield of the five special ids; (logits, None) with sequence_prediction off.  Checked on a
