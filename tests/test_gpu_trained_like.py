@@ -182,3 +182,59 @@ def test_trained_like_configs1_full_size_chains_and_certified_cold_start():
         assert r["audit_checked"] >= 0.01 * r["sample_forwards_fast"], (call, r)
     assert rec["f16_logits_finite"] and rec["bf16_logits_finite"], rec
     assert rec["certified_warm"]["sigma_pair_err"] > 6e-4, rec       # these weights DO put the estimate elsewhere (random init: 3.6e-4)
+
+
+def test_trained_like_structure_decoder_rmsd():
+    """The structure decoder (sample_esmdiff.py:40-61; 30 blocks, d 1280) with the same trained statistics put on its weights —
+    LayerNorm gains up to 30 on a few channels of every norm, eight FFN units per block with 50x row norm (columns of ffn.3
+    compensated), four embedding channels at +-500: the float32 decoder and the float32-grade `f32_split` decoder (whose FFN mid
+    rows are split with their own scale since r05) both keep the backbone within north_star's 1e-4 A of the float32 oracle."""
+    import math
+    from esmdiff_amd.config import DecoderConfig
+    from esmdiff_amd.engine import StructureDecoder
+    from esmdiff_amd.weights import random_init_decoder_state_dict
+    from oracle.decoder_ref import build_decoder_from_state_dict
+    from oracle.geom_ref import backbone_rmsd
+    cfg = DecoderConfig()
+    sd = random_init_decoder_state_dict(cfg, seed=6, with_pairwise=False)
+    g = torch.Generator().manual_seed(77)
+    D, FH = cfg.d_model, cfg.ffn_hidden
+    for k in list(sd):
+        w = sd[k]
+        if w.dim() == 1 and w.numel() == D and k.endswith(".weight") and ("layernorm_qkv.0" in k or "q_ln" in k or "k_ln" in k or ".ffn.0." in k
+                                                                           or k == "decoder_stack.norm.weight"):
+            w = w.clone()
+            ch = torch.randperm(D, generator=g)[:12]
+            w[ch] = torch.exp(torch.rand(12, generator=g) * math.log(6.0) + math.log(5.0))            # 5 .. 30
+            sd[k] = w
+    for i in range(cfg.n_layers):
+        b = f"decoder_stack.blocks.{i}."
+        rows = torch.randperm(FH, generator=g)[:8]
+        up = sd[b + "ffn.1.weight"].clone()
+        up[rows] *= 50.0
+        up[rows + FH] *= 50.0
+        sd[b + "ffn.1.weight"] = up
+        down = sd[b + "ffn.3.weight"].clone()
+        down[:, rows] /= 50.0 ** 1.5
+        sd[b + "ffn.3.weight"] = down
+    emb = sd["embed.weight"].clone()
+    ch = torch.randperm(D, generator=g)[:4]
+    emb[:, ch] = 500.0 * torch.where(torch.rand(4, generator=g) < 0.5, -1.0, 1.0) + 10.0 * torch.randn(emb.shape[0], 4, generator=g)
+    sd["embed.weight"] = emb
+    ref_net = build_decoder_from_state_dict(cfg, sd)
+    B, L = 2, 130
+    tok = torch.randint(0, 4096, (B, L), generator=g)
+    tok[:, 0], tok[:, -1] = 4098, 4097
+    with torch.no_grad():
+        ref, pl_ref = ref_net(tok, return_plddt=True)
+    rec = {"coord_abs_max_A": float(ref.abs().max())}
+    for prec in ("f32", "f32_split"):
+        dec = StructureDecoder(cfg, sd, max_batch=B, max_len=L, precision=prec)
+        got, pl = dec.decode(tok.cuda(), return_plddt=True)
+        dec.close()
+        rec[prec] = {"rmsd_aligned_A": [float(v) for v in backbone_rmsd(got.cpu(), ref)], "finite": bool(torch.isfinite(got).all()),
+                     "max_atom_dev_A": float((got.cpu() - ref).norm(dim=-1).max()), "plddt_err": float((pl.cpu() - pl_ref).abs().max())}
+    _record("structure_decoder_30_blocks", rec)
+    for prec in ("f32", "f32_split"):
+        assert rec[prec]["finite"] and max(rec[prec]["rmsd_aligned_A"]) <= 1e-4 and rec[prec]["max_atom_dev_A"] <= 1e-3, (prec, rec)
+        assert rec[prec]["plddt_err"] < 1e-4, (prec, rec)
