@@ -647,3 +647,33 @@ def test_bf16_logit_error_decomposition_body_vs_head():
     assert abs(tot2 - sum2) < 0.15 * tot2, rec
     assert 0.5 < b["head_share_of_error_variance"] < 0.8, rec                      # measured 0.64
     assert rec["f16"]["total_vs_ref"]["rms_masked_rows"] < b["total_vs_ref"]["rms_masked_rows"] / 5, rec   # 1/8 of the operand rounding
+
+
+def test_dispatch_plan_and_build_info_say_what_runs():
+    """esmdiff_describe_plan / esmdiff_get_build_info (ABI 7; the CLI prints both beside "Sampling token time"): at configs[1]'s
+    size the bf16 engine runs two sub-batch streams of 12 900 rows on the regular path with the 256 x 256 four-wave GEMM for all
+    four block linears; at configs[0]'s size one stream on the small-batch path; the F32_SPLIT engine says so; the option setter
+    moves the plan and nothing else reads the environment (a product build says debug_env=0)."""
+    from esmdiff_amd import _native as N
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ModelConfig(n_layers=1)
+    sd = random_init_state_dict(cfg, seed=0, device="cuda")
+    eng = Engine(cfg, sd, max_batch=100, max_len=258)
+    big, small = eng.describe_plan(100, 258), eng.describe_plan(4, 60)
+    assert "precision=bf16" in big and "streams=2" in big and "rows_per_stream=12900" in big and "path=regular" in big, big
+    for lin in ("qkv", "out", "ffn_up", "ffn_down"):
+        assert f"gemm[{lin}]=256x256w4" in big, big
+    assert "streams=1" in small and "path=small-batch" in small and "gemm[out]=128x*/S4" in small and "gemm[ffn_down]=128x*/S8" in small, small
+    eng.set_streams(1)
+    assert "streams=1" in eng.describe_plan(100, 258) and "rows_per_stream=25800" in eng.describe_plan(100, 258)
+    with pytest.raises(RuntimeError, match="1 .. 4"):
+        eng.set_streams(7)
+    eng.close()
+    sp = Engine(cfg, sd, max_batch=100, max_len=258, precision="f32_split")
+    plan = sp.describe_plan(100, 258)
+    assert "precision=f32_split" in plan and "head=f32-grade" in plan and "streams=2" in plan and "k_sliced_small_batches=0" in plan, plan
+    sp.close()
+    info = N.build_info()
+    assert "abi=7" in info and "debug_env=0" in info, info
