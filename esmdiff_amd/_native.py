@@ -36,6 +36,8 @@ class Weight(ctypes.Structure):
 
 # esmdiff_sample_step as a numpy record (one per sample; uploaded as raw bytes)
 SAMPLE_STEP_DTYPE = [("sample_index", "<u8"), ("move_chance_t", "<f4"), ("move_chance_s", "<f4"), ("step", "<i4"), ("final", "<i4")]
+# esmdiff_gibbs_sample_step
+GIBBS_STEP_DTYPE = [("sample_index", "<u8"), ("step", "<i4"), ("n_unmask", "<i4")]
 
 
 class Rng(ctypes.Structure):
@@ -54,7 +56,7 @@ EXPORTS = [
     "esmdiff_set_gibbs_options", "esmdiff_split_rows", "esmdiff_split_weight", "esmdiff_gemm_split",
     "esmdiff_get_embeddings", "esmdiff_set_final_skip", "esmdiff_gemm_f16", "esmdiff_ddpm_step_margin", "esmdiff_forward_logits_sigmas", "esmdiff_set_small_batch_splitk",
     "esmdiff_ddpm_step_rows", "esmdiff_logit_error_stats", "esmdiff_get_build_info", "esmdiff_describe_plan", "esmdiff_set_option",
-    "esmdiff_get_sequence_logits",
+    "esmdiff_get_sequence_logits", "esmdiff_gibbs_step_rows", "esmdiff_shared_forward_batch",
 ]
 OPT_STREAMS, OPT_DUAL_MIN_TOKENS = 1, 2      # esmdiff_option
 
@@ -94,7 +96,8 @@ def lib():
     L.esmdiff_ddpm_step_margin.argtypes = [vp, vp, vp, i32, f32, f32, i32, ctypes.POINTER(Rng), i32, i32, i32, f32, vp, vp]
     L.esmdiff_ddpm_step_margin.restype = ctypes.c_int
     L.esmdiff_ddpm_step_rows.argtypes = [vp, vp, vp, i32, vp, ctypes.c_uint64, i32, i32, f32, f32, vp, vp, vp]
-    L.esmdiff_logit_error_stats.argtypes = [vp, i32, vp, i32, vp, i32, i32, vp, vp]
+    L.esmdiff_logit_error_stats.argtypes = [vp, i32, vp, i32, vp, i32, i32, i32, vp, vp]
+    L.esmdiff_gibbs_step_rows.argtypes = [vp, vp, vp, vp, i32, f32, f32, vp, ctypes.c_uint64, i32, i32, f32, f32, vp, vp, vp]
     L.esmdiff_get_build_info.argtypes = [ctypes.c_char_p, i32]
     L.esmdiff_describe_plan.argtypes = [vp, i32, i32, ctypes.c_char_p, i32]
     L.esmdiff_set_option.argtypes = [vp, i32, ctypes.c_int64]
@@ -131,6 +134,7 @@ def lib():
     L.esmdiff_encoder_encode.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, vp]
     L.esmdiff_set_gibbs_options.argtypes = [vp, i32, ctypes.POINTER(i32), i32]
     L.esmdiff_set_step0_sharing.argtypes = [vp, i32]
+    L.esmdiff_shared_forward_batch.argtypes = [vp, i32, i32]
     L.esmdiff_set_final_skip.argtypes = [vp, i32]
     L.esmdiff_set_small_batch_splitk.argtypes = [vp, i32]
     L.esmdiff_get_counters.argtypes = [vp, c_i64p, c_i64p, i32]
@@ -144,7 +148,7 @@ def lib():
     for n in EXPORTS:
         if n not in ("esmdiff_engine_destroy", "esmdiff_last_error", "esmdiff_encoder_destroy", "esmdiff_encoder_last_error"):
             getattr(L, n).restype = ctypes.c_int
-    if L.esmdiff_abi_version() != 7:
+    if L.esmdiff_abi_version() != 8:
         raise RuntimeError("libesmdiff_hip.so ABI version mismatch")
     _lib = L
     return L

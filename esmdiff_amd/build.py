@@ -55,9 +55,24 @@ def _hipcc() -> str:
     return "hipcc"
 
 
+HEADERS = [INCLUDE / "esmdiff_hip.h", INCLUDE / "esmdiff_hip_test.h"]
+
+
 def _newest_src() -> float:
-    files = list(CSRC.glob("*")) + [INCLUDE / "esmdiff_hip.h", Path(__file__)]
+    files = list(CSRC.glob("*")) + HEADERS + [Path(__file__)]
     return max(f.stat().st_mtime for f in files)
+
+
+def _write_export_map(path: Path) -> None:
+    """The dynamic symbol table holds the C ABI and nothing else: every `esmdiff_*` function the two headers declare is global,
+    everything else (the C++ launchers of both operand-type namespaces, template instantiations, the HIP registration
+    helpers) is local to the library.  tests/test_host_cpu.py checks `nm -D`."""
+    import re
+    names = set()
+    for h in HEADERS:
+        names |= set(re.findall(r"\b(esmdiff_[a-z0-9_]+)\s*\(", h.read_text()))
+    names -= {"esmdiff_gemm_epilogue"}
+    path.write_text("{\n  global:\n" + "".join(f"    {n};\n" for n in sorted(names)) + "  local:\n    *;\n};\n")
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
@@ -70,7 +85,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if LIB.exists() and not force and LIB.stat().st_mtime >= _newest_src():
         return LIB
     cc = _hipcc()
-    headers = [p.stat().st_mtime for p in list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + [INCLUDE / "esmdiff_hip.h"]]
+    headers = [p.stat().st_mtime for p in list(CSRC.glob("*.h")) + list(CSRC.glob("*.inc")) + HEADERS]
 
     def compile_one(job):
         name, f16 = job
@@ -89,7 +104,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             if verbose and err.strip():
                 print(f"[{name}] {err}", file=sys.stderr)
     objs = [str(OBJDIR / f"{n}.o") for n in UNITS] + [str(OBJDIR / f"{n}_f16.o") for n in F16_UNITS]
-    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", str(LIB)],
+    emap = OBJDIR / "exports.map"
+    _write_export_map(emap)
+    r = subprocess.run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={emap}", *objs, "-o", str(LIB)],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -1,55 +1,59 @@
-"""Certified sampling: the ids of the f32-grade chain at close to the reduced-precision engine's speed.
+"""Certified sampling: the ids of the f32-grade chain at close to the reduced-precision engine's speed, for both sampling
+modes of the CLI (ddpm: /root/reference/slm/models/model.py:543-607; gibbs: /root/reference/slm/sample_esmdiff.py:66-130, the
+reference's default).
 
-The state of the ancestral sampler (model.py:543-581) between two updates is a matrix of token ids, so a rounding error of
-the network does not accumulate from update to update: as long as every draw of an update came out the same, the next
-update starts from the identical input.  A draw is an arg-max of q_v / g_v (model.py:24-28) with q_v = exp(z_v - lse) *
-(mc_t - mc_s), or mc_s for the mask column.  Between two tokens the logsumexp cancels, so the log of the ratio of two
-candidates moves by the error of the logit DIFFERENCE z_a - z_b; against the mask column it moves by the error of
-z_a - lse, and lse is a convex combination of the logits (the common part of the error cancels there too).  If that pair
-error is at most P = 2 eps, a winner that beats the runner-up by more than the factor exp(2 eps) is the winner for the
-f32-grade logits as well.  The sampler kernel reports, per sample, whether all of its draws were that clear
-(esmdiff_ddpm_step_rows, csrc/sampler.hip).
+The state of either sampler between two updates is a matrix of token ids, so a rounding error of the network does not
+accumulate from update to update: as long as every decision of an update came out the same, the next update starts from the
+identical input.  What an update decides, and what can move it:
 
-What happens to a sample with a close call (r05: speculative, batched, audited).  The samples of a batch are independent
-(model.py:583-607 is row-wise), so nothing forces a flagged sample to be settled in the update it was flagged in:
+  ddpm    a draw is an arg-max of q_v / g_v (model.py:24-28) with q_v = exp(z_v - lse) * (mc_t - mc_s), or mc_s for the mask
+          column.  Between two tokens the logsumexp cancels, so the log of the ratio of two candidates moves by the error of the
+          logit DIFFERENCE z_a - z_b; against the mask column it moves by the error of z_a - lse, and lse is a convex combination
+          of the logits.  Both are at most the RANGE of the row's logit error, max e - min e.  If that is at most P, a winner that
+          beats the runner-up by more than the factor exp(P) is the winner for the f32-grade logits as well
+          (esmdiff_ddpm_step_rows, csrc/sampler.hip).
+  gibbs   three decisions per step (esm's iterative_sampling_raw): the nucleus cut (a token's membership
+          moves only if the cumulative mass at it is within the factor exp(+-P) of top_p, or a token within P of it changes
+          sides), the temperature race among the kept tokens (as above, with P / temperature), and which k positions have the
+          lowest entropy (moves only if the k-th and the (k+1)-th entropy are within 2 E, E a bound on the entropy error).  Only
+          the rows a prompt unmasks in this step count.  esmdiff_gibbs_step_rows (csrc/gibbs.hip) reports all three per prompt.
+
+What happens to a sample with a close call (speculative, batched, audited).  The samples of a batch are independent, so nothing
+forces a flagged sample to be settled in the update it was flagged in:
 
   fast lane   every sample carries its own update counter; one reduced-precision forward per iteration advances all unfinished
-              samples (one sigma per sample, esmdiff_forward_logits_sigmas), flagged or not — a flagged sample CONTINUES on its
-              fast ids, speculatively.  Nothing in the lane waits for the host: flags come back through pinned memory one
+              samples (ddpm: one sigma per sample, esmdiff_forward_logits_sigmas), flagged or not — a flagged sample CONTINUES on
+              its fast ids, speculatively.  Nothing in the lane waits for the host: flags come back through pinned memory one
               iteration late, while the GPU is already inside the next forward.
   slow lane   a flagged sample-update (tokens before, fast tokens after, fast logits) is queued; when `verify_batch` of them
-              have gathered they are evaluated in ONE f32-grade forward — each at its own sigma — and drawn again with their own
-              Philox keys (per-sample step parameters).  Equal ids (almost always: the flag says "could differ", ~1 in 12
-              does) confirm the speculation.  Different ids roll that sample back: its tokens become the f32-grade ones after
-              that update, its counter is set behind it, everything it did since is discarded (an epoch number per sample
-              marks stale flags and queue entries), and it catches up in the following fast forwards.
-  audit       a random `audit_rate` of the UNFLAGGED sample-updates goes through the same verification.  An audit whose ids
-              differ is a certification miss: counted (`audit_mismatches`), repaired by the same roll-back, and its error
-              raises eps.  stats carries audit_checked / audit_mismatches / audit_max_logit_err / audit_max_pair_err.
+              have gathered they are evaluated in ONE f32-grade forward and drawn again with their own Philox keys (per-sample
+              step parameters).  Equal ids (almost always) confirm the speculation.  Different ids roll that sample back: its
+              tokens become the f32-grade ones after that update, its counter is set behind it, everything it did since is
+              discarded (an epoch number per sample marks stale flags and queue entries), and it catches up in the following
+              fast forwards.
+  audit       a random share of the UNFLAGGED sample-updates goes through the same verification: `audit_rate` (2 %) until
+              `audit_clean_target` (500) audits in a row were clean, `audit_rate_steady` (0.5 %) from then on; a mismatch starts
+              the count again.  An audit whose ids differ is a certification miss: counted (`audit_mismatches`), repaired by the
+              same roll-back, and its error raises the bounds.
 
-`eps` (eps=None, the default) is chosen from the error DISTRIBUTION, not from a maximum: every verified item yields both
-engines' logits for the same input, esmdiff_logit_error_stats reduces them per token row to the r.m.s. and the maximum of the
-logit error e_v and of the pair error d_v = e_v - e_(v+1) (4 099 pairs per masked row).  Within one row the errors are the
-projections of ONE hidden-state error onto 4 101 head rows — Gaussian-like with a scale that belongs to the row — so the
-statistic is the per-row r.m.s., and the bound takes the largest one seen (a pooled r.m.s. is a scale mixture: on weights with
-trained statistics its tail reached 7 sigma, per row it stays at 5-5.5).  The pair bound in use is
+The bounds come from the MEASURED error of this engine pair, not from a model of it: every verified item yields both engines'
+logits for the same input; esmdiff_logit_error_stats reduces them per token row to the maximum and r.m.s. of the logit error e,
+of the neighbouring-pair error d_v = e_v - e_(v+1), the row's range max e - min e, and the entropy error.  The pair that decides
+a draw is arbitrary (winner and runner-up of a noisy race), so the bound in use is
 
-    P = max(k_sigma * (largest per-row r.m.s. of d seen so far), max_factor * (largest |d| seen so far)),   eps = P / 2
+    P = max(k_sigma * (largest per-row r.m.s. of d seen), max_factor * (largest row RANGE seen))          (eps = P / 2)
+    E = max(k_sigma * (largest per-item r.m.s. of the entropy error seen), max_factor * (largest entropy error seen))
 
-Measured at configs[1] (f16 body + f32-grade head against F32_SPLIT): sigma_d = 3.1e-4, the largest |d| of ~1e6 pairs per item
-sits at 5.3-5.7 sigma, as a Gaussian's does.  With k_sigma = 6 on the LARGEST row sigma (3.6e-4; the typical row's is 15 % smaller)
-and Gaussian pair errors a draw whose gap is just outside the flagged band flips with probability <= 2 Q(6) = 2e-9; integrated
-over the gap density rho (0.13 per unit log gap and masked row, measured: stats["rerun_share_vs_eps"]) the miss probability is
-<= 4 rho sigma_d phi(k) / k^2 ~ 3e-14 per draw, ~1e-8 per 100-sample job of 335 000 draws — and the audit watches the assumption.  (r04 used 2 x the largest |e| = ~16 sigma_d: 2.5x the
-re-runs for no measurable gain in safety; its rule is still available as a fixed `eps`.)  Until `n_boot` items have been seen the bound is
-widened by `boot_factor` and at least two samples per update are audited; the very first call starts from a probe of two samples
-on both engines.  A verified item whose largest |d| exceeds the P its update was certified with is an `eps_violation`; it raises
-P for everything that follows (also when eps is fixed).
+widened by `boot_factor` until `n_boot` items have been seen; while NOTHING has been seen every sample-update is verified.  A
+verified item whose range exceeds the P its update was certified with (or whose entropy error exceeds E) is a `violation`; it
+raises the bound for everything that follows (also when eps is fixed).  The certificate is STATISTICAL: "k-sigma of the
+measured error distribution + audit".  What it asserts is checked by measurement — job-level equality with the f32-grade
+chain over many seeds (profiles/r06_certified_soak.txt: a rule-of-three bound) and the audit counters of every run — not by a
+probability derived from a Gaussian model.
 
-The result is "the f32-grade engine's chain unless a pair error exceeded P on an unflagged, unaudited draw".  The F32_SPLIT
-engine's logits do not depend on the batch a sample is evaluated in, so with it as `exact` the certified chain IS that
-engine's chain, id for id (tests/test_gpu_strict.py, profiles/r05_certified_soak.txt).  No reference counterpart — the
-reference has one precision.
+The result is "the f32-grade engine's chain unless an error exceeded the bounds on an unflagged, unaudited decision".  The
+F32_SPLIT engine's logits do not depend on the batch a sample is evaluated in, so with it as `exact` the certified chain IS
+that engine's chain, id for id (tests/test_gpu_strict.py).  No reference counterpart — the reference has one precision.
 """
 from __future__ import annotations
 
@@ -64,7 +68,11 @@ from .engine import Engine
 from .schedule import DDPMSchedule
 from .constants import STRUCTURE_MASK_TOKEN
 
-_GAP_GRID = (0.25, 0.5, 1.0, 2.0, 4.0)      # stats["rerun_share_vs_eps"]: multiples of the eps in use
+_GAP_GRID = (0.25, 0.5, 1.0, 2.0, 4.0)      # stats["rerun_share_vs_eps"]: multiples of the bound in use
+CERTIFICATE = "k-sigma statistical + audit"
+
+# columns of the per-item statistics (one row per verified sample-update)
+_ME, _SE, _MD, _SD, _ROWS, _SDROW, _RANGE, _MDH, _SDH = range(9)
 
 
 class _Async:
@@ -85,72 +93,201 @@ class _Async:
         return self.host.numpy()
 
 
+class _DdpmRule:
+    """model.py:543-607 as the loop sees it: T updates + the noise-removal pass; a sample without a MASK is complete."""
+    mode, all_columns, track_mask, n_gaps = "ddpm", False, True, 1
+
+    def __init__(self, sampler, schedule: DDPMSchedule, B: int, dev):
+        fast, exact = sampler.fast, sampler.exact
+        self.T = T = schedule.num_steps
+        self.total = np.full(B, T + 1, dtype=np.int64)             # updates per sample; the last one is the noise removal
+        tf_f, tf_e = fast.conditioning_rows(schedule.t_freq), exact.conditioning_rows(schedule.t_freq)
+        self.tf = {id(fast): None if tf_f is None else tf_f.to(device=dev, dtype=torch.float32).contiguous(),
+                   id(exact): None if tf_e is None else tf_e.to(device=dev, dtype=torch.float32).contiguous()}
+        self.mc_t = np.array([float(schedule.mc_t[i]) for i in range(T)] + [0.0], dtype=np.float32)
+        self.mc_s = np.array([float(schedule.mc_s[i]) for i in range(T)] + [0.0], dtype=np.float32)
+
+    def skip_empty(self, step: np.ndarray) -> None:
+        pass
+
+    def cond(self, eng, steps: np.ndarray, steps_dev):
+        tf = self.tf[id(eng)]
+        if tf is None:
+            return None
+        return tf[int(steps[0])] if steps_dev is None else tf[steps_dev]
+
+    def wants_steps_on_device(self, eng) -> bool:
+        return self.tf[id(eng)] is not None
+
+    def before_forward(self, eng, idx_dev) -> None:
+        pass
+
+    def params(self, eng, sample_ids: np.ndarray, steps: np.ndarray) -> np.ndarray:
+        return eng.sample_step_params_host(sample_ids, self.mc_t[steps], self.mc_s[steps], steps, (steps == self.T).astype(np.int32))
+
+    def draw(self, eng, x, seq, lg, par, seed, bounds=None, flags=None, gaps=None):
+        if bounds is None:
+            eng.ddpm_step_rows(x, lg, par, seed=seed)
+        else:
+            eng.ddpm_step_rows(x, lg, par, seed=seed, eps=0.5 * bounds[0], flags=flags, gaps=gaps.reshape(-1))
+
+    def gap_units(self, bounds):
+        return (bounds[0],)
+
+    def shared_first_draw(self, eng, x, lg_one, seed, sample_offset, c0, n):
+        raise NotImplementedError
+
+
+class _GibbsRule:
+    """esm's iterative_sampling_raw as the loop sees it: prompt s runs total[s] = min(num_steps, #masked) steps and unmasks
+    table[t, s] positions at step t; no time conditioning; optional per-prompt backbone frames (geometric attention)."""
+    mode, all_columns, track_mask, n_gaps = "gibbs", True, False, 2
+
+    def __init__(self, sampler, table: torch.Tensor, temperature: float, top_p: float, frames, dev):
+        self.table = table.detach().to("cpu", torch.int32).numpy()        # (T, B)
+        T, B = self.table.shape
+        nz = self.table > 0
+        self.total = np.where(nz.any(0), T - np.argmax(nz[::-1], 0), 0).astype(np.int64)   # index of the last unmasking step + 1
+        self.temperature, self.top_p = float(temperature), float(top_p)
+        self.frames = None if frames is None else tuple(f.to(dev) for f in frames)
+        self.engines = (sampler.fast, sampler.exact)
+
+    def skip_empty(self, step: np.ndarray) -> None:
+        """A step that unmasks nothing changes nothing (the plain loop still runs its forward; the ids cannot depend on it)."""
+        T, B = self.table.shape
+        for s in range(B):
+            while step[s] < self.total[s] and self.table[step[s], s] <= 0:
+                step[s] += 1
+
+    def cond(self, eng, steps, steps_dev):
+        return None
+
+    def wants_steps_on_device(self, eng) -> bool:
+        return False
+
+    def before_forward(self, eng, idx_dev) -> None:
+        if self.frames is not None:
+            eng.set_frames(*(self.frames if idx_dev is None else tuple(f[idx_dev] for f in self.frames)))
+
+    def params(self, eng, sample_ids: np.ndarray, steps: np.ndarray, local_ids: Optional[np.ndarray] = None) -> np.ndarray:
+        ks = self.table[np.minimum(steps, self.table.shape[0] - 1), local_ids]
+        return eng.gibbs_step_params_host(sample_ids, steps, np.where(steps < self.total[local_ids], ks, 0))
+
+    def draw(self, eng, x, seq, lg, par, seed, bounds=None, flags=None, gaps=None):
+        if bounds is None:
+            eng.gibbs_step_rows(x, seq, lg, self.temperature, self.top_p, par, seed=seed)
+        else:
+            eng.gibbs_step_rows(x, seq, lg, self.temperature, self.top_p, par, seed=seed, pair_bound=bounds[0],
+                                entropy_bound=bounds[1], flags=flags, gaps=gaps)
+
+    def gap_units(self, bounds):
+        return (bounds[0], 2.0 * bounds[1])
+
+    def finish(self) -> None:
+        if self.frames is not None:
+            for eng in self.engines:
+                eng.set_frames(None)
+
+
 class CertifiedSampler:
     """fast: a reduced-precision Engine (f16 with the f32-grade head recommended: its logit error is 8x below bf16's, so 8x
     fewer close calls); exact: an f32-grade Engine of the same checkpoint (precision 'f32_split' or 'f32')."""
 
     def __init__(self, fast: Engine, exact: Engine, eps: Optional[float] = None, *, k_sigma: float = 6.0,
                  max_factor: float = 1.05, eps_floor: float = 1e-5, audit_rate: float = 0.02, verify_batch: int = 32,
-                 n_boot: int = 8, boot_factor: float = 1.5, audit_seed: int = 0):
+                 n_boot: int = 8, boot_factor: float = 1.5, audit_seed: int = 0, audit_rate_steady: Optional[float] = None,
+                 audit_clean_target: int = 500, entropy_eps: Optional[float] = None):
         if fast.device != exact.device:
             raise ValueError("both engines must live on the same GPU")
         if eps is not None and not eps > 0:
             raise ValueError("eps must be positive")
+        if entropy_eps is not None and not entropy_eps > 0:
+            raise ValueError("entropy_eps must be positive")
         if not k_sigma > 0 or not max_factor >= 1.0 or not boot_factor >= 1.0:
             raise ValueError("k_sigma must be positive, max_factor and boot_factor >= 1")
-        if not 0.0 <= audit_rate <= 1.0:
+        if not 0.0 <= audit_rate <= 1.0 or (audit_rate_steady is not None and not 0.0 <= audit_rate_steady <= 1.0):
             raise ValueError("audit_rate must be in [0, 1]")
         if verify_batch < 1:
             raise ValueError("verify_batch must be >= 1")
         self.fast, self.exact = fast, exact
         self.eps = None if eps is None else float(eps)          # None: from the error distribution (module docstring)
+        self.entropy_eps = None if entropy_eps is None else float(entropy_eps)
         self.k_sigma, self.max_factor, self.eps_floor = float(k_sigma), float(max_factor), float(eps_floor)
         self.audit_rate, self.verify_batch = float(audit_rate), int(verify_batch)
+        # the steady rate applies once audit_clean_target audits in a row were clean (all calls of this engine pair)
+        self.audit_rate_steady = min(self.audit_rate, 0.005) if audit_rate_steady is None else float(audit_rate_steady)
+        self.audit_clean_target, self.audit_clean_run = int(audit_clean_target), 0
         self.n_boot, self.boot_factor = int(n_boot), float(boot_factor)
         self._audit_rng = np.random.default_rng(audit_seed)
-        # running error estimate of this engine pair (all calls): per-item r.m.s. and maxima
-        self.sigma_d_seen = 0.0      # largest per-ROW r.m.s. of the pair error d (what k_sigma multiplies)
+        # running error estimate of this engine pair (all calls, both modes): per-item r.m.s. and maxima
+        self.sigma_d_seen = 0.0      # largest per-ROW r.m.s. of the neighbouring-pair error d (what k_sigma multiplies)
         self.sigma_d_item_seen = 0.0 # largest per-item (sample-update) r.m.s. of d, for the reports
         self.sigma_e_seen = 0.0      # largest per-item r.m.s. of the logit error e
         self.max_d_seen = 0.0
+        self.range_seen = 0.0        # largest per-row max e - min e: the bound on the error of ANY pair's difference
         self.err_seen = 0.0          # largest |e| (r04's statistic, kept for the reports)
+        self.sigma_h_seen = 0.0      # largest per-item r.m.s. of the entropy error
+        self.max_dh_seen = 0.0       # largest entropy error
         self.n_seen = 0              # verified items the estimate rests on
         self.pair_raise = 0.0        # pair bound forced by violations (also with a fixed eps)
+        self.entropy_raise = 0.0
         self.stats: dict = {}
 
-    # ---- eps ------------------------------------------------------------------------------------------------------------
+    # ---- bounds -----------------------------------------------------------------------------------------------------------
     def pair_bound(self) -> float:
         """P: the bound on the error of a logit difference the next update is certified with (= 2 eps)."""
         if self.eps is not None:
             return max(2.0 * self.eps, self.pair_raise)
-        p = max(self.k_sigma * self.sigma_d_seen, self.max_factor * self.max_d_seen)
+        p = max(self.k_sigma * self.sigma_d_seen, self.max_factor * self.range_seen)
         if self.n_seen < self.n_boot:
             p *= self.boot_factor
         return max(p, self.pair_raise, 2.0 * self.eps_floor)
 
+    def entropy_bound(self) -> float:
+        """E: the bound on the error of a row's entropy (gibbs mode: the order of the positions)."""
+        if self.entropy_eps is not None:
+            return max(self.entropy_eps, self.entropy_raise)
+        e = max(self.k_sigma * self.sigma_h_seen, self.max_factor * self.max_dh_seen)
+        if self.n_seen < self.n_boot:
+            e *= self.boot_factor
+        return max(e, self.entropy_raise, 1e-7)
+
     def _eps_now(self) -> float:
         return 0.5 * self.pair_bound()
 
+    def _audit_rate_now(self) -> float:
+        return self.audit_rate_steady if self.audit_clean_run >= self.audit_clean_target else self.audit_rate
+
+    def _blind(self, gibbs: bool = False) -> bool:
+        """No verified item yet and a bound is to come from them: nothing can be certified, every sample-update is verified."""
+        return self.n_seen == 0 and (self.eps is None or (gibbs and self.entropy_eps is None))
+
     def _observe_items(self, st: np.ndarray, V: int) -> None:
-        """st (n, 6): per item max |e|, sum e^2, max |d|, sum d^2, masked rows, largest per-row sum d^2."""
-        for me, se, md, sd, rows, sd_row in st:
+        """st (n, >= 9): per item max |e|, sum e^2, max |d|, sum d^2, masked rows, largest per-row sum d^2, largest row range,
+        largest |entropy error|, sum of its squares."""
+        for it in st:
+            rows = it[_ROWS]
             if rows <= 0:
                 continue
             self.n_seen += 1
-            self.err_seen = max(self.err_seen, float(me))
-            self.max_d_seen = max(self.max_d_seen, float(md))
-            self.sigma_e_seen = max(self.sigma_e_seen, math.sqrt(float(se) / (rows * (V - 1))))
-            self.sigma_d_item_seen = max(self.sigma_d_item_seen, math.sqrt(float(sd) / (rows * (V - 2))))
-            self.sigma_d_seen = max(self.sigma_d_seen, math.sqrt(float(sd_row) / (V - 2)))
+            self.err_seen = max(self.err_seen, float(it[_ME]))
+            self.max_d_seen = max(self.max_d_seen, float(it[_MD]))
+            self.range_seen = max(self.range_seen, float(it[_RANGE]))
+            self.sigma_e_seen = max(self.sigma_e_seen, math.sqrt(float(it[_SE]) / (rows * (V - 1))))
+            self.sigma_d_item_seen = max(self.sigma_d_item_seen, math.sqrt(float(it[_SD]) / (rows * (V - 2))))
+            self.sigma_d_seen = max(self.sigma_d_seen, math.sqrt(float(it[_SDROW]) / (V - 2)))
+            self.max_dh_seen = max(self.max_dh_seen, float(it[_MDH]))
+            self.sigma_h_seen = max(self.sigma_h_seen, math.sqrt(float(it[_SDH]) / rows))
 
-    def _item_stats(self, lg_fast: torch.Tensor, lg_exact: torch.Tensor, x_in: torch.Tensor) -> torch.Tensor:
-        """(n, 6) on the device: max |e|, sum e^2, max |d|, sum d^2, masked rows, largest per-row sum d^2 — per sample over its
-        masked rows."""
-        st = self.exact.logit_error_stats(lg_fast, lg_exact, x_in)
+    def _item_stats(self, lg_fast: torch.Tensor, lg_exact: torch.Tensor, x_in: torch.Tensor, all_columns: bool) -> torch.Tensor:
+        """(n, 9) on the device, per sample over its masked rows (column order: _ME .. _SDH)."""
+        st = self.exact.logit_error_stats(lg_fast, lg_exact, x_in, all_columns)
         rows = (x_in == STRUCTURE_MASK_TOKEN).sum(1).to(torch.float32)
-        return torch.stack([st[..., 0].amax(1), st[..., 1].sum(1), st[..., 2].amax(1), st[..., 3].sum(1), rows, st[..., 3].amax(1)], 1)
+        dh = st[..., 5]
+        return torch.stack([st[..., 0].amax(1), st[..., 1].sum(1), st[..., 2].amax(1), st[..., 3].sum(1), rows, st[..., 3].amax(1),
+                            st[..., 4].amax(1), dh.abs().amax(1), (dh * dh).sum(1)], 1)
 
-    # ---- the loop ---------------------------------------------------------------------------------------------------------
+    # ---- the two entry points ---------------------------------------------------------------------------------------------
     @torch.no_grad()
     def ddpm_sample(self, sequence_tokens: torch.Tensor, schedule: DDPMSchedule, *, seed: int, sample_offset: int = 0,
                     input_prior: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -159,30 +296,61 @@ class CertifiedSampler:
         fast forward takes the fast.max_batch unfinished samples with the lowest indices, so a sample that was rolled back
         rides along with later ones instead of leaving the GPU with a tail of one-sample forwards.  Ids do not depend on the
         lane width (Philox is keyed by the global sample index)."""
-        import time
-        fast, exact = self.fast, self.exact
         B, L = sequence_tokens.shape
-        W = min(B, fast.max_batch)                                 # lane width: samples per fast forward
-        t_call = time.perf_counter()
-        dev = fast.device
-        MASK = STRUCTURE_MASK_TOKEN
+        dev = self.fast.device
         seq = sequence_tokens.to(device=dev, dtype=torch.int64).contiguous()
         if input_prior is None:
-            x = torch.full((B, L), MASK, dtype=torch.int64, device=dev)
+            x = torch.full((B, L), STRUCTURE_MASK_TOKEN, dtype=torch.int64, device=dev)
         else:
             if tuple(input_prior.shape) != (B, L):
                 raise ValueError(f"Invalid input_prior shape: {tuple(input_prior.shape)} v.s. (seq) {(B, L)}")
             x = input_prior.to(device=dev, dtype=torch.int64).contiguous().clone()
+        rule = _DdpmRule(self, schedule, B, dev)
+        identical = input_prior is None and B > 1 and schedule.num_steps > 0 and bool((seq == seq[:1]).all())
+        return self._run(rule, seq, x, seed, sample_offset, identical, known_masks=input_prior is not None or schedule.num_steps == 0)
+
+    @torch.no_grad()
+    def gibbs_sample(self, sequence_tokens: torch.Tensor, x0: torch.Tensor, n_unmask_table: torch.Tensor, temperature: float,
+                     top_p: float, *, seed: int, sample_offset: int = 0, frames=None) -> torch.Tensor:
+        """Same arguments and result layout as Engine.gibbs_sample (n_unmask_table (T, B) int32: positions to unmask per step and
+        prompt), plus `frames` = (rot (B, L, 3, 3), trans (B, L, 3), has_frame (B, L)) for coordinate conditioning (what
+        Engine.set_frames takes; the sampler hands every forward the frames of the prompts it runs).  GenerationConfig options
+        (strategy, invalid_ids) must have been set on BOTH engines.  self.stats describes the call; more prompts than
+        fast.max_batch are streamed as in ddpm_sample."""
+        B, L = sequence_tokens.shape
+        dev = self.fast.device
+        seq = sequence_tokens.to(device=dev, dtype=torch.int64).contiguous()
+        if tuple(x0.shape) != (B, L):
+            raise ValueError(f"Invalid x0 shape: {tuple(x0.shape)} v.s. (seq) {(B, L)}")
+        x = x0.to(device=dev, dtype=torch.int64).contiguous().clone()
+        tab = torch.as_tensor(n_unmask_table)
+        if tab.dim() != 2 or tab.shape[1] != B:
+            raise ValueError(f"n_unmask_table must be (T, B = {B}), got {tuple(tab.shape)}")
+        rule = _GibbsRule(self, tab, temperature, top_p, frames, dev)
+        identical = B > 1 and bool((seq == seq[:1]).all()) and bool((x == x[:1]).all()) and bool((tab == tab[:, :1]).all()) and \
+            (rule.frames is None or all(bool((f == f[:1]).all()) for f in rule.frames))
+        try:
+            return self._run(rule, seq, x, seed, sample_offset, identical, known_masks=True)
+        finally:
+            rule.finish()
+
+    # ---- the loop ---------------------------------------------------------------------------------------------------------
+    def _run(self, rule, seq: torch.Tensor, x: torch.Tensor, seed: int, sample_offset: int, identical: bool,
+             known_masks: bool) -> torch.Tensor:
+        import time
+        fast, exact = self.fast, self.exact
+        B, L = seq.shape
+        W = min(B, fast.max_batch)                                 # lane width: samples per fast forward
+        t_call = time.perf_counter()
+        dev = fast.device
+        MASK = STRUCTURE_MASK_TOKEN
+        gibbs = rule.mode == "gibbs"
         if hasattr(fast, "_check_ids"):
             fast._check_ids(seq, x)                                # once: every later forward sees these ids or the kernels' own
-        T = schedule.num_steps
         V = exact.cfg.n_structure_heads
-        tf_fast = fast.conditioning_rows(schedule.t_freq)
-        tf_exact = exact.conditioning_rows(schedule.t_freq)
-        tf_fast_d = None if tf_fast is None else tf_fast.to(device=dev, dtype=torch.float32).contiguous()
-        tf_exact_d = None if tf_exact is None else tf_exact.to(device=dev, dtype=torch.float32).contiguous()
-        mc_t = np.array([float(schedule.mc_t[i]) for i in range(T)] + [0.0], dtype=np.float32)
-        mc_s = np.array([float(schedule.mc_s[i]) for i in range(T)] + [0.0], dtype=np.float32)
+        total = rule.total                                         # updates per sample
+        Tmax = int(total.max()) if B else 0
+        NG = rule.n_gaps
 
         ld = fast.ld_logits
         lbuf = [torch.empty(W, L, ld, dtype=torch.float32, device=dev) for _ in range(2)]     # fast logits, two updates in flight
@@ -191,53 +359,38 @@ class CertifiedSampler:
                   "lg": torch.empty(cap, L, ld, dtype=torch.float32, device=dev), "items": []} for _ in range(2)]
         fill = 0                                                   # index of the pool that is filling
 
-        step = np.zeros(B, dtype=np.int64)                         # next update of each sample (T = noise removal, T + 1 = done)
+        step = np.zeros(B, dtype=np.int64)                         # next update of each sample (total[s] = done)
         epoch = np.zeros(B, dtype=np.int64)
-        mask_known = np.zeros(B, dtype=bool)                       # is has_mask[s] valid for the sample's current state?
+        mask_known = np.zeros(B, dtype=bool)                       # ddpm: is has_mask[s] valid for the sample's current state?
         has_mask = np.ones(B, dtype=bool)
         updates: deque = deque()                                   # fast updates whose flags are still on their way
         verifies: deque = deque()
-        st = {"samples": B, "updates": T + 1, "fast_launches": 0, "verify_launches": 0, "verify_batch_sizes": [],
-              "flagged": 0, "audit_checked": 0, "audit_mismatches": 0, "audit_eps_violations": 0, "audit_max_logit_err": 0.0,
-              "audit_max_pair_err": 0.0, "corrections": 0, "eps_violations": 0, "rollback_updates_discarded": 0,
-              "sample_forwards_fast": 0, "sample_forwards_exact": 0, "max_logit_err_observed": 0.0, "max_pair_err_observed": 0.0,
-              "flagged_per_update": [0] * (T + 1), "eps_used": []}
-        gap_log: List[float] = []                                  # min gap of every live sample-update / the eps it ran with
+        st = {"mode": rule.mode, "certificate": CERTIFICATE, "samples": B, "updates": Tmax, "fast_launches": 0, "verify_launches": 0,
+              "verify_batch_sizes": [], "flagged": 0, "flag_reasons": {"race": 0, "nucleus": 0, "order": 0, "no_estimate": 0},
+              "audit_checked": 0, "audit_mismatches": 0, "audit_eps_violations": 0,
+              "audit_max_logit_err": 0.0, "audit_max_pair_err": 0.0, "audit_max_range_err": 0.0, "corrections": 0, "eps_violations": 0,
+              "entropy_violations": 0, "rollback_updates_discarded": 0, "sample_forwards_fast": 0, "sample_forwards_exact": 0,
+              "max_logit_err_observed": 0.0, "max_pair_err_observed": 0.0, "max_range_err_observed": 0.0,
+              "max_entropy_err_observed": 0.0, "flagged_per_update": [0] * max(Tmax, 1), "eps_used": [], "entropy_eps_used": []}
+        gap_log: List[List[float]] = [[] for _ in range(NG)]       # smallest gaps of every live sample-update / the bound they ran with
         timers: list = []                                          # (lane, start event, end event) of every forward + draw
 
-        def settle_final(s: int) -> None:
-            # a sample without a MASK is carried through every remaining update and through the noise removal unchanged
-            # (model.py:530-532, 575-579, 606-607): nothing left to run for it
-            if mask_known[s] and not has_mask[s]:
-                step[s] = T + 1
+        def runnable() -> np.ndarray:
+            if rule.track_mask:      # ddpm: the last update (noise removal) only for samples known to hold a MASK
+                return (step < total - 1) | ((step == total - 1) & mask_known & has_mask)
+            return step < total
 
-        # -- first update of a one-protein batch: identical inputs for every sample -> ONE f32-grade forward, nothing to certify
-        shared0 = input_prior is None and B > 1 and T > 0 and bool((seq == seq[:1]).all())
-        if input_prior is not None or T == 0:
+        def settle_final(s: int) -> None:
+            # ddpm: a sample without a MASK is carried through every remaining update and through the noise removal unchanged
+            # (model.py:530-532, 575-579, 606-607): nothing left to run for it
+            if rule.track_mask and mask_known[s] and not has_mask[s]:
+                step[s] = total[s]
+
+        if rule.track_mask and known_masks:
             has_mask[:], mask_known[:] = (x == MASK).any(1).cpu().numpy(), True
             for s in range(B):
                 settle_final(s)
-        if self.eps is None and self.n_seen == 0:
-            n = 1 if shared0 else min(2, B)                        # start the error estimate (first call of this engine pair)
-            t0 = None if tf_exact_d is None else tf_exact_d[0]
-            lg_e = exact.forward_logits(x[:n], seq[:n], t0)
-            lg_f = fast.forward_logits(x[:n], seq[:n], None if tf_fast_d is None else tf_fast_d[0])
-            self._observe_items(self._item_stats(lg_f, lg_e, x[:n]).cpu().numpy(), V)
-            st["sample_forwards_fast"] += n
-            st["sample_forwards_exact"] += n
-        if shared0:
-            lg1 = exact.forward_logits(x[:1], seq[:1], None if tf_exact_d is None else tf_exact_d[0])
-            lbuf[0][..., :V] = lg1
-            for c0 in range(0, B, W):
-                n = min(W, B - c0)
-                exact.ddpm_step(x[c0:c0 + n], lbuf[0][:n, :, :V], float(mc_t[0]), float(mc_s[0]), seed=seed,
-                                sample_offset=sample_offset + c0, step=0)
-            step[:] = 1
-            st["sample_forwards_exact"] += 1
-            if T == 1:
-                has_mask[:], mask_known[:] = (x == MASK).any(1).cpu().numpy(), True
-                for s in range(B):
-                    settle_final(s)
+        rule.skip_empty(step)
 
         def up(a: np.ndarray) -> torch.Tensor:
             """Host array -> device through pinned memory: never waits for the work already queued on the stream (a pageable
@@ -252,63 +405,109 @@ class CertifiedSampler:
             ev.record()
             return ev
 
+        def params(eng, local: np.ndarray, steps: np.ndarray) -> np.ndarray:
+            if gibbs:
+                return rule.params(eng, sample_offset + local, steps, local)
+            return rule.params(eng, sample_offset + local, steps)
+
+        # -- the error estimate of a new engine pair starts from a probe of samples that have something to decide
+        if self._blind(gibbs) and B:
+            cand = np.nonzero(step < total)[0]
+            cand = cand[:1] if identical else cand[:2]
+            if len(cand):
+                idx_d = up(cand)
+                xs, sq = x[idx_d], seq[idx_d]
+                steps0 = step[cand].copy()
+                outs = []
+                for eng in (exact, fast):
+                    rule.before_forward(eng, idx_d)
+                    sd = up(steps0) if (rule.wants_steps_on_device(eng) and len(cand) > 1) else None
+                    outs.append(eng.forward_logits(xs, sq, rule.cond(eng, steps0, sd)).clone())
+                self._observe_items(self._item_stats(outs[1], outs[0], xs, rule.all_columns).cpu().numpy(), V)
+                st["sample_forwards_fast"] += len(cand)
+                st["sample_forwards_exact"] += len(cand)
+
+        # -- identical inputs at the first update (the CLI repeats ONE protein): the fast forward of that update runs on a few
+        #    samples and serves all of them — each draws with its own noise, is flagged by the same rule and verified like any other
+        step_first = step.copy()
+        n_share = min(W, int(getattr(fast, "shared_forward_batch", lambda b, l: 1)(W, L))) if identical else 0
+        shared_lg: list = []                                       # the first update's logits of ONE sample, once computed
+
         def launch_fast(active: np.ndarray, which: int) -> None:
             n = len(active)
             full = n == B
             steps = step[active].copy()
             # every upload first: nothing below waits for the host
-            par = up(fast.sample_step_params_host(sample_offset + active, mc_t[steps], mc_s[steps], steps, (steps == T).astype(np.int32)))
+            par = up(params(fast, active, steps))
             mixed = not (steps == steps[0]).all()
-            steps_d = up(steps) if (mixed and tf_fast_d is not None) else None
+            steps_d = up(steps) if (mixed and rule.wants_steps_on_device(fast)) else None
+            idx_d = None if full else up(active)
             if full:
                 xa, sa = x, seq
             else:
-                idx_d = up(active)
                 xa, sa = x[idx_d], seq[idx_d]
             prev = xa.clone()
-            if tf_fast_d is None:
-                tf = None
-            elif not mixed:
-                tf = tf_fast_d[int(steps[0])]
-            else:
-                tf = tf_fast_d[steps_d]
+            bounds = (self.pair_bound(), self.entropy_bound())
             e0 = tick()
-            lg = fast.forward_logits(xa, sa, tf, out=lbuf[which][:n], check_ids=False)    # ids checked once below
-            eps_i = self._eps_now()
+            first = n_share > 0 and not mixed and bool((steps == step_first[active]).all()) and bool((epoch[active] == 0).all())
+            if first and (shared_lg or n > n_share):               # the shared first update: every input row is the same
+                n_fwd = 0
+                if not shared_lg:
+                    rule.before_forward(fast, None if n_share == B else up(active[:n_share]))
+                    lg1 = fast.forward_logits(xa[:n_share], sa[:n_share], rule.cond(fast, steps[:1], None), check_ids=False)
+                    shared_lg.append(lg1[:1].clone())
+                    n_fwd = n_share
+                lg = lbuf[which][:n, :, :shared_lg[0].shape[-1]]
+                lg.copy_(shared_lg[0].expand(n, L, shared_lg[0].shape[-1]))
+            else:
+                rule.before_forward(fast, idx_d)
+                lg = fast.forward_logits(xa, sa, rule.cond(fast, steps, steps_d), out=lbuf[which][:n], check_ids=False)
+                n_fwd = n
             flags = torch.zeros(n, dtype=torch.int32, device=dev)
-            gaps = torch.full((n,), float("inf"), dtype=torch.float32, device=dev)
-            fast.ddpm_step_rows(xa, lg, par, seed=seed, eps=eps_i, flags=flags, gaps=gaps)
+            gaps = torch.full((n, NG), float("inf"), dtype=torch.float32, device=dev)
+            rule.draw(fast, xa, sa, lg, par, seed, bounds, flags, gaps)
             timers.append(("fast", e0, tick()))
             if not full:
                 x[idx_d] = xa
             after = xa.clone() if full else xa
-            back = _Async(torch.stack([flags.to(torch.float32), gaps, (after == MASK).any(1).to(torch.float32)]))
+            back = _Async(torch.cat([flags.to(torch.float32)[:, None], gaps, (after == MASK).any(1).to(torch.float32)[:, None]], 1))
             updates.append({"active": active, "steps": steps, "epochs": epoch[active].copy(), "prev": prev, "after": after,
-                            "lg": lbuf[which], "back": back, "eps": eps_i})
+                            "lg": lbuf[which], "back": back, "bounds": bounds, "blind": self._blind(gibbs)})
             step[active] += 1
             mask_known[active] = False
+            rule.skip_empty(step)
             st["fast_launches"] += 1
-            st["sample_forwards_fast"] += n
-            st["eps_used"].append(eps_i)
+            st["sample_forwards_fast"] += n_fwd
+            st["eps_used"].append(0.5 * bounds[0])
+            st["entropy_eps_used"].append(bounds[1])
 
         def process_update(rec) -> None:
             nonlocal fill
-            fl, gp, hm = rec["back"].get()
+            res = rec["back"].get()
+            fl, gp, hm = res[:, 0], res[:, 1:1 + NG], res[:, 1 + NG]
             live = epoch[rec["active"]] == rec["epochs"]
+            units = rule.gap_units(rec["bounds"])
             pick, kinds = [], []
             audits_wanted = 2 if (self.eps is None and self.n_seen < self.n_boot) else 0
             for j in np.nonzero(live)[0]:
                 s, k = int(rec["active"][j]), int(rec["steps"][j])
                 has_mask[s], mask_known[s] = bool(hm[j] > 0), True
                 settle_final(s)
-                if np.isfinite(gp[j]):
-                    gap_log.append(float(gp[j]) / (2.0 * rec["eps"]))
-                if fl[j] > 0:
+                drew = bool(np.isfinite(gp[j, 0]))                 # (a sample-update that drew nothing has nothing to verify)
+                for c in range(NG):
+                    if np.isfinite(gp[j, c]) and units[c] > 0:
+                        gap_log[c].append(float(gp[j, c]) / units[c])
+                f = int(fl[j])
+                if f > 0 or (rec["blind"] and drew):
                     pick.append(j); kinds.append("flag")
                     st["flagged"] += 1
-                    st["flagged_per_update"][k] += 1
-                elif np.isfinite(gp[j]) and (self._audit_rng.random() < self.audit_rate or audits_wanted > 0):
-                    pick.append(j); kinds.append("audit")          # (a sample-update that drew nothing has nothing to audit)
+                    st["flagged_per_update"][min(k, len(st["flagged_per_update"]) - 1)] += 1
+                    if f & 1: st["flag_reasons"]["race"] += 1
+                    if f & 2: st["flag_reasons"]["nucleus"] += 1
+                    if f & 4: st["flag_reasons"]["order"] += 1
+                    if f == 0: st["flag_reasons"]["no_estimate"] += 1
+                elif drew and (self._audit_rng.random() < self._audit_rate_now() or audits_wanted > 0):
+                    pick.append(j); kinds.append("audit")
                     audits_wanted -= 1
             while pick:
                 pool = pools[fill]
@@ -325,13 +524,12 @@ class CertifiedSampler:
                 pool["lg"][lo:lo + len(take)] = rec["lg"][jd]
                 for j, kind in zip(take, tk):
                     pool["items"].append({"s": int(rec["active"][j]), "k": int(rec["steps"][j]), "epoch": int(rec["epochs"][j]),
-                                          "kind": kind, "eps": rec["eps"]})
+                                          "kind": kind, "bounds": rec["bounds"]})
 
         def launch_verify() -> None:
             nonlocal fill
             pool = pools[fill]
-            items = pool["items"]
-            n = len(items)
+            n = len(pool["items"])
             if n == 0:
                 return
             while verifies:                                       # settle the earlier batch first: its roll-backs make entries stale
@@ -339,17 +537,16 @@ class CertifiedSampler:
             items = pool["items"]
             ss = np.array([it["s"] for it in items], dtype=np.int64)
             ks = np.array([it["k"] for it in items], dtype=np.int64)
-            par = up(exact.sample_step_params_host(sample_offset + ss, mc_t[ks], mc_s[ks], ks, (ks == T).astype(np.int32)))
-            ss_d, ks_d = up(ss), up(ks)
+            par = up(params(exact, ss, ks))
+            ss_d = up(ss)
+            ks_d = up(ks) if (rule.wants_steps_on_device(exact) and n > 1) else None
             xs = pool["before"][:n].clone()
             sq = seq[ss_d]
-            tf = None if tf_exact_d is None else tf_exact_d[ks_d]
-            if tf is not None and n == 1:
-                tf = tf[0]
             e0 = tick()
-            lg2 = exact.forward_logits(xs, sq, tf, check_ids=False)
-            stats = self._item_stats(pool["lg"][:n], lg2, pool["before"][:n])
-            exact.ddpm_step_rows(xs, lg2, par, seed=seed)
+            rule.before_forward(exact, ss_d)
+            lg2 = exact.forward_logits(xs, sq, rule.cond(exact, ks, ks_d), check_ids=False)
+            stats = self._item_stats(pool["lg"][:n], lg2, pool["before"][:n], rule.all_columns)
+            rule.draw(exact, xs, sq, lg2, par, seed)
             timers.append(("verify", e0, tick()))
             neq = (xs != pool["after"][:n]).any(1).to(torch.float32)
             hm = (xs == MASK).any(1).to(torch.float32)
@@ -363,37 +560,51 @@ class CertifiedSampler:
 
         def process_verify(rec) -> None:
             res = rec["back"].get()
-            self._observe_items(res[:, :6], V)
+            self._observe_items(res[:, :9], V)
             for j, it in enumerate(rec["items"]):
-                me, md, neq, hm = float(res[j, 0]), float(res[j, 2]), res[j, 6] > 0, res[j, 7] > 0
+                me, md, rg, dh = float(res[j, _ME]), float(res[j, _MD]), float(res[j, _RANGE]), float(res[j, _MDH])
+                neq, hm = res[j, 9] > 0, res[j, 10] > 0
                 st["max_logit_err_observed"] = max(st["max_logit_err_observed"], me)
                 st["max_pair_err_observed"] = max(st["max_pair_err_observed"], md)
+                st["max_range_err_observed"] = max(st["max_range_err_observed"], rg)
+                st["max_entropy_err_observed"] = max(st["max_entropy_err_observed"], dh)
                 audit = it["kind"] == "audit"
                 if audit:
                     st["audit_checked"] += 1
                     st["audit_max_logit_err"] = max(st["audit_max_logit_err"], me)
                     st["audit_max_pair_err"] = max(st["audit_max_pair_err"], md)
-                if md > 2.0 * it["eps"]:                         # the pair error left the bound this update was certified with
+                    st["audit_max_range_err"] = max(st["audit_max_range_err"], rg)
+                P_used, E_used = it["bounds"]
+                if rg > P_used:                                  # some pair's error left the bound this update was certified with
                     st["eps_violations"] += 1
                     st["audit_eps_violations"] += int(audit)
-                    self.pair_raise = max(self.pair_raise, self.max_factor * md)
+                    self.pair_raise = max(self.pair_raise, self.max_factor * rg)
+                if gibbs and dh > E_used:
+                    st["entropy_violations"] += 1
+                    self.entropy_raise = max(self.entropy_raise, self.max_factor * dh)
                 s = it["s"]
-                if epoch[s] != it["epoch"] or not neq:
+                stale = epoch[s] != it["epoch"]
+                if audit and not stale:
+                    self.audit_clean_run = 0 if neq else self.audit_clean_run + 1
+                if stale or not neq:
                     continue                                      # stale (the sample was rolled back meanwhile) or confirmed
                 st["audit_mismatches" if audit else "corrections"] += 1
-                if audit:                                         # a miss of the certificate: widen the bound for what follows
-                    self.pair_raise = max(self.pair_raise, self.max_factor * max(md, 2.0 * it["eps"]) * 1.5)
+                if audit:                                         # a miss of the certificate: widen the bounds for what follows
+                    self.pair_raise = max(self.pair_raise, self.max_factor * max(rg, P_used) * 1.5)
+                    if gibbs:
+                        self.entropy_raise = max(self.entropy_raise, self.max_factor * max(dh, E_used) * 1.5)
                 st["rollback_updates_discarded"] += int(step[s] - (it["k"] + 1))
                 x[s] = rec["xs"][j]
                 step[s] = it["k"] + 1
                 epoch[s] += 1
                 has_mask[s], mask_known[s] = bool(hm), True
                 settle_final(s)
+                rule.skip_empty(step)
 
         which = 0
         t_tail = None
         while True:
-            active = np.nonzero((step < T) | ((step == T) & mask_known & has_mask))[0][:W]
+            active = np.nonzero(runnable())[0][:W]
             if t_tail is None and len(active) < W and st["fast_launches"] > 0:
                 if fast.device.type == "cuda":                    # the lane is no longer full: what follows is the tail
                     torch.cuda.synchronize(fast.device)
@@ -407,12 +618,12 @@ class CertifiedSampler:
             while verifies:                                       # (launched in an earlier iteration, or nothing else to do)
                 process_verify(verifies.popleft())
             queued = len(pools[fill]["items"])
-            if queued >= self.verify_batch or (queued and not len(active)):
+            if queued >= self.verify_batch or (queued and not len(active)) or (queued and self._blind(gibbs)):
                 launch_verify()
             if not len(active) and not updates and not verifies and not pools[fill]["items"]:
-                if (step == T + 1).all():
+                if (step >= total).all():
                     break
-                if not ((step < T) | ((step == T) & mask_known & has_mask)).any():
+                if not runnable().any():
                     raise RuntimeError("certified sampler stalled: unfinished samples without pending work")   # (unreachable)
 
         if fast.device.type == "cuda":
@@ -423,18 +634,25 @@ class CertifiedSampler:
         if timers and timers[0][1] is not None:                   # device time inside the two lanes (HIP events on the stream)
             for lane in ("fast", "verify"):
                 st[f"gpu_seconds_{lane}"] = round(sum(a.elapsed_time(b) for ln_, a, b in timers if ln_ == lane) * 1e-3, 4)
-        gl = np.array(gap_log) if gap_log else np.zeros(0)
+        gl = np.array(gap_log[0]) if gap_log[0] else np.zeros(0)
         n_upd = max(1, len(gl))
-        used = st.pop("eps_used")
+        used, used_h = st.pop("eps_used"), st.pop("entropy_eps_used")
         st.update({
             "eps": self.eps if self.eps is not None else "auto", "k_sigma": self.k_sigma, "max_factor": self.max_factor,
-            "audit_rate": self.audit_rate, "verify_batch": self.verify_batch,
+            "audit_rate": self.audit_rate, "audit_rate_steady": self.audit_rate_steady, "audit_rate_now": self._audit_rate_now(),
+            "audit_clean_run": self.audit_clean_run, "verify_batch": self.verify_batch,
             "eps_min_used": min(used) if used else None, "eps_max_used": max(used) if used else None,
-            "sigma_pair_err": self.sigma_d_seen, "sigma_pair_err_per_item": self.sigma_d_item_seen, "sigma_logit_err": self.sigma_e_seen, "max_pair_err_all_calls": self.max_d_seen,
-            "max_logit_err_all_calls": self.err_seen, "items_seen_all_calls": self.n_seen, "first_update_shared": shared0,
-            # share of sample-updates whose smallest gap is within 2 * (m * eps): what a bound of m x the eps in use would re-run
+            "sigma_pair_err": self.sigma_d_seen, "sigma_pair_err_per_item": self.sigma_d_item_seen, "sigma_logit_err": self.sigma_e_seen,
+            "max_pair_err_all_calls": self.max_d_seen, "max_range_err_all_calls": self.range_seen,
+            "max_logit_err_all_calls": self.err_seen, "items_seen_all_calls": self.n_seen, "first_update_shared": bool(identical),
+            # share of sample-updates whose smallest gap is within m x the bound in use: what a bound of m x that one would re-run
             "rerun_share_vs_eps": {str(m): round(float((gl <= m).sum()) / n_upd, 5) for m in _GAP_GRID},
             "rerun_share": round(st["flagged"] / n_upd, 5),
         })
+        if gibbs:
+            gh = np.array(gap_log[1]) if gap_log[1] else np.zeros(0)
+            st.update({"entropy_eps_min_used": min(used_h) if used_h else None, "entropy_eps_max_used": max(used_h) if used_h else None,
+                       "sigma_entropy_err": self.sigma_h_seen, "max_entropy_err_all_calls": self.max_dh_seen,
+                       "order_share_vs_bound": {str(m): round(float((gh <= m).sum()) / max(1, len(gh)), 5) for m in _GAP_GRID}})
         self.stats = st
         return x

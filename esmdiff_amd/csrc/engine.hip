@@ -99,6 +99,8 @@ struct esmdiff_engine {
          *mid = nullptr, *dlt = nullptr, *dlt2 = nullptr;
   float *logits = nullptr, *cond = nullptr, *sig_hidden = nullptr, *tfreq = nullptr, *g_entropy = nullptr;
   int32_t *g_sampled = nullptr, *g_nunmask = nullptr;
+  uint8_t* g_rowflag = nullptr;   // esmdiff_gibbs_step_rows with bounds: per-row report, reduced per prompt by the select kernel
+  float* g_rowgap = nullptr;
   int ld_logits = 0, tfreq_rows = 0;
   int sigma_rows = 1;   // sinusoid rows the next forward reads: 1 (all samples share sigma) or B (esmdiff_forward_logits_sigmas)
   // two-stream forward: the second half of a large batch runs on `side`, forked/joined with events
@@ -733,6 +735,11 @@ int esmdiff_describe_plan(const esmdiff_engine* e, int32_t B, int32_t L, char* b
   return n;
 }
 
+int esmdiff_shared_forward_batch(const esmdiff_engine* e, int32_t B, int32_t L) {
+  if (!e || B <= 0 || L <= 0 || B > e->cfg.max_batch || L > e->cfg.max_len) return ESMDIFF_E_INVALID;
+  return shared_forward_batch(e, B, L);
+}
+
 int esmdiff_set_final_skip(esmdiff_engine* e, int32_t on) {
   if (!e) return ESMDIFF_E_INVALID;
   e->final_skip = on ? 1 : 0;
@@ -1115,6 +1122,8 @@ static int create_engine(const esmdiff_config* cfg, const esmdiff_weight* table,
     TRY(dalloc(e, &e->cseq, Mx));
     TRY(dalloc(e, &e->g_inv_mask, (size_t)128, true));
     TRY(dalloc(e, &e->g_sampled, Mx));
+    TRY(dalloc(e, &e->g_rowflag, Mx));
+    TRY(dalloc(e, &e->g_rowgap, Mx));
     TRY(dalloc(e, &e->g_nunmask, (size_t)e->tfreq_rows * cfg->max_batch));
     {  // split-K workspaces: S * N <= 12288 for every shape the launcher splits; rows up to the small-batch switch
       const char* sk = ed_dbg_env("ESMDIFF_GEMM_SPLITK");
@@ -1346,9 +1355,9 @@ int esmdiff_ddpm_step_rows(esmdiff_engine* e, int64_t* x_inout, const float* log
 }
 
 int esmdiff_logit_error_stats(const float* a, int32_t ld_a, const float* b, int32_t ld_b, const int64_t* x, int32_t rows,
-                              int32_t vocab, float* out, void* stream) {
+                              int32_t vocab, int32_t all_columns, float* out, void* stream) {
   if (!a || !b || !x || !out || rows < 0 || vocab <= 0 || ld_a < vocab || ld_b < vocab) return ESMDIFF_E_INVALID;
-  return launch_logit_error_stats(a, ld_a, b, ld_b, x, rows, vocab, out, (hipStream_t)stream) == hipSuccess ? 0 : ESMDIFF_E_HIP;
+  return launch_logit_error_stats(a, ld_a, b, ld_b, x, rows, vocab, all_columns ? 1 : 0, out, (hipStream_t)stream) == hipSuccess ? 0 : ESMDIFF_E_HIP;
 }
 
 int esmdiff_ddpm_sample(esmdiff_engine* e, const int64_t* seq, int64_t* x_inout, int32_t B, int32_t L, int32_t T,
@@ -1426,6 +1435,28 @@ int esmdiff_gibbs_step(esmdiff_engine* e, int64_t* x_inout, const int64_t* seq, 
   HIP_TRY(e, launch_gibbs_step(x_inout, seq, logits, ld_logits, e->cfg.vocab_out, temperature, top_p, n_unmask, u, u ? 0 : 1, rng ? rng->seed : 0,
                                rng ? rng->sample_offset : 0, step, e->g_sampled, e->g_entropy, B, L, (hipStream_t)stream, 0,
                                e->g_strategy, e->g_inv_on ? e->g_inv_mask : nullptr));
+  p.mark(S_SAMPLER);
+  return 0;
+}
+
+int esmdiff_gibbs_step_rows(esmdiff_engine* e, int64_t* x_inout, const int64_t* seq, const float* logits, int32_t ld_logits,
+                            float temperature, float top_p, const esmdiff_gibbs_sample_step* params, uint64_t seed, int32_t B,
+                            int32_t L, float pair_bound, float entropy_bound, int32_t* sample_flags, float* sample_gaps,
+                            void* stream) {
+  if (!e) return ESMDIFF_E_INVALID;
+  if (!x_inout || !seq || !logits || !params) return fail(e, ESMDIFF_E_INVALID, "null pointer");
+  if (!(temperature >= 0.f)) return fail(e, ESMDIFF_E_INVALID, "temperature must be >= 0 (0 = arg-max of the filtered logits)");
+  if (!(top_p > 0.f) || top_p > 1.f) return fail(e, ESMDIFF_E_INVALID, "top_p must be in (0, 1]");
+  if (ld_logits < 4096 || e->cfg.vocab_out < 4096 || ld_logits < e->cfg.vocab_out) return fail(e, ESMDIFF_E_INVALID, "bad shape");
+  if (int r = check_bl(e, B, L)) return r;
+  if (pair_bound < 0.f && (sample_flags || sample_gaps))
+    return fail(e, ESMDIFF_E_INVALID, "sample_flags / sample_gaps need pair_bound >= 0 (and entropy_bound >= 0)");
+  if (pair_bound >= 0.f && !(entropy_bound >= 0.f)) return fail(e, ESMDIFF_E_INVALID, "entropy_bound must be >= 0");
+  Prof p{e, (hipStream_t)stream};
+  p.mark(S_SAMPLER);
+  HIP_TRY(e, launch_gibbs_step_rows(x_inout, seq, logits, ld_logits, e->cfg.vocab_out, temperature, top_p, params, seed, e->g_sampled,
+                                    e->g_entropy, B, L, pair_bound, entropy_bound, e->g_rowflag, e->g_rowgap, sample_flags, sample_gaps,
+                                    (hipStream_t)stream, e->g_strategy, e->g_inv_on ? e->g_inv_mask : nullptr));
   p.mark(S_SAMPLER);
   return 0;
 }

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include "../../include/esmdiff_hip.h"
+#include "../../include/esmdiff_hip_test.h"
 
 #include <map>
 #include <mutex>

@@ -240,28 +240,38 @@ hipError_t launch_ddpm_step_rows(int64_t* x, const float* logits, int ld, int V,
 
 // Logit-error statistics of one engine against another on the same input (certified sampling: how far the fast engine's logits are
 // from the f32-grade ones).  One workgroup per token row; rows that are not MASK (their draw does not read the logits) give zeros.
-// e_v = a_v - b_v over the columns a draw can pick (all but the MASK column); d_v = e_v - e_{v+1}: the error of a logit DIFFERENCE,
-// which is what decides a draw between two tokens.  out[row] = { max |e|, sum e^2, max |d|, sum d^2 }.
+// e_v = a_v - b_v over the columns a decision reads: all but the MASK column for the ddpm draw (all_columns = 0; that column is
+// pushed to -1e6 before anything looks at it, model.py:528), every column for the gibbs step (all_columns = 1: the nucleus and the
+// entropy are taken over the whole row).  d_v = e_v - e_{v+1} is the error of the logit difference of two NEIGHBOURING tokens (a
+// sample of the pair-error distribution: 4 099 of them per row); the pair that decides a draw is arbitrary, and its error is at
+// most the row's RANGE max e - min e.  H = entropy of softmax over the same columns (plain expf / logf: a statistic, not a draw).
+// out[row] = { max |e|, sum e^2, max |d|, sum d^2, max e - min e, H(a) - H(b), H(b), 0 }.
+constexpr int STATS_W = 8;
 __global__ __launch_bounds__(NT) void logit_error_stats_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b,
-                                                               int ldb, const int64_t* __restrict__ x, int V,
+                                                               int ldb, const int64_t* __restrict__ x, int V, int all_columns,
                                                                float* __restrict__ out) {
   const int row = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  __shared__ float s_r[4][4];
+  __shared__ float s_r[4][12];
   if (x[row] != MASK_ID) {
-    if (t < 4) out[(int64_t)row * 4 + t] = 0.f;
+    if (t < STATS_W) out[(int64_t)row * STATS_W + t] = 0.f;
     return;
   }
   const float* za = a + (int64_t)row * lda;
   const float* zb = b + (int64_t)row * ldb;
-  float me = 0.f, se = 0.f, md = 0.f, sd = 0.f;
+  float me = 0.f, se = 0.f, md = 0.f, sd = 0.f, emax = -3.402823466e38f, emin = 3.402823466e38f;
+  float ma = -3.402823466e38f, mb = -3.402823466e38f;
   for (int v = t; v < V; v += NT) {
-    if (v == MASK_ID) continue;
+    if (!all_columns && v == MASK_ID) continue;
     const float e = za[v] - zb[v];
     me = fmaxf(me, fabsf(e));
     se += e * e;
+    emax = fmaxf(emax, e);
+    emin = fminf(emin, e);
+    ma = fmaxf(ma, za[v]);
+    mb = fmaxf(mb, zb[v]);
     const int w = v + 1;
-    if (w < V && w != MASK_ID) {
+    if (w < V && (all_columns || w != MASK_ID)) {
       const float d = e - (za[w] - zb[w]);
       md = fmaxf(md, fabsf(d));
       sd += d * d;
@@ -271,25 +281,61 @@ __global__ __launch_bounds__(NT) void logit_error_stats_kernel(const float* __re
   for (int off = 32; off >= 1; off >>= 1) {
     me = fmaxf(me, __shfl_xor(me, off, 64));
     md = fmaxf(md, __shfl_xor(md, off, 64));
+    emax = fmaxf(emax, __shfl_xor(emax, off, 64));
+    emin = fminf(emin, __shfl_xor(emin, off, 64));
+    ma = fmaxf(ma, __shfl_xor(ma, off, 64));
+    mb = fmaxf(mb, __shfl_xor(mb, off, 64));
     se += __shfl_xor(se, off, 64);
     sd += __shfl_xor(sd, off, 64);
   }
   if (lane == 0) {
     s_r[wave][0] = me; s_r[wave][1] = se; s_r[wave][2] = md; s_r[wave][3] = sd;
+    s_r[wave][4] = emax; s_r[wave][5] = emin; s_r[wave][6] = ma; s_r[wave][7] = mb;
+  }
+  __syncthreads();
+  ma = fmaxf(fmaxf(s_r[0][6], s_r[1][6]), fmaxf(s_r[2][6], s_r[3][6]));
+  mb = fmaxf(fmaxf(s_r[0][7], s_r[1][7]), fmaxf(s_r[2][7], s_r[3][7]));
+  // entropies of both rows: H = log S - A / S with S = sum exp(z - m), A = sum exp(z - m) (z - m)
+  float Sa = 0.f, Aa = 0.f, Sb = 0.f, Ab = 0.f;
+  for (int v = t; v < V; v += NT) {
+    if (!all_columns && v == MASK_ID) continue;
+    const float da = za[v] - ma, db = zb[v] - mb;
+    const float ea = expf(da), eb = expf(db);
+    Sa += ea; Aa += ea * da;
+    Sb += eb; Ab += eb * db;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    Sa += __shfl_xor(Sa, off, 64);
+    Aa += __shfl_xor(Aa, off, 64);
+    Sb += __shfl_xor(Sb, off, 64);
+    Ab += __shfl_xor(Ab, off, 64);
+  }
+  if (lane == 0) {
+    s_r[wave][8] = Sa; s_r[wave][9] = Aa; s_r[wave][10] = Sb; s_r[wave][11] = Ab;
   }
   __syncthreads();
   if (t == 0) {
-    out[(int64_t)row * 4 + 0] = fmaxf(fmaxf(s_r[0][0], s_r[1][0]), fmaxf(s_r[2][0], s_r[3][0]));
-    out[(int64_t)row * 4 + 1] = (s_r[0][1] + s_r[1][1]) + (s_r[2][1] + s_r[3][1]);
-    out[(int64_t)row * 4 + 2] = fmaxf(fmaxf(s_r[0][2], s_r[1][2]), fmaxf(s_r[2][2], s_r[3][2]));
-    out[(int64_t)row * 4 + 3] = (s_r[0][3] + s_r[1][3]) + (s_r[2][3] + s_r[3][3]);
+    float* o = out + (int64_t)row * STATS_W;
+    o[0] = fmaxf(fmaxf(s_r[0][0], s_r[1][0]), fmaxf(s_r[2][0], s_r[3][0]));
+    o[1] = (s_r[0][1] + s_r[1][1]) + (s_r[2][1] + s_r[3][1]);
+    o[2] = fmaxf(fmaxf(s_r[0][2], s_r[1][2]), fmaxf(s_r[2][2], s_r[3][2]));
+    o[3] = (s_r[0][3] + s_r[1][3]) + (s_r[2][3] + s_r[3][3]);
+    o[4] = fmaxf(fmaxf(s_r[0][4], s_r[1][4]), fmaxf(s_r[2][4], s_r[3][4])) -
+           fminf(fminf(s_r[0][5], s_r[1][5]), fminf(s_r[2][5], s_r[3][5]));
+    const float SA = (s_r[0][8] + s_r[1][8]) + (s_r[2][8] + s_r[3][8]), AA = (s_r[0][9] + s_r[1][9]) + (s_r[2][9] + s_r[3][9]);
+    const float SB = (s_r[0][10] + s_r[1][10]) + (s_r[2][10] + s_r[3][10]), AB = (s_r[0][11] + s_r[1][11]) + (s_r[2][11] + s_r[3][11]);
+    const float Ha = logf(SA) - AA / SA, Hb = logf(SB) - AB / SB;
+    o[5] = Ha - Hb;
+    o[6] = Hb;
+    o[7] = 0.f;
   }
 }
 
-hipError_t launch_logit_error_stats(const float* a, int lda, const float* b, int ldb, const int64_t* x, int rows, int V, float* out,
-                                    hipStream_t stream) {
+hipError_t launch_logit_error_stats(const float* a, int lda, const float* b, int ldb, const int64_t* x, int rows, int V, int all_columns,
+                                    float* out, hipStream_t stream) {
   if (rows <= 0) return hipSuccess;
-  hipLaunchKernelGGL(logit_error_stats_kernel, dim3(rows), dim3(NT), 0, stream, a, lda, b, ldb, x, V, out);
+  hipLaunchKernelGGL(logit_error_stats_kernel, dim3(rows), dim3(NT), 0, stream, a, lda, b, ldb, x, V, all_columns, out);
   return hipGetLastError();
 }
 

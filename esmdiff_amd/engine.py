@@ -256,17 +256,19 @@ class Engine:
                                                    math.exp(e2), e2, _ptr(flags), _ptr(gaps), _stream()))
         return x
 
-    def logit_error_stats(self, a: torch.Tensor, b: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-        """(n, L, 4) f32 = per token row {max |a - b|, sum (a - b)^2, max |d|, sum d^2} over the drawable columns of the rows of
-        x (n, L) that are MASK (d = the error of adjacent logit differences), zeros elsewhere (esmdiff_logit_error_stats)."""
+    def logit_error_stats(self, a: torch.Tensor, b: torch.Tensor, x: torch.Tensor, all_columns: bool = False) -> torch.Tensor:
+        """(n, L, 8) f32 = per token row {max |e|, sum e^2, max |d|, sum d^2, max e - min e, H(a) - H(b), H(b), 0}, e = a - b over the
+        columns a decision reads — all but the MASK column (the ddpm draw), or every column with all_columns (the gibbs step) — of
+        the rows of x (n, L) that are MASK; d = the error of neighbouring logit differences, the range bounds the error of ANY
+        pair's difference, H = the row's softmax entropy; zeros elsewhere (esmdiff_logit_error_stats)."""
         n, L = x.shape
         for t_ in (a, b):
             assert t_.dtype == torch.float32 and t_.is_cuda and t_.stride(-1) == 1 and t_.shape[:2] == (n, L)
             assert t_.stride(0) == t_.stride(1) * L
         assert x.dtype == torch.int64 and x.is_cuda and x.is_contiguous()
-        out = torch.empty(n, L, 4, dtype=torch.float32, device=self.device)
+        out = torch.empty(n, L, 8, dtype=torch.float32, device=self.device)
         N.check(self._lib.esmdiff_logit_error_stats(_ptr(a), a.stride(1), _ptr(b), b.stride(1), _ptr(x), n * L,
-                                                    self.cfg.n_structure_heads, _ptr(out), _stream()))
+                                                    self.cfg.n_structure_heads, int(bool(all_columns)), _ptr(out), _stream()))
         return out
 
     def ddpm_sample(self, sequence_tokens: torch.Tensor, schedule: DDPMSchedule, *, seed: int,
@@ -314,6 +316,41 @@ class Engine:
         self._chk(self._lib.esmdiff_gibbs_step(self._h, _ptr(x), _ptr(seq), _ptr(logits), ld, float(temperature),
                                                float(top_p), _ptr(nu), _ptr(u), ctypes.byref(rng) if rng else None,
                                                int(step), B, L, _stream()))
+        return x
+
+    @staticmethod
+    def gibbs_step_params_host(sample_index, step, n_unmask):
+        """Host sequences (one entry per prompt) -> the esmdiff_gibbs_sample_step records as a uint8 numpy array (n, 16)."""
+        import numpy as np
+        n = len(sample_index)
+        rec = np.zeros(n, dtype=N.GIBBS_STEP_DTYPE)
+        rec["sample_index"], rec["step"], rec["n_unmask"] = sample_index, step, n_unmask
+        return rec.view(np.uint8).reshape(n, -1)
+
+    def gibbs_step_rows(self, x: torch.Tensor, sequence_tokens: torch.Tensor, logits: torch.Tensor, temperature: float,
+                        top_p: float, params: torch.Tensor, *, seed: int, pair_bound: Optional[float] = None,
+                        entropy_bound: Optional[float] = None, flags: Optional[torch.Tensor] = None,
+                        gaps: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """gibbs_step (Philox noise) with one parameter set per prompt (esmdiff_gibbs_step_rows): params from
+        gibbs_step_params_host, uploaded.  With pair_bound R and entropy_bound E (bounds on the error of a row's logit differences
+        and of its entropy, certified.py) flags[b] (int32, zeroed by the caller) gets bit 0 / 1 / 2 where the race / the nucleus
+        membership / the entropy order of the rows prompt b unmasks could come out differently for logits within the bounds, and
+        gaps[b] (f32 (B, 2), +inf on entry) the smallest race gap (logit units) and the selected-to-unselected entropy distance."""
+        B, L = x.shape
+        assert x.dtype == torch.int64 and x.is_cuda and x.is_contiguous()
+        assert logits.dtype == torch.float32 and logits.is_cuda and logits.stride(-1) == 1
+        ld = logits.stride(1)
+        assert logits.stride(0) == ld * L
+        seq = self._tok(sequence_tokens, B, L)
+        assert params.dtype == torch.uint8 and params.is_cuda and params.shape == (B, 16) and params.is_contiguous()
+        assert flags is None or (flags.dtype == torch.int32 and flags.is_cuda and flags.numel() == B and flags.is_contiguous())
+        assert gaps is None or (gaps.dtype == torch.float32 and gaps.is_cuda and gaps.shape == (B, 2) and gaps.is_contiguous())
+        if (flags is not None or gaps is not None) and pair_bound is None:
+            raise ValueError("flags / gaps need pair_bound and entropy_bound")
+        R = -1.0 if pair_bound is None else float(pair_bound)
+        E = 0.0 if entropy_bound is None else float(entropy_bound)
+        self._chk(self._lib.esmdiff_gibbs_step_rows(self._h, _ptr(x), _ptr(seq), _ptr(logits), ld, float(temperature), float(top_p),
+                                                    _ptr(params), int(seed), B, L, R, E, _ptr(flags), _ptr(gaps), _stream()))
         return x
 
     def gibbs_sample(self, sequence_tokens: torch.Tensor, x0: torch.Tensor, n_unmask_table: torch.Tensor,
@@ -388,6 +425,14 @@ class Engine:
         from identical tokens (checked on the device), the first forward runs on a sub-batch and serves all samples; ids are
         bit-identical to the unshared run.  Off by default."""
         self._chk(self._lib.esmdiff_set_step0_sharing(self._h, int(bool(on))))
+
+    def shared_forward_batch(self, B: int, L: int) -> int:
+        """Smallest n <= B whose (n, L) forward takes the dispatch path of a (B, L) forward — bit-identical logits per sample
+        (esmdiff_shared_forward_batch); B when there is none."""
+        n = self._lib.esmdiff_shared_forward_batch(self._h, int(B), int(L))
+        if n < 0:
+            self._chk(n)
+        return int(n)
 
     def set_small_batch_splitk(self, on: bool) -> None:
         """F32_SPLIT engines: K-sliced residual linears for forwards of <= 4096 rows (esmdiff_set_small_batch_splitk) — faster

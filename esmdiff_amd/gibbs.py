@@ -74,6 +74,10 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
     that carry coordinates but no structure tokens get them from `encoder` (an esmdiff_amd.engine.StructureEncoder) for every
     residue with finite coordinates; those positions are then known tokens, not MASK, and are not sampled."""
     eng = getattr(client, "net", client)
+    # precision "certified" (esmdiff_amd/certified.py): `net` is the f32-grade engine, `fast` the f16 one that draws every step; the
+    # decisions of a step that the f16 logits leave open are verified on `net` — the ids of `net`'s own chain at ~2x its rate
+    cert = getattr(client, "certified", None)
+    engines = [eng] + ([client.fast] if cert is not None else [])
     if decoder is None:
         decoder = getattr(client, "decoder", None)
     if encoder is None:
@@ -105,6 +109,7 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
             if cb.shape[0] != L - 2:
                 raise ValueError(f"coordinates cover {cb.shape[0]} residues, sequence has {L - 2}")
             x0[b, 1:-1] = encoder.encode(cb[None]).reshape(-1).to(x0.device)     # MASK where a residue has no coordinates
+    frames = None
     if any(has_xyz):
         from .geometry import build_affine3d_from_coordinates
         if not getattr(eng, "has_geom", False):
@@ -117,7 +122,9 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
                 if cb.shape[0] != L - 2:
                     raise ValueError(f"coordinates cover {cb.shape[0]} residues, sequence has {L - 2}")
                 xyz[b, 1:-1] = cb[:, :3, :]                  # BOS / EOS carry no coordinates
-        eng.set_frames(*build_affine3d_from_coordinates(xyz))
+        frames = build_affine3d_from_coordinates(xyz)
+        if cert is None:
+            eng.set_frames(*frames)
     totals = (x0 == C.STRUCTURE_MASK_TOKEN).sum(1).tolist()
     T = max(min(cfg0.num_steps, t) for t in totals) if max(totals) > 0 else 0
     if T == 0:
@@ -129,14 +136,20 @@ def iterative_sampling_raw(client, proteins: Sequence[ESMProtein], configs: Sequ
             table[: len(sch), b] = torch.tensor(sch, dtype=torch.int32)
         custom = cfg0.strategy != "entropy" or bool(cfg0.invalid_ids)
         if custom:
-            eng.set_gibbs_options(cfg0.strategy, cfg0.invalid_ids or ())
+            for e_ in engines:
+                e_.set_gibbs_options(cfg0.strategy, cfg0.invalid_ids or ())
         try:
-            out_x = eng.gibbs_sample(seq, x0, table, cfg0.temperature, cfg0.top_p, seed=seed,
-                                     sample_offset=sample_offset).cpu()
+            if cert is not None:     # (more prompts than the engines' max_batch are streamed through the fast lane)
+                out_x = cert.gibbs_sample(seq, x0, table, cfg0.temperature, cfg0.top_p, seed=seed, sample_offset=sample_offset,
+                                          frames=frames).cpu()
+            else:
+                out_x = eng.gibbs_sample(seq, x0, table, cfg0.temperature, cfg0.top_p, seed=seed,
+                                         sample_offset=sample_offset).cpu()
         finally:
             if custom:
-                eng.set_gibbs_options()
-    if any(has_xyz):
+                for e_ in engines:
+                    e_.set_gibbs_options()
+    if any(has_xyz) and cert is None:
         eng.set_frames(None)
     coords = plddt = ptm = None
     if decoder is not None:                        # esm: client.decode(tensor) -> ESMProtein with coordinates, pLDDT, pTM

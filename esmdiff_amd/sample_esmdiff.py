@@ -134,6 +134,14 @@ def decode_to_pdb(tokens: torch.Tensor, sequence: str, decoder, save_to: Path, s
     write_models_pdb(coords, plddt, sequence, save_to, sample_basename)
 
 
+def certified_record(cs) -> dict:
+    """What the run's json says about a certified call (esmdiff_amd/certified.py): the kind of certificate and its counters."""
+    keys = ("certificate", "mode", "eps_min_used", "eps_max_used", "entropy_eps_max_used", "flagged", "flag_reasons", "corrections",
+            "audit_checked", "audit_mismatches", "audit_rate_now", "eps_violations", "entropy_violations", "sample_forwards_fast",
+            "sample_forwards_exact")
+    return {k: cs.stats.get(k) for k in keys if k in cs.stats}
+
+
 @timer
 @torch.no_grad()
 def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: str, num_samples: int = 5,
@@ -181,7 +189,13 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
             batch_sizes(seq_tok.numel(), count, n_max_residue_square):
         raise ValueError(f"--parity replays the reference's per-batch torch.rand stream, but the engine capacity ({cap}) would "
                          "split the reference's batches and reorder it: build the engine with a larger max_batch")
-    for bs in batch_sizes(seq_tok.numel(), count, n_max_residue_square, cap) if count else []:
+    sizes = batch_sizes(seq_tok.numel(), count, n_max_residue_square, cap) if count else []
+    if getattr(model, "certified", None) is not None and noise == "philox" and count:
+        # certified sampling streams: the reference's batches (sample_esmdiff.py:181-216) go to the sampler as ONE call; it runs
+        # the fast engine's max_batch unfinished samples with the lowest indices per forward, so a sample that is rolled back rides
+        # along with later ones instead of ending its batch with a tail of small forwards.  Same ids (Philox by global index).
+        sizes = [count]
+    for bs in sizes:
         batch = seq_tok[None, :].repeat(bs, 1)
         prior = None
         if mask_ids is not None:
@@ -215,10 +229,7 @@ def ddpm_sample_by_esm(sequence, pl_model, output_dir: Path, sample_basename: st
              "noise": noise, "world_size": world, "sampling_seconds": round(sample_t, 3),
              "precision": "certified" if getattr(model, "certified", None) is not None else getattr(getattr(model, "net", model), "precision", None),
              "head_precision": getattr(getattr(model, "fast", None) or getattr(model, "net", model), "head_precision", None),
-             **({} if getattr(model, "certified", None) is None else {"certified": {
-                 k: model.certified.stats.get(k) for k in ("eps_min_used", "eps_max_used", "flagged", "corrections", "audit_checked",
-                                                           "audit_mismatches", "eps_violations", "sample_forwards_fast",
-                                                           "sample_forwards_exact")}}),
+             **({} if getattr(model, "certified", None) is None else {"certified": certified_record(model.certified)}),
              "decoder_precision": getattr(decoder, "precision", None),
              **({} if ptm is None else {"ptm": [round(float(v), 4) for v in ptm.cpu()]})}, indent=1))
         if coords is not None:
@@ -270,7 +281,10 @@ def minibatch_gibbs_by_esm(protseq, esm3_model, output_dir: Path, sample_basenam
     offset, count = shard_samples(num_samples, world, rank)
     out_list, done = [], 0
     cap = getattr(getattr(esm3_model, "net", esm3_model), "max_batch", 0)
-    for bs in batch_sizes(len(protseq), count, n_max_residue_square, cap) if count else []:
+    sizes = batch_sizes(len(protseq), count, n_max_residue_square, cap) if count else []
+    if getattr(esm3_model, "certified", None) is not None and count:
+        sizes = [count]                    # certified sampling streams all of a target's prompts through its fast lane (see ddpm_sample_by_esm)
+    for bs in sizes:
         prot_list = [ESMProtein(sequence=protseq, coordinates=coordinates, structure_tokens=st) for _ in range(bs)]
         if rank == 0:
             print(f"Generating {len(prot_list)} samples for {protseq}...")
@@ -304,6 +318,8 @@ def minibatch_gibbs_by_esm(protseq, esm3_model, output_dir: Path, sample_basenam
             {"sequence": protseq, "mode": "gibbs", "num_steps": num_steps, "num_samples": num_samples,
              "temperature": temperature, "top_p": top_p, "seed": seed, "world_size": world,
              "sampling_seconds": round(time() - start_t, 3),
+             "precision": "certified" if getattr(esm3_model, "certified", None) is not None else getattr(getattr(esm3_model, "net", esm3_model), "precision", None),
+             **({} if getattr(esm3_model, "certified", None) is None else {"certified": certified_record(esm3_model.certified)}),
              **({} if ptm is None else {"ptm": [round(float(v), 4) for v in ptm.cpu()]})}, indent=1))
         if coords is not None:
             write_models_pdb(coords, plddt, protseq, output_dir / f"{sample_basename}.pdb", sample_basename)
@@ -336,17 +352,18 @@ def get_argparser(argv=None):
     p.add_argument("--synthetic_len", type=int, default=0, help="sample a random sequence of this length")
     p.add_argument("--n_max_residue_square", type=int, default=DEFAULT_NMAX)
     p.add_argument("--parity", action="store_true", help="uniforms from torch's CPU generator, like the reference")
-    p.add_argument("--precision", choices=["bf16", "f16", "f32", "f32_split", "certified"], default="bf16",
-                   help="arithmetic of the sampling network: bf16 = the MFMA throughput path (default); f32 = the strict path, the "
-                        "reference's own float32 arithmetic on the f32-input MFMA (ids equal to a float32 run of the same seed; ~1/12 "
-                        "of the throughput); f32_split = float32-grade linears as three f16 MFMA passes over split operands (~1/4); f16 = the "
-                        "bf16 path with IEEE-half operands (same speed, 1/8 of the rounding error); certified = the f16 engine draws and only the "
-                        "samples with a close call are re-run on an f32_split engine for that update: the f32_split chain's ids at ~2x its rate "
-                        "(--mode ddpm; the gibbs mode has no certified form and runs on the f32_split engine)")
-    p.add_argument("--head_precision", choices=["body", "f32"], default=None,
+    p.add_argument("--precision", choices=["bf16", "f16", "f32", "f32_split", "certified"], default="certified",
+                   help="arithmetic of the sampling network.  certified (default, both modes) = the ids of the float32-grade (f32_split) "
+                        "chain at ~2.4x its rate: an f16 engine draws every update and only the decisions its measured logit error leaves "
+                        "open are verified on an f32_split engine, in batches, with an audit (a statistical certificate: k-sigma of the "
+                        "measured error + audit, counters in the run's json); bf16 = the MFMA throughput path (the benchmark's headline; "
+                        "near-tie draws can differ from a float32 run); f16 = the bf16 path with IEEE-half operands (same speed, 1/8 of the "
+                        "rounding error); f32_split = float32-grade linears as three f16 MFMA passes over split operands (~1/3 of bf16); f32 = "
+                        "the strict path, the reference's own float32 arithmetic on the f32-input MFMA (~1/10; the referee)")
+    p.add_argument("--head_precision", choices=["body", "f32", "bf16", "f16"], default=None,
                    help="bf16 / f16 networks: 'f32' = final LayerNorm + output head in float32 grade (+1 %% time, fewer near-tie "
-                        "flips), 'body' = the head in the network's own precision.  Default: 'body', except --precision certified, "
-                        "whose fast engine gets the float32-grade head (the validated configuration)")
+                        "flips), 'body' (aliases: 'bf16', 'f16') = the head in the network's own precision.  Default: 'body', except "
+                        "--precision certified, whose fast engine gets the float32-grade head (the validated configuration)")
     p.add_argument("--decoder_precision", choices=["f32", "f32_split", "bf16"], default="f32",
                    help="arithmetic of the VQ-VAE structure decoder (and encoder): f32 (default, backbone within 1e-4 A of a float32 "
                         "decode, encoder codes equal to a float32 encoder's) or bf16")
@@ -356,8 +373,10 @@ def get_argparser(argv=None):
 
 def main(argv=None):
     args = get_argparser(argv)
-    if args.head_precision == "body":      # explicit: the head in the body's precision, also for the certified sampler's fast engine
+    if args.head_precision in ("body", "bf16", "f16"):   # explicit: the head in the body's precision, also for the certified sampler's fast engine
         args.head_precision = {"bf16": "bf16", "f16": "f16", "certified": "f16"}.get(args.precision)
+    if args.parity and args.precision == "certified":
+        args.precision = "f32_split"       # the reference's torch.rand stream is drawn per batch on one engine: the float32-grade one
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -366,6 +385,8 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
+    from .dist import pin_to_gpu_numa
+    numa = pin_to_gpu_numa(local_rank)     # one process per GPU: launch thread, weight upload and PDB writer stay on the GPU's socket
     if args.ckpt is None and not args.random_init and not args.esm3_ckpt:
         # the reference falls back to the stock esm3_sm_open_v1 weights in gibbs mode (sample_esmdiff.py:252-255);
         # they cannot be fetched offline, so a checkpoint (or --random_init) is required in both modes here
@@ -436,8 +457,11 @@ def main(argv=None):
                else random_init_encoder_state_dict(ecfg, seed=args.seed, device=f"cuda:{local_rank}"))
         encoder = StructureEncoder(ecfg, esd, device=local_rank,     # same switch as the decoder (the encoder has no split form)
                                    precision="f32" if args.decoder_precision == "f32_split" else args.decoder_precision)
+    lt = getattr(model, "load_timings", None)
+    print(f"[rank {rank}] weights ready: load_s = {lt['load_s'] if lt else 'n/a (random init)'}"
+          f"{'' if not lt else ' (' + lt['path'] + ')'}, NUMA pinning = {numa}", flush=True)
     if rank == 0:
-        print(f">>> Sampling mode = {args.mode} ...")
+        print(f">>> Sampling mode = {args.mode}, precision = {args.precision} ...")
     for name, seq in targets:
         if args.mode == "gibbs":
             coordinates = coords_of.get(name) if mask_ids is not None else None   # sample_esmdiff.py:286-289

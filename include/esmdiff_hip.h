@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESMDIFF_ABI_VERSION 7   /* 7: + esmdiff_ddpm_step_rows, esmdiff_logit_error_stats (additions only); 6: + esmdiff_ddpm_step_margin, esmdiff_forward_logits_sigmas, esmdiff_set_small_batch_splitk */
+#define ESMDIFF_ABI_VERSION 8   /* 8: + esmdiff_gibbs_step_rows; esmdiff_logit_error_stats writes 8 floats per row and takes all_columns; 7: + esmdiff_ddpm_step_rows, esmdiff_logit_error_stats (additions only); 6: + esmdiff_ddpm_step_margin, esmdiff_forward_logits_sigmas, esmdiff_set_small_batch_splitk */
 
 /* structure-track vocabulary: esm constants mirrored at model.py:380-381 */
 #define ESMDIFF_VOCAB 4101
@@ -233,13 +233,17 @@ int esmdiff_ddpm_step_rows(esmdiff_engine* eng, int64_t* x_inout, const float* l
                            const esmdiff_sample_step* params, uint64_t seed, int32_t B, int32_t L, float margin_ratio,
                            float margin_diff, int32_t* sample_flags, float* sample_min_gap, void* stream);
 
-/* How far two engines' logits are apart on the same input (ABI 7; no reference counterpart — the reference has one precision).
- * a, b: f32 [rows, ld_a / ld_b] raw logits of the same token rows; x: int64 [rows] the tokens that went in.  For every row that
- * is MASK (the only rows whose draw reads the logits), over the vocab columns a draw can pick (all v < vocab but the MASK column):
- * e_v = a_v - b_v and d_v = e_v - e_(v+1), the error of the logit DIFFERENCE of two tokens, which is what decides a draw between
- * them.  out f32 [rows, 4] = { max |e|, sum e^2, max |d|, sum d^2 }; zeros for rows that are not MASK. */
+/* How far two engines' logits are apart on the same input (ABI 7, widened in ABI 8; no reference counterpart — the reference
+ * has one precision).  a, b: f32 [rows, ld_a / ld_b] raw logits of the same token rows; x: int64 [rows] the tokens that went in.
+ * For every row that is MASK (the only rows whose decisions read the logits), over the columns a decision reads — all v < vocab
+ * but the MASK column for the ddpm draw (all_columns = 0: model.py:528 pushes that column to -1e6), every v < vocab for the gibbs
+ * step (all_columns = 1: nucleus and entropy span the whole row): e_v = a_v - b_v; d_v = e_v - e_(v+1), the error of the logit
+ * difference of two NEIGHBOURING tokens (a sample of the pair-error distribution); max e - min e, the bound on the error of the
+ * difference of ANY two tokens of the row, which is what decides a draw between them; and the entropy H of softmax over the same
+ * columns for both inputs.  out f32 [rows, 8] = { max |e|, sum e^2, max |d|, sum d^2, max e - min e, H(a) - H(b), H(b), 0 };
+ * zeros for rows that are not MASK. */
 int esmdiff_logit_error_stats(const float* a, int32_t ld_a, const float* b, int32_t ld_b, const int64_t* x, int32_t rows,
-                              int32_t vocab, float* out, void* stream);
+                              int32_t vocab, int32_t all_columns, float* out, void* stream);
 
 /* Replaces MaskedDiffusionLanguageModeling.ddpm_sample (model.py:543-581) for one batch, entirely on
  * the device, Philox noise: T updates + the noise-removal pass.  x_inout holds the prior on entry
@@ -260,6 +264,10 @@ int esmdiff_ddpm_sample(esmdiff_engine* eng, const int64_t* seq, int64_t* x_inou
  * esmdiff_get_counters: network forwards issued and token rows pushed through them since create / the last reset — the
  * work actually executed, for FLOP accounting (bench.py reports the shared run as a separate, labelled figure). */
 int esmdiff_set_step0_sharing(esmdiff_engine* eng, int32_t on);
+/* The sub-batch size step-0 sharing uses (ABI 8): the smallest number of samples n <= B whose (n, L) forward takes the same
+ * dispatch path — and so produces the same logits bit for bit — as a (B, L) forward; B when there is none.  Returns n >= 1, or a
+ * negative esmdiff_status.  Callers that drive the loop themselves (esmdiff_amd/certified.py) share their first forward with it. */
+int esmdiff_shared_forward_batch(const esmdiff_engine* eng, int32_t B, int32_t L);
 /* Exact skip of the noise-removal forward (off by default; exact).  The last of the T + 1 forwards of esmdiff_ddpm_sample only
  * serves `x = argmax(log p)` (model.py:575-579), and for a position that is no longer MASK the re-parameterised log p is 0 at its
  * own token and -1e6 elsewhere (model.py:530-532): a sample without a MASK comes back unchanged.  With the option on, the
@@ -288,77 +296,38 @@ int esmdiff_gibbs_step(esmdiff_engine* eng, int64_t* x_inout, const int64_t* seq
  * (0, NULL, 0) restores the defaults.  Synchronous (a 512-byte upload). */
 int esmdiff_set_gibbs_options(esmdiff_engine* eng, int32_t strategy, const int32_t* invalid_ids, int32_t n_invalid);
 
+/* esmdiff_gibbs_step (Philox source) with ONE PARAMETER SET PER PROMPT (ABI 8), and optionally a report of how close the step's
+ * decisions were.  iterative_sampling_raw moves a batch through the same step index, but nothing couples its prompts (every
+ * decision above is per row or per prompt), so a batch may hold prompts that sit at DIFFERENT steps of their chains: params[b]
+ * (DEVICE array of B entries) gives prompt b its global Philox sample index (what esmdiff_rng.sample_offset + b is in the plain
+ * entry), its Philox step index and the number of positions it unmasks.  Per prompt the ids written are those esmdiff_gibbs_step
+ * writes for that prompt alone with the same scalars, bit for bit (tests/test_gpu_kernels.py).
+ * pair_bound < 0: plain draws (sample_flags / sample_gaps must be NULL).  pair_bound = R >= 0, entropy_bound = E >= 0: the logits
+ * are taken to be known only up to an error whose difference between any two columns of a row is at most R (so every probability
+ * up to the factor exp(+-R)) and which moves a row's entropy by at most E.  sample_flags[b] (int32 [B], zeroed by the caller) then
+ * gets, over the rows prompt b UNMASKS in this step: bit 0 — a draw's winner does not lead the best other possibly-kept token by
+ * more than exp(R / temperature) (temperature 0: R); bit 1 — the winner's membership of the nucleus, or a better token's, depends
+ * on the error (kept for sure: mass{z_j >= z_v - R} exp(R) <= top_p S; dropped for sure: mass{z_j >= z_v + R} exp(-R) > top_p S),
+ * or the fall-back was taken; bit 2 — the largest selected and the smallest unselected entropy are not more than 2 E apart
+ * (strategy "entropy" only).  An unflagged prompt's new ids are those ANY logits within the bounds would have produced.
+ * sample_gaps (f32 [B, 2], optional, +inf on entry): the smallest race gap of the unmasked rows in logit units, and the entropy
+ * distance above — statistics, not inputs of the step.  Used by esmdiff_amd/certified.py (CertifiedSampler.gibbs_sample). */
+typedef struct {
+  uint64_t sample_index;   /* Philox key: the prompt's GLOBAL index */
+  int32_t step;            /* Philox step index = index of the step in the prompt's chain */
+  int32_t n_unmask;        /* positions to unmask in this step (<= 0: the prompt is left alone) */
+} esmdiff_gibbs_sample_step;
+int esmdiff_gibbs_step_rows(esmdiff_engine* eng, int64_t* x_inout, const int64_t* seq, const float* logits, int32_t ld_logits,
+                            float temperature, float top_p, const esmdiff_gibbs_sample_step* params, uint64_t seed, int32_t B,
+                            int32_t L, float pair_bound, float entropy_bound, int32_t* sample_flags, float* sample_gaps,
+                            void* stream);
+
 /* The whole loop of iterative_sampling_raw for one batch on the device (Philox noise, no time conditioning):
  * T x (forward, gibbs step).  n_unmask_table: [T,B] int32 [host] = positions to unmask per step and prompt
  * (cosine schedule, computed by the host: esmdiff_amd/gibbs.py). */
 int esmdiff_gibbs_sample(esmdiff_engine* eng, const int64_t* seq, int64_t* x_inout, int32_t B, int32_t L, int32_t T,
                          float temperature, float top_p, const int32_t* n_unmask_table, const esmdiff_rng* rng,
                          void* stream);
-
-/* Per-kernel entry points (used by the parity tests and the bench's roofline leg). */
-
-/* C[M,N] (+)= A[M,K] · W[N,K]^T, bf16 in, f32 accumulate.  epilogue: see esmdiff_gemm_epilogue. */
-typedef enum {
-  ESMDIFF_EPI_BF16 = 0,       /* out bf16 [M,N]                                   */
-  ESMDIFF_EPI_RESID_F32 = 1,  /* out f32 [M,N] += acc * alpha   (residual stream)   */
-  ESMDIFF_EPI_SWIGLU_BF16 = 2,/* W rows interleaved gate/up in blocks of 32; out bf16 [M,N/2] */
-  ESMDIFF_EPI_BIAS_GELU_BF16 = 3, /* out bf16 = gelu(acc + bias[N])                 */
-  ESMDIFF_EPI_BIAS_F32 = 4    /* out f32 [M,ldc] = acc + bias, columns >= n_valid skipped */
-} esmdiff_gemm_epilogue;
-
-int esmdiff_gemm_bf16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N,
-                      int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream);
-
-/* The same kernels in their f16 build (csrc/ed_half.h, namespace ed16; what precision = ESMDIFF_PRECISION_F16 engines run): A, W and
- * the 16-bit outputs are IEEE half instead of bfloat16, conversions saturate at +-65504; everything else as esmdiff_gemm_bf16. */
-int esmdiff_gemm_f16(const void* A, const void* W, void* out, const float* bias, int32_t M, int32_t N,
-                     int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue, void* stream);
-
-/* The strict path's linear (csrc/strict.hip): out f32 [M,ldc] = epi(A f32 [M,K] (row stride lda) . W f32 [N,K]^T), every
- * product and sum in float32 on v_mfma_f32_32x32x2_f32 (fixed, batch-independent K order per output element; not ascending k);
- * K % 32 == 0; columns >= n_valid are not written. */
-typedef enum {
-  ESMDIFF_F32EPI_STORE = 0,      /* out = acc (+ bias[N] when bias != NULL)                        */
-  ESMDIFF_F32EPI_BIAS_GELU = 1,  /* out = gelu(acc + bias), exact (erf) GELU                        */
-  ESMDIFF_F32EPI_RESID_DIV = 2   /* out = out + acc / div  (x + branch / scaling_factor, in place)  */
-} esmdiff_gemm_f32_epilogue;
-int esmdiff_gemm_f32(const float* A, int32_t lda, const float* W, float* out, const float* bias, int32_t M, int32_t N,
-                     int32_t K, int32_t ldc, int32_t n_valid, float div, int32_t epilogue, void* stream);
-
-/* The F32_SPLIT path's linear and its operand preparation (csrc/gemm_split.hip, csrc/gemm256w4.hip SPLIT = 1).
- *   esmdiff_split_rows    src f32 [M,K] (row stride ld) -> a3 f16 [M,3K] = [hi | lo | hi] of src * 2^k(row), rs[M] = 2^-k(row)
- *   esmdiff_split_weight  src f32 [N,K] -> w3 f16 [N_pad,3K] = [lo | hi | hi] of src * 2^k (rows N..N_pad-1 zero-filled,
- *                         N_pad a multiple of 256 >= N), *inv_scale_out [host] = 2^-k; synchronous
- *   esmdiff_gemm_split    out f32 [M,ldc] = epi(rs[m] * w_inv_scale * A . W^T [+ bias[N]]); N (= N_pad) % 256 == 0,
- *                         K % 128 == 0, ldc >= N: whole padded rows are written (the kernel carries no column bound);
- *                         epilogue ESMDIFF_F32EPI_STORE (bias optional) or ESMDIFF_F32EPI_RESID_DIV. */
-int esmdiff_split_rows(const float* src, int32_t ld, void* a2, float* rs, int32_t M, int32_t K, void* stream);
-int esmdiff_split_weight(const float* src, void* w2, int32_t N, int32_t N_pad, int32_t K, float* inv_scale_out);
-int esmdiff_gemm_split(const void* a2, const float* rs, const void* w2, float w_inv_scale, float* out, const float* bias,
-                       int32_t M, int32_t N, int32_t K, int32_t ldc, float div, int32_t epilogue, void* stream);
-
-/* The same GEMM as the engine issues it: with the engine's split-K workspace, so the small-M path (M < 1152 rows,
- * K >= 2048: FFN-down) runs as K slices + a fixed-order reduce kernel (csrc/gemm.hip).  Not re-entrant per engine. */
-int esmdiff_gemm_bf16_ws(esmdiff_engine* eng, const void* A, const void* W, void* out, const float* bias, int32_t M,
-                         int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha, int32_t epilogue,
-                         void* stream);
-
-/* The small-batch form of a residual branch (M < 1152 rows; csrc/engine.hip::forward): the branch linear A[M,K] W[N,K]^T
- * is left as S raw f32 K-slice planes in the engine's workspace (S = *splits_out, a function of N and K only) and the
- * LayerNorm kernel that follows sums them:  x[M,N] f32 += alpha * (A W^T);  y bf16 [M,N] = LayerNorm(x) * w (+ b).
- * N = d_model of the engine's shapes (N % 128 == 0, N <= 2048), K % 64 == 0.  Not re-entrant per engine. */
-int esmdiff_branch_linear_layernorm(esmdiff_engine* eng, const void* A, const void* W, float* x, float alpha,
-                                    const float* w, const float* b, void* y, int32_t M, int32_t N, int32_t K,
-                                    int32_t* splits_out, void* stream);
-
-/* y bf16 [M,D] = LayerNorm(x f32 [M,D]) * w (+ b); b may be NULL.  eps = 1e-5. */
-int esmdiff_layernorm_bf16(const float* x, const float* w, const float* b, void* y, int32_t M, int32_t D,
-                           void* stream);
-
-/* Attention over pre-processed heads: qkv bf16 [B*L, 3*D] (GEMM output) -> ctx bf16 [B*L, D].
- * Applies the full-width q/k LayerNorm (weights f32 [D]), rotary, 1/sqrt(64) scaling, non-causal softmax. */
-int esmdiff_attention_bf16(esmdiff_engine* eng, const void* qkv, const float* q_ln_w, const float* k_ln_w,
-                           void* ctx, int32_t B, int32_t L, void* stream);
 
 /* Coordinate conditioning (block 0's geometric attention).  Replaces what the reference does inside
  * CustomizedESM3.forward when structure_coords is given (/root/reference/slm/models/net.py:433-441, :468):
@@ -448,29 +417,9 @@ int esmdiff_metrics_validity(const double* ca, int32_t n, int32_t L, double ca_v
 int esmdiff_metrics_bonding_validity(const double* ca_model, int32_t n_model, const double* ca_ref, int32_t n_ref,
                                      int32_t L, double* out, void* stream);
 
-/* Accumulated per-section device time of the esmdiff_forward_logits/ddpm_sample calls since profiling was
- * enabled: esmdiff_set_profiling(eng, 1) brackets every launch with HIP events on the launch stream (no sync);
- * mode 2 brackets only the dominant kernel (FFN-up GEMM, section 6), cheap enough for a timed region; 0 = off. sections: 0 embed, 1 layernorm, 2 gemm_qkv,
- * 3 qk_norm_rope, 4 attention, 5 gemm_out, 6 gemm_ffn_up, 7 gemm_ffn_down, 8 head, 9 sampler.
- * ms_out: [16] floats, launches_out: [16] ints [host].  Synchronises the device. */
-int esmdiff_set_profiling(esmdiff_engine* eng, int32_t on);
-int esmdiff_get_profile(esmdiff_engine* eng, float* ms_out, int32_t* launches_out);
-
-#ifdef ED_DEBUG
-/* ---- measurement aids: exported only by libraries built with -DED_DEBUG (ESMDIFF_EXTRA_CXXFLAGS=-DED_DEBUG python -m
- * esmdiff_amd.build); the product library carries neither these nor the ESMDIFF_DEBUG_SKIP launch-skipping switch, and
- * esmdiff_engine_create FAILS when that variable is set.  Used by scratch/ A/B scripts only. ---- */
-/* Measurement aid: one forward at (B, L) `n` times as plain launches and as `n` replays of one captured hipGraph of the
- * same launches (engine-owned stream); milliseconds per forward of each [host]. */
-int esmdiff_debug_graph_ab(esmdiff_engine* eng, const int64_t* seq, const int64_t* x, int32_t B, int32_t L, int32_t n,
-                           float* ms_direct, float* ms_graph);
-
-/* Wall-clock helper for the bench's roofline leg: runs the GEMM `iters` times on `stream` bracketed by
- * HIP events on that stream and returns the average milliseconds per launch in *ms_out [host]. */
-int esmdiff_gemm_bf16_timed(const void* A, const void* W, void* out, const float* bias, int32_t M,
-                            int32_t N, int32_t K, int32_t ldc, int32_t n_valid, float alpha,
-                            int32_t epilogue, int32_t iters, float* ms_out, void* stream);
-#endif /* ED_DEBUG */
+/* Per-kernel entry points of the parity tests, the per-section profiler of bench.py's roofline leg and the -DED_DEBUG
+ * measurement aids are declared in esmdiff_hip_test.h: they are exported by the same library but are not part of the surface a
+ * binding of the reference's call sites needs. */
 
 #ifdef __cplusplus
 }

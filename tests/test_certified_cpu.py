@@ -112,14 +112,56 @@ class _Net:
             x[b:b + 1].copy_(torch.from_numpy(new))
         return x
 
-    def logit_error_stats(self, a, b, x):
-        e = (a[..., :V] - b[..., :V]).numpy().astype(np.float64)
-        e = np.delete(e, MASK, axis=-1)                      # drawable columns; pairs (4095, 4097) do not exist in the kernel
+    def logit_error_stats(self, a, b, x, all_columns=False):
+        """esmdiff_logit_error_stats restated (8 columns per row, include/esmdiff_hip.h)."""
+        za, zb = a[..., :V].numpy().astype(np.float64), b[..., :V].numpy().astype(np.float64)
+        e = za - zb
+        if not all_columns:
+            za, zb, e = (np.delete(t, MASK, axis=-1) for t in (za, zb, e))   # drawable columns; pairs (4095, 4097) do not exist in the kernel
         d = e[..., :-1] - e[..., 1:]
-        d = np.delete(d, MASK - 1, axis=-1)
+        if not all_columns:
+            d = np.delete(d, MASK - 1, axis=-1)
+
+        def H(z):
+            lp = z - z.max(-1, keepdims=True)
+            lp = lp - np.log(np.exp(lp).sum(-1, keepdims=True))
+            return -(np.exp(lp) * lp).sum(-1)
+        ha, hb = H(za), H(zb)
         m = (x.numpy() == MASK)[..., None]
-        out = np.stack([np.abs(e).max(-1), (e * e).sum(-1), np.abs(d).max(-1), (d * d).sum(-1)], -1) * m
+        out = np.stack([np.abs(e).max(-1), (e * e).sum(-1), np.abs(d).max(-1), (d * d).sum(-1), e.max(-1) - e.min(-1), ha - hb, hb,
+                        np.zeros_like(hb)], -1) * m
         return torch.from_numpy(out.astype(np.float32))
+
+    # ---- gibbs mode --------------------------------------------------------------------------------------------------------
+    def gibbs_step_params_host(self, sample_index, step, n_unmask):
+        from esmdiff_amd.engine import Engine
+        return Engine.gibbs_step_params_host(sample_index, step, n_unmask)
+
+    def gibbs_step_rows(self, x, seq, lg, temperature, top_p, params, *, seed, pair_bound=None, entropy_bound=None, flags=None,
+                        gaps=None):
+        """esmdiff_gibbs_step_rows restated by oracle/gibbs_margin_ref.py (ids: the C oracle's plain step per prompt)."""
+        from oracle import gibbs_margin_ref as M
+        rec = params.numpy().view(M.GIBBS_STEP_DTYPE).reshape(-1)
+        new, f, g = M.gibbs_step_rows(x.numpy(), seq.numpy(), np.ascontiguousarray(lg.numpy()), temperature, top_p, rec, seed,
+                                      R=pair_bound, E=entropy_bound, vocab=V)
+        x.copy_(torch.from_numpy(new))
+        if flags is not None:
+            flags.copy_(torch.from_numpy(f))
+        if gaps is not None:
+            gaps.copy_(torch.from_numpy(g))
+        return x
+
+    def set_frames(self, rot, trans=None, has_frame=None):
+        self.frames_seen = getattr(self, "frames_seen", []) + [None if rot is None else tuple(rot.shape)]
+
+    def gibbs_chain(self, seq, x0, table, temperature, top_p, seed):
+        x = x0.clone()
+        for t in range(table.shape[0]):
+            lg = self.forward_logits(x, seq, None)
+            new = c_oracle.gibbs_step(x.numpy(), seq.numpy(), np.ascontiguousarray(lg.numpy()), temperature, top_p, table[t].numpy(),
+                                      seed=seed, sample_offset=0, step=t, vocab=V)
+            x = torch.from_numpy(new)
+        return x
 
     def chain(self, seq, sch, seed, prior=None):
         B, L = seq.shape
@@ -266,3 +308,94 @@ def test_certified_argument_checks():
         CertifiedSampler(_Net(), _Net(), audit_rate=1.5)
     with pytest.raises(ValueError, match="verify_batch"):
         CertifiedSampler(_Net(), _Net(), verify_batch=0)
+
+
+# ---- gibbs mode (the CLI's default, /root/reference/slm/sample_esmdiff.py:66-130, :241) ------------------------------------------
+def _gibbs_setup(B, L, steps, same, masked=None):
+    """Prompts with BOS / EOS and `masked[b]` interior positions to sample (default: all of them): x0, the (T, B) table."""
+    from esmdiff_amd.gibbs import unmask_schedule
+    seq = _seqs(B, L, same).clone()
+    seq[:, 0], seq[:, -1] = 0, 2
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randint(0, 4096, (B, L), generator=g)
+    x0[:, 0], x0[:, -1] = 4098, 4097
+    masked = [L - 2] * B if masked is None else masked
+    for b, n in enumerate(masked):
+        x0[b, 1:1 + n] = MASK
+    T = max(min(steps, n) for n in masked)
+    table = torch.zeros(T, B, dtype=torch.int32)
+    for b, n in enumerate(masked):
+        sch = unmask_schedule(n, steps)
+        table[:len(sch), b] = torch.tensor(sch, dtype=torch.int32)
+    return seq, x0, table
+
+
+@pytest.mark.parametrize("same_protein,temperature,top_p", [(False, 1.4, 0.9), (True, 1.4, 0.9), (False, 0.0, 0.7), (False, 0.8, 1.0)])
+def test_certified_gibbs_chain_equals_exact_chain_under_bounded_logit_error(same_protein, temperature, top_p):
+    """The three decisions of a gibbs step (nucleus membership, temperature race, entropy order) under a bounded logit error:
+    the certified chain equals the exact engine's chain, while the uncertified fast chain leaves it.  Bounds from the measured
+    error (eps = None): the range of the row's logit error for the pairs, the entropy error for the order."""
+    B, L, steps, noise, scale = 7, 14, 5, 0.03, 1.0
+    seq, x0, table = _gibbs_setup(B, L, steps, same_protein)
+    want = _Net(scale=scale).gibbs_chain(seq, x0, table, temperature, top_p, seed=11)
+    assert int((want == MASK).sum()) == 0
+    plain = _Net(noise=noise, seed=1, scale=scale).gibbs_chain(seq, x0, table, temperature, top_p, seed=11)
+    assert not torch.equal(plain, want), "the stand-in is too easy: the perturbed chain never leaves the exact one"
+    fast = _Net(noise=noise, seed=1, scale=scale)
+    cs = CertifiedSampler(fast, _Net(scale=scale), verify_batch=3, audit_rate=0.1)
+    got = cs.gibbs_sample(seq, x0, table, temperature, top_p, seed=11)
+    st = cs.stats
+    assert torch.equal(got, want), st
+    assert st["mode"] == "gibbs" and st["certificate"] == "k-sigma statistical + audit"
+    assert st["eps_violations"] == 0 and st["entropy_violations"] == 0 and st["audit_mismatches"] == 0
+    assert st["max_range_err_observed"] <= 2 * noise * 1.0001 and st["max_entropy_err_observed"] <= st["entropy_eps_max_used"]
+    assert st["first_update_shared"] == same_protein and st["lane_width"] == 3
+    assert st["flagged"] > 0 and st["corrections"] > 0 and max(st["verify_batch_sizes"]) <= 3
+    assert sum(st["flag_reasons"].values()) >= st["flagged"]
+    if top_p >= 1.0:
+        assert st["flag_reasons"]["nucleus"] == 0            # no nucleus: nothing to be unsure about
+
+
+def test_certified_gibbs_ragged_prompts_frames_and_empty_steps():
+    """Prompts with different numbers of masked positions (different step counts, zero rows in the table), a prompt with
+    nothing to sample, more prompts than the lane holds, and per-prompt frames handed to every forward of the prompts it runs."""
+    B, L, steps = 5, 12, 4
+    seq, x0, table = _gibbs_setup(B, L, steps, False, masked=[10, 3, 0, 7, 1])
+    scale = 1.0
+    want = _Net(scale=scale).gibbs_chain(seq, x0, table, 1.4, 0.9, seed=5)
+    assert torch.equal(want[2], x0[2])
+    fast, exact = _Net(noise=0.03, seed=4, scale=scale), _Net(scale=scale)
+    cs = CertifiedSampler(fast, exact, verify_batch=2, audit_rate=0.2)
+    frames = (torch.zeros(B, L, 3, 3), torch.zeros(B, L, 3), torch.ones(B, L, dtype=torch.bool))
+    got = cs.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=5, frames=frames)
+    assert torch.equal(got, want), cs.stats
+    assert fast.frames_seen[-1] is None and exact.frames_seen[-1] is None           # cleared at the end
+    assert all(f is None or (f[0] <= 3 and f[1:] == (L, 3, 3)) for f in fast.frames_seen) and len(fast.frames_seen) > 2
+    assert cs.stats["sample_forwards_fast"] <= 10 + 3 + 7 + 1 + 2 * B            # no forward for steps that unmask nothing
+    with pytest.raises(ValueError, match="n_unmask_table"):
+        cs.gibbs_sample(seq, x0, table[:, :3], 1.4, 0.9, seed=5)
+    with pytest.raises(ValueError, match="x0 shape"):
+        cs.gibbs_sample(seq, x0[:, :5], table, 1.4, 0.9, seed=5)
+
+
+def test_gibbs_rows_step_is_the_plain_step_per_prompt():
+    """Contract of esmdiff_gibbs_step_rows (the GPU test checks the kernel against the same statement): prompts at different
+    steps in one call = each prompt alone through the plain step with its own Philox index, step and count."""
+    from oracle import gibbs_margin_ref as M
+    net = _Net(scale=1.0)
+    B, L = 4, 10
+    seq, x0, _ = _gibbs_setup(B, L, 4, False)
+    lg = net.forward_logits(x0, seq, None)
+    rec = np.zeros(B, dtype=M.GIBBS_STEP_DTYPE)
+    rec["sample_index"], rec["step"], rec["n_unmask"] = 20 + np.arange(B), [0, 3, 1, 2], [2, 0, 5, 1]
+    got, flags, gaps = M.gibbs_step_rows(x0.numpy(), seq.numpy(), lg.numpy(), 1.4, 0.9, rec, seed=9, R=1e-3, E=1e-5)
+    for b in range(B):
+        want = c_oracle.gibbs_step(x0[b:b + 1].numpy(), seq[b:b + 1].numpy(), np.ascontiguousarray(lg[b:b + 1].numpy()), 1.4, 0.9,
+                                   np.array([rec["n_unmask"][b]], np.int32), seed=9, sample_offset=20 + b, step=int(rec["step"][b]),
+                                   vocab=V)
+        assert np.array_equal(got[b], want[0])
+        assert int((got[b] != x0[b].numpy()).sum()) == rec["n_unmask"][b]
+    assert flags[1] == 0 and np.isinf(gaps[1]).all()          # a prompt that unmasks nothing reports nothing
+    # the report is monotone in the bounds: wider bounds can only add flags
+    _, f_wide, _ = M.gibbs_step_rows(x0.numpy(), seq.numpy(), lg.numpy(), 1.4, 0.9, rec, seed=9, R=0.5, E=0.5)
+    assert ((flags & ~f_wide) == 0).all() and (f_wide[[0, 2, 3]] & 4).all()

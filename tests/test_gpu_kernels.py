@@ -182,29 +182,169 @@ def test_sampler_rows_equals_plain_step_per_sample(tiny):
         eng.ddpm_step_rows(torch.from_numpy(x).cuda(), zt, par, seed=1, eps=-1.0, flags=flags)
 
 
-def test_logit_error_stats_vs_torch(tiny):
-    """esmdiff_logit_error_stats: per masked row max / sum of squares of the logit error and of the adjacent-pair error over the
-    drawable columns (all but MASK; the pair (4095, 4096) and (4096, 4097) do not exist), zeros for carried rows — vs float64."""
+@pytest.mark.parametrize("all_columns", [False, True])
+def test_logit_error_stats_vs_torch(tiny, all_columns):
+    """esmdiff_logit_error_stats (ABI 8: 8 floats per row): per masked row max / sum of squares of the logit error and of the
+    neighbouring-pair error, the RANGE max e - min e (the bound on ANY pair's error: the pair that decides a draw is not a
+    neighbouring one) and the entropy difference — over the drawable columns (all but MASK; the pairs (4095, 4096) and (4096, 4097)
+    do not exist) for the ddpm draw, over every column for the gibbs step; zeros for carried rows — vs float64."""
     _, _, eng, _, _ = tiny
     g = torch.Generator().manual_seed(8)
     n, L = 5, 23
     a = torch.randn(n, L, 4104, generator=g).cuda()
     b = (a.cpu() + 1e-3 * torch.randn(n, L, 4104, generator=g)).cuda()
-    b[..., MASK] += 100.0                                        # the MASK column must not count
+    if not all_columns:
+        b[..., MASK] += 100.0                                    # the MASK column must not count
+    # one NON-neighbouring pair with a large error difference on one row: invisible to the pair statistic, seen by the range
+    b[1, 2, 100] += 0.05
+    b[1, 2, 101] += 0.05
+    b[1, 2, 102] += 0.05
+    b[1, 2, 3000] -= 0.05
+    b[1, 2, 3001] -= 0.05
+    b[1, 2, 3002] -= 0.05
     x = torch.full((n, L), MASK, dtype=torch.int64)
     x[:, 3:9] = 7
     x[2] = 5
-    got = eng.logit_error_stats(a[..., :V], b, x.cuda()).cpu().double()
-    e = (a[..., :V] - b[..., :V]).cpu().double()
-    keep = [v for v in range(V) if v != MASK]
+    got = eng.logit_error_stats(a[..., :V], b, x.cuda(), all_columns).cpu().double()
+    assert got.shape == (n, L, 8)
+    ad, bd = a[..., :V].cpu().double(), b[..., :V].cpu().double()
+    e = ad - bd
+    keep = list(range(V)) if all_columns else [v for v in range(V) if v != MASK]
     d = e[..., :-1] - e[..., 1:]
-    dk = [v for v in range(V - 1) if v != MASK and v + 1 != MASK]
-    want = torch.stack([e[..., keep].abs().amax(-1), (e[..., keep] ** 2).sum(-1), d[..., dk].abs().amax(-1), (d[..., dk] ** 2).sum(-1)], -1)
+    dk = list(range(V - 1)) if all_columns else [v for v in range(V - 1) if v != MASK and v + 1 != MASK]
+    H = lambda z: -(torch.log_softmax(z, -1).exp() * torch.log_softmax(z, -1)).sum(-1)
+    ha, hb = H(ad[..., keep]), H(bd[..., keep])
+    want = torch.stack([e[..., keep].abs().amax(-1), (e[..., keep] ** 2).sum(-1), d[..., dk].abs().amax(-1), (d[..., dk] ** 2).sum(-1),
+                        e[..., keep].amax(-1) - e[..., keep].amin(-1), ha - hb, hb, torch.zeros_like(hb)], -1)
     want = want * (x == MASK)[..., None]
     assert torch.equal(got[x != MASK], torch.zeros_like(got[x != MASK]))
     assert float((got[..., 0] - want[..., 0]).abs().max()) == 0 and float((got[..., 2] - want[..., 2]).abs().max()) == 0
+    assert float((got[..., 4] - want[..., 4]).abs().max()) < 1e-7
     assert float(((got[..., 1] - want[..., 1]) / want[..., 1].clamp_min(1e-30)).abs().max()) < 1e-5
     assert float(((got[..., 3] - want[..., 3]) / want[..., 3].clamp_min(1e-30)).abs().max()) < 1e-5
+    assert float((got[..., 5] - want[..., 5]).abs().max()) < 3e-6 and float((got[..., 6] - want[..., 6]).abs().max()) < 1e-5
+    assert float(got[1, 2, 4]) > 0.099 and float(got[1, 2, 2]) < 0.06         # the injected pair: range 0.1, largest neighbour error 0.05
+
+
+def _gibbs_case(rng, B, L, scale, frac_known=0.0):
+    z = rng.standard_normal((B, L, 4104)).astype(np.float32) * scale
+    seq = np.concatenate([[0], rng.integers(4, 24, L - 2), [2]])[None].repeat(B, 0).astype(np.int64)
+    x = np.full((B, L), MASK, dtype=np.int64)
+    x[:, 0], x[:, -1] = 4098, 4097
+    known = rng.random((B, L)) < frac_known
+    known[:, 0] = known[:, -1] = False
+    x[known] = rng.integers(0, 4096, int(known.sum()))
+    return z, seq, x
+
+
+def test_gibbs_rows_equals_plain_step_per_prompt_and_margin_report(tiny):
+    """esmdiff_gibbs_step_rows (ABI 8): a batch whose prompts sit at different steps (own Philox index, step, count) = every prompt
+    alone through esmdiff_gibbs_step with its scalars, ids bit for bit, and through the C oracle; with bounds the ids are the
+    same and the per-prompt report lies between the float64 restatement's (oracle/gibbs_margin_ref.py) at 2 % tighter and 2 %
+    wider bounds — flags are monotone in the bounds, so only decisions within 2 % of a bound may differ."""
+    from oracle import c_oracle
+    from oracle import gibbs_margin_ref as M
+    from esmdiff_amd import _native as N
+    _, _, eng, _, _ = tiny
+    rng = np.random.default_rng(17)
+    n_flag = n_clear = 0
+    for case in range(14):
+        B, L = int(rng.integers(1, 7)), int(rng.integers(4, 29))
+        scale = float(rng.choice([0.3, 0.6, 3.0, 12.0]))
+        z, seq, x = _gibbs_case(rng, B, L, scale, float(rng.choice([0.0, 0.4])))
+        if case % 4 == 1:
+            z[:, ::3, 4099] += 6.0 * scale                   # a heavy special id inside the nucleus of some rows
+        temp, top_p = float(rng.choice([0.0, 0.7, 1.4])), float(rng.choice([0.5, 0.9, 1.0]))
+        idx, steps, ks = rng.integers(0, 2 ** 40, B), rng.integers(0, 60, B), rng.integers(0, 6, B)
+        seed = int(rng.integers(0, 2 ** 31))
+        R, E = float(rng.choice([2e-3, 2e-2, 0.2])), float(rng.choice([1e-5, 1e-3, 3e-2]))
+        xt, st, zt = torch.from_numpy(x).cuda(), torch.from_numpy(seq).cuda(), torch.from_numpy(z).cuda()
+        par = torch.from_numpy(eng.gibbs_step_params_host(idx, steps, ks)).cuda()
+        flags = torch.zeros(B, dtype=torch.int32, device="cuda")
+        gaps = torch.full((B, 2), float("inf"), device="cuda")
+        got = eng.gibbs_step_rows(xt.clone(), st, zt, temp, top_p, par, seed=seed, pair_bound=R, entropy_bound=E, flags=flags, gaps=gaps)
+        plain = eng.gibbs_step_rows(xt.clone(), st, zt, temp, top_p, par, seed=seed)
+        assert torch.equal(got, plain), case
+        for b in range(B):
+            one = eng.gibbs_step(xt[b:b + 1].clone(), st[b:b + 1], zt[b:b + 1], temp, top_p, torch.tensor([int(ks[b])], dtype=torch.int32),
+                                 seed=seed, sample_offset=int(idx[b]), step=int(steps[b]))
+            assert torch.equal(got[b:b + 1], one), (case, b)
+        rec = np.zeros(B, dtype=N.GIBBS_STEP_DTYPE)
+        rec["sample_index"], rec["step"], rec["n_unmask"] = idx, steps, ks
+        want, f_lo, g_ref = M.gibbs_step_rows(x, seq, z, temp, top_p, rec, seed, R=R * 0.98, E=E * 0.98, vocab=4101)
+        _, f_hi, _ = M.gibbs_step_rows(x, seq, z, temp, top_p, rec, seed, R=R * 1.02, E=E * 1.02, vocab=4101)
+        assert np.array_equal(got.cpu().numpy(), want), case
+        f = flags.cpu().numpy()
+        assert ((f_lo & ~f) == 0).all() and ((f & ~f_hi) == 0).all(), (case, f.tolist(), f_lo.tolist(), f_hi.tolist(), temp, top_p, R, E)
+        gp = gaps.cpu().numpy()
+        for b in range(B):
+            if ks[b] <= 0 or not (x[b] == MASK).any():
+                assert f[b] == 0 and np.isinf(gp[b]).all()
+                continue
+            for c in range(2):
+                if g_ref[b, c] < 1e30:
+                    assert abs(gp[b, c] - g_ref[b, c]) <= 3e-5 * max(1.0, abs(g_ref[b, c])) + 3e-6, (case, b, c, gp[b], g_ref[b])
+            n_flag += int(f[b] != 0)
+            n_clear += int(f[b] == 0)
+    assert n_flag >= 5 and n_clear >= 5, (n_flag, n_clear)       # both outcomes were exercised
+    with pytest.raises(RuntimeError, match="pair_bound"):
+        lib_flags = torch.zeros(B, dtype=torch.int32, device="cuda")
+        eng._chk(eng._lib.esmdiff_gibbs_step_rows(eng._h, xt.data_ptr(), st.data_ptr(), zt.data_ptr(), 4104, 1.0, 0.9, par.data_ptr(), 1, B, L,
+                                                  -1.0, 0.0, lib_flags.data_ptr(), None, None))
+
+
+def test_gibbs_margin_unflagged_prompts_are_invariant_under_bounded_errors(tiny):
+    """What the report of esmdiff_gibbs_step_rows certifies: an UNFLAGGED prompt's new ids are those any logits within the
+    bounds would have produced.  For random rows, eight error fields whose range is below R — random, and adversarial ones
+    (everything above the nucleus cut pushed down and everything below pushed up, and the reverse; the runner-up of the race
+    pushed up; low-entropy rows pushed towards high entropy) — and E = the largest entropy change they cause: every unflagged
+    prompt draws the same ids from the perturbed logits; flagged prompts exist and some of them do change."""
+    _, _, eng, _, _ = tiny
+    rng = np.random.default_rng(23)
+    tot = {"unflagged": 0, "flagged": 0, "flagged_changed": 0}
+    for case in range(6):
+        B, L = 6, 24
+        scale = float([0.4, 0.6, 1.0, 3.0, 0.6, 6.0][case])
+        temp, top_p = (1.4, 0.9) if case != 4 else (0.0, 0.8)
+        R = float([0.02, 0.05, 0.05, 0.1, 0.05, 0.2][case])
+        z, seq, x = _gibbs_case(rng, B, L, scale)
+        ks = rng.integers(1, 6, B)
+        idx, steps, seed = np.arange(B) + 50, rng.integers(0, 20, B), 7 + case
+        zd = z[..., :V].astype(np.float64)
+        p = np.exp(zd - zd.max(-1, keepdims=True))
+        p /= p.sum(-1, keepdims=True)
+        order = np.argsort(-zd, -1)
+        cum = np.take_along_axis(np.cumsum(np.take_along_axis(p, order, -1), -1), np.argsort(order, -1), -1)   # mass of {z_j >= z_v}
+        fields = [rng.uniform(-R / 2, R / 2, zd.shape) * 0.99 for _ in range(4)]
+        fields.append(np.where(cum <= top_p, -R / 2, R / 2) * 0.99)         # squeeze the nucleus from both sides
+        fields.append(np.where(cum <= top_p, R / 2, -R / 2) * 0.99)
+        Hrow = -(p * np.log(np.maximum(p, 1e-300))).sum(-1)
+        surpr = -np.log(np.maximum(p, 1e-300)) - Hrow[..., None]
+        fields.append(np.sign(surpr) * R / 2 * 0.99)                        # the steepest entropy change a range-R error allows
+        fields.append(-np.sign(surpr) * R / 2 * 0.99)
+
+        def H(zz):
+            q = np.exp(zz - zz.max(-1, keepdims=True))
+            q /= q.sum(-1, keepdims=True)
+            return -(q * np.log(np.maximum(q, 1e-300))).sum(-1)
+        E = max(float(np.abs(H(zd + f) - H(zd)).max()) for f in fields) * 1.02 + 1e-6
+        xt, st = torch.from_numpy(x).cuda(), torch.from_numpy(seq).cuda()
+        par = torch.from_numpy(eng.gibbs_step_params_host(idx, steps, ks)).cuda()
+        flags = torch.zeros(B, dtype=torch.int32, device="cuda")
+        base = eng.gibbs_step_rows(xt.clone(), st, torch.from_numpy(z).cuda(), temp, top_p, par, seed=seed, pair_bound=R, entropy_bound=E,
+                                   flags=flags).cpu()
+        f = flags.cpu().numpy()
+        changed = np.zeros(B, bool)
+        for fld in fields:
+            zp = z.copy()
+            zp[..., :V] = (zd + fld).astype(np.float32)
+            other = eng.gibbs_step_rows(xt.clone(), st, torch.from_numpy(zp).cuda(), temp, top_p, par, seed=seed).cpu()
+            changed |= (other != base).any(1).numpy()
+        assert not (changed & (f == 0)).any(), (case, f.tolist(), changed.tolist())
+        tot["unflagged"] += int((f == 0).sum())
+        tot["flagged"] += int((f != 0).sum())
+        tot["flagged_changed"] += int((changed & (f != 0)).sum())
+    assert tot["unflagged"] >= 6 and tot["flagged"] >= 6 and tot["flagged_changed"] >= 2, tot
 
 
 def test_sampler_full_size_config2(tiny):

@@ -443,7 +443,7 @@ def test_cli_precision_flags(tmp_path):
     assert (tmp_path / "T1.4_step4_topp0.9_N3" / "synthetic30.tokens.npy").exists()
     # the bf16 engine on the same seed: same ids on this tiny case or not, but its json says bf16 / f32 decoder
     out2 = tmp_path / "bf16"
-    main([a if a != str(tmp_path) else str(out2) for a in common[:-2]] + ["--mode", "ddpm"])
+    main([a if a != str(tmp_path) else str(out2) for a in common[:-2]] + ["--precision", "bf16", "--head_precision", "bf16", "--mode", "ddpm"])
     meta2 = json.loads((out2 / "step4_eps1e-05_N3" / "synthetic30.json").read_text())
     assert meta2["precision"] == "bf16" and meta2["decoder_precision"] == "f32"
     # r04: float32 grade on the f16 MFMA (sampler AND decoder) must give the exact-f32 run's ids on the same seed; the f16 engine
@@ -1073,6 +1073,152 @@ def test_certified_sampler_inpainting_prior_small_batches_and_streaming(streamed
     assert torch.equal(got2, exact.ddpm_sample(seq[:1].repeat(B, 1), sch, seed=4)) and cs.stats["first_update_shared"]
     fast.close()
     exact.close()
+
+
+@pytest.mark.parametrize("streamed", [False, True])
+def test_certified_gibbs_tiny_with_coordinates_ragged_and_streaming(streamed):
+    """CertifiedSampler.gibbs_sample on the real engines (TINY model, the reference's default mode, sample_esmdiff.py:66-130):
+    prompts with different numbers of masked positions, per-prompt backbone frames (block 0's geometric attention), verification
+    batches of 3, every unflagged step audited, and — streamed — more prompts than the fast engine's max_batch in one call.  Bar:
+    every id equal to the F32_SPLIT engine's own gibbs chain, 0 audit mismatches; then the reference's call shape
+    (iterative_sampling_raw on a precision="certified" model) against the same chain."""
+    from esmdiff_amd.certified import CertifiedSampler
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.geometry import build_affine3d_from_coordinates
+    from esmdiff_amd.gibbs import unmask_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    sd = random_init_state_dict(TINY, seed=6, with_geom=True)
+    B, L, steps = 9, 40, 7
+    g = torch.Generator().manual_seed(41)
+    seq = torch.stack([_seq(1, L, g)[0] for _ in range(B)]).cuda()
+    x0 = torch.randint(0, 4096, (B, L), generator=g)
+    x0[:, 0], x0[:, -1] = 4098, 4097
+    masked = [38, 20, 5, 0, 38, 12, 1, 30, 38]
+    for b, n in enumerate(masked):
+        x0[b, 1:1 + n] = MASK
+    T = max(min(steps, n) for n in masked)
+    table = torch.zeros(T, B, dtype=torch.int32)
+    for b, n in enumerate(masked):
+        sch = unmask_schedule(n, steps)
+        table[:len(sch), b] = torch.tensor(sch, dtype=torch.int32)
+    xyz = torch.cumsum(torch.randn(B, L, 3, 3, generator=g) * 1.5, 1)
+    xyz[:, 5:9] = float("inf")                                   # residues without a frame
+    frames = build_affine3d_from_coordinates(xyz)
+    exact = Engine(TINY, sd, max_batch=B, max_len=L, precision="f32_split")
+    fast = Engine(TINY, sd, max_batch=4 if streamed else B, max_len=L, precision="f16", head_precision="f32")
+    exact.set_frames(*frames)
+    want = exact.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=3, sample_offset=10)
+    exact.set_frames(None)
+    cs = CertifiedSampler(fast, exact, verify_batch=3, audit_rate=1.0)
+    got = cs.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=3, sample_offset=10, frames=frames)
+    st = cs.stats
+    assert torch.equal(got, want), st
+    assert int((got == MASK).sum()) == 0 and torch.equal(got[3].cpu(), x0[3])
+    assert st["mode"] == "gibbs" and st["lane_width"] == (4 if streamed else B) and not st["first_update_shared"]
+    assert st["audit_mismatches"] == 0 and st["eps_violations"] == 0 and st["entropy_violations"] == 0, st
+    n_steps = sum(sum(1 for k in unmask_schedule(n, steps) if k > 0) for n in masked)
+    assert st["audit_checked"] + st["flagged"] >= n_steps             # every step that drew was verified one way or the other
+    assert st["sample_forwards_fast"] <= n_steps + 2 + 3 * st["corrections"] + st["rollback_updates_discarded"] + 4
+    # without frames the chain is another one (the conditioning is live), and it is certified too; identical prompts share step 0
+    seq1, x1 = seq[:1].repeat(B, 1), x0[:1].repeat(B, 1)
+    tab1 = table[:, :1].repeat(1, B)
+    got2 = cs.gibbs_sample(seq1, x1, tab1, 1.4, 0.9, seed=4)
+    assert torch.equal(got2, exact.gibbs_sample(seq1, x1, tab1, 1.4, 0.9, seed=4)) and cs.stats["first_update_shared"]
+    assert not torch.equal(got2[0], got[0])
+    fast.close()
+    exact.close()
+
+
+def test_certified_gibbs_through_iterative_sampling_raw_and_cli(tmp_path):
+    """The reference's call shape on a precision="certified" model (what the CLI's default mode builds): ids = the F32_SPLIT
+    engine's gibbs chain, for plain prompts and for inpainting with coordinates; the CLI defaults to --precision certified and
+    writes the certificate's counters next to the tokens."""
+    import json
+    from esmdiff_amd.config import TINY
+    from esmdiff_amd.gibbs import iterative_sampling_raw
+    from esmdiff_amd.model import random_init_model
+    from esmdiff_amd.sdk import ESMProtein, GenerationConfig
+    seqs = "RPDFCLEPPYTGPCKARIIRYFYNAKAGLCQTFVYGGCRAKRNNFKSAEDCMRTCGGA"
+    model = random_init_model(TINY, seed=2, max_batch=4, max_len=60, precision="certified")
+    split = random_init_model(TINY, seed=2, max_batch=8, max_len=60, precision="f32_split")
+    n = 6                                                        # more than max_batch = 4: streamed through the fast lane
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.cumsum(torch.randn(58, 3, 3, generator=g) * 1.5, 0)
+    xyz[20:30] = float("inf")
+    for coords in (None, xyz):
+        prots = [ESMProtein(sequence=seqs, coordinates=coords) for _ in range(n)]
+        cfgs = [GenerationConfig(track="structure", num_steps=9, temperature=1.4, top_p=0.9) for _ in range(n)]
+        out = iterative_sampling_raw(model, prots, cfgs, seed=5, sample_offset=2)
+        ref = iterative_sampling_raw(split, prots, cfgs, seed=5, sample_offset=2)
+        assert all(torch.equal(a.structure_tokens, b.structure_tokens) for a, b in zip(out, ref))
+        assert model.certified.stats["mode"] == "gibbs" and model.certified.stats["audit_mismatches"] == 0
+    from esmdiff_amd import sample_esmdiff as cli
+    args = ["--random_init", "--tiny", "--synthetic_len", "30", "--num_samples", "5", "--num_steps", "6", "--no_timestamp", "--seed", "1"]
+    cli.main(args + ["--output", str(tmp_path / "c")])                                     # default mode (gibbs), default precision
+    cli.main(args + ["--output", str(tmp_path / "s"), "--precision", "f32_split"])
+    jc = next((tmp_path / "c").rglob("*.json"))
+    rec = json.loads(jc.read_text())
+    assert rec["precision"] == "certified" and rec["mode"] == "gibbs" and rec["certified"]["certificate"] == "k-sigma statistical + audit"
+    tc = np.load(next((tmp_path / "c").rglob("*.tokens.npy")))
+    ts = np.load(next((tmp_path / "s").rglob("*.tokens.npy")))
+    assert np.array_equal(tc, ts) and tc.shape == (5, 30)
+
+
+def test_certified_gibbs_equals_f32_split_chain_configs1_full_batch():
+    """The CLI's default mode at BASELINE configs[1]'s size (100 prompts x 256 residues, 25 steps, temperature 1.4, top-p 0.9,
+    48 blocks): CertifiedSampler.gibbs_sample (f16 + f32-grade head draws, decisions left open by the measured error bounds
+    verified on F32_SPLIT in batches, 2 % audit) against the F32_SPLIT engine's own gibbs chain.  Bar: every id equal, cold call
+    and three more seeds; 0 audit mismatches / violations; >= 1.6x the F32_SPLIT engine's rate (VERDICT r05 item 1 asks 1.8x of the
+    soak, profiles/r06_certified_gibbs_soak.txt)."""
+    import time
+    from esmdiff_amd.certified import CertifiedSampler
+    from esmdiff_amd.config import ESM3_OPEN
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.gibbs import unmask_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ESM3_OPEN
+    sd = random_init_state_dict(cfg, seed=11, device="cuda")
+    B, L, T = 100, 258, 25
+    g = torch.Generator().manual_seed(258)
+    seq = _seq(B, L, g).cuda()
+    x0 = torch.full((B, L), MASK, dtype=torch.int64)
+    x0[:, 0], x0[:, -1] = 4098, 4097
+    table = torch.tensor(unmask_schedule(L - 2, T), dtype=torch.int32)[:, None].repeat(1, B)
+    exact = Engine(cfg, sd, max_batch=B, max_len=L, precision="f32_split")
+    fast = Engine(cfg, sd, max_batch=B, max_len=L, precision="f16", head_precision="f32")
+    ref = exact.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=23)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    exact.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=23)
+    torch.cuda.synchronize(); t_split = time.perf_counter() - t0
+    plain = fast.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=23)
+    cs = CertifiedSampler(fast, exact)
+    cold = cs.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=23)
+    cold_stats = cs.stats
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    got = cs.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=23)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    st = cs.stats
+    keys = ("flagged", "flag_reasons", "corrections", "rollback_updates_discarded", "audit_checked", "audit_mismatches", "eps_violations",
+            "entropy_violations", "sample_forwards_exact", "sample_forwards_fast", "fast_launches", "eps_max_used", "entropy_eps_max_used",
+            "sigma_pair_err", "max_range_err_observed", "sigma_entropy_err", "max_entropy_err_observed", "rerun_share",
+            "order_share_vs_bound", "rerun_share_vs_eps", "gpu_seconds_fast", "gpu_seconds_verify")
+    more = []
+    for s_ in (101, 102, 103):
+        more.append(bool(torch.equal(cs.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=s_), exact.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=s_))))
+    out = {"B": B, "L_tok": L, "steps": T, "f32_split_alone_seconds": round(t_split, 2), "seconds": round(dt, 2),
+           "samples_per_s": round(B / dt, 2), "ids_equal_to_f32_split_chain": bool(torch.equal(got, ref)) and bool(torch.equal(cold, ref)),
+           "uncertified_f16_samples_identical": int((plain == ref).all(1).sum()), "more_seeds_identical": more,
+           "more_seeds_audit_mismatches": cs.stats["audit_mismatches"],
+           "first_call": {k: cold_stats.get(k) for k in keys}, **{k: st.get(k) for k in keys}}
+    fast.close()
+    exact.close()
+    del sd
+    _record("certified_gibbs_configs1_full_batch", out)
+    assert out["ids_equal_to_f32_split_chain"] and all(more), out
+    for part in (out, out["first_call"]):
+        assert part["audit_mismatches"] == 0 and part["eps_violations"] == 0 and part["entropy_violations"] == 0, part
+    assert out["samples_per_s"] > 1.6 * B / out["f32_split_alone_seconds"], out
 
 
 def test_model_wrapper_semantics_vs_reference_parameterization():

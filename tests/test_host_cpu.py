@@ -35,7 +35,8 @@ def test_library_exports_every_declared_symbol():
     from esmdiff_amd.build import build
     lib_path = build()
     assert lib_path.exists()
-    header = (ROOT / "include" / "esmdiff_hip.h").read_text()
+    surface = (ROOT / "include" / "esmdiff_hip.h").read_text()
+    header = surface + (ROOT / "include" / "esmdiff_hip_test.h").read_text()
     header = re.sub(r"#ifdef ED_DEBUG.*?#endif /\* ED_DEBUG \*/", "", header, flags=re.S)   # measurement aids of debug builds
     assert "esmdiff_debug_graph_ab" not in header
     declared = set(re.findall(r"\b(esmdiff_[a-z0-9_]+)\s*\(", header))
@@ -46,12 +47,24 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
     # both operand-type builds of the kernels are linked in (csrc/ed_half.h: namespace ed = bf16, ed16 = f16)
     import subprocess
-    syms = subprocess.run(["nm", "-D", "--defined-only", str(lib_path)], capture_output=True, text=True).stdout
+    syms = subprocess.run(["nm", "--defined-only", str(lib_path)], capture_output=True, text=True).stdout
     for fn in ("launch_gemm_bf16", "launch_attention", "launch_add_layernorm_bf16", "launch_qk_norm_rope", "launch_to_bf16"):
         assert f"_ZN2ed{len(fn)}{fn}" in syms and f"_ZN4ed16{len(fn)}{fn}" in syms, fn
+    # ... but the DYNAMIC symbol table is the C ABI and nothing else: no C++ internal is exported
+    dyn = subprocess.run(["nm", "-D", "--defined-only", str(lib_path)], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in dyn.splitlines() if ln.strip()}
+    assert not [n for n in exported if n.startswith("_Z")], sorted(n for n in exported if n.startswith("_Z"))[:5]
+    assert exported == declared, exported ^ declared
+    # the drop-in surface (esmdiff_hip.h) holds no per-kernel test entry point; those live in esmdiff_hip_test.h
+    for name in ("esmdiff_gemm_bf16", "esmdiff_gemm_split", "esmdiff_split_rows", "esmdiff_layernorm_bf16", "esmdiff_attention_bf16",
+                 "esmdiff_branch_linear_layernorm", "esmdiff_set_profiling"):
+        assert name not in re.findall(r"\b(esmdiff_[a-z0-9_]+)\s*\(", surface), name
+    for name in ("esmdiff_ddpm_sample", "esmdiff_forward_logits", "esmdiff_ddpm_step", "esmdiff_gibbs_step", "esmdiff_engine_create",
+                 "esmdiff_gibbs_step_rows", "esmdiff_ddpm_step_rows"):
+        assert name in re.findall(r"\b(esmdiff_[a-z0-9_]+)\s*\(", surface), name
     # the product library carries no debug exports
     assert not hasattr(L, "esmdiff_debug_graph_ab") and not hasattr(L, "esmdiff_gemm_bf16_timed")
-    assert L.esmdiff_abi_version() == 7
+    assert L.esmdiff_abi_version() == 8
 
 
 def test_config_dimensions():
@@ -100,7 +113,7 @@ def test_product_library_reads_no_tuning_environment():
     stray = {n for n in names if not enum_like.match(n)} - {"ESMDIFF_DEBUG_SKIP", "ESMDIFF_"}
     assert not stray, f"the product library mentions environment switches: {sorted(stray)}"
     info = N.build_info()
-    assert "abi=7" in info and "arch=gfx950" in info and "debug_env=0" in info, info
+    assert "abi=8" in info and "arch=gfx950" in info and "debug_env=0" in info, info
     for sym in ("esmdiff_set_option", "esmdiff_describe_plan", "esmdiff_get_build_info"):
         assert hasattr(N.lib(), sym)
 
