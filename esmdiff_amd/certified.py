@@ -36,13 +36,21 @@ forces a flagged sample to be settled in the update it was flagged in:
               the count again.  An audit whose ids differ is a certification miss: counted (`audit_mismatches`), repaired by the
               same roll-back, and its error raises the bounds.
 
+  direct      speculation only pays while few sample-updates need the slow lane: a verified sample-update costs an f32-grade
+              forward ON TOP of the fast one.  When more than `direct_share` (0.5) of the last two lanes' worth of sample-updates were
+              flagged, the rest of the call runs on the f32-grade engine alone (its draws need no certificate), so a certified call is
+              never much slower than the f32-grade engine by itself.  That is the regime of the gibbs mode on weights whose output
+              distributions are all nearly uniform (random initialisation): the entropies of the positions then lie ~4e-5 apart and
+              the ORDER of two of them is decided below what f16 resolves (profiles/r06_certified_gibbs_*.txt).
+
 The bounds come from the MEASURED error of this engine pair, not from a model of it: every verified item yields both engines'
 logits for the same input; esmdiff_logit_error_stats reduces them per token row to the maximum and r.m.s. of the logit error e,
 of the neighbouring-pair error d_v = e_v - e_(v+1), the row's range max e - min e, and the entropy error.  The pair that decides
 a draw is arbitrary (winner and runner-up of a noisy race), so the bound in use is
 
     P = max(k_sigma * (largest per-row r.m.s. of d seen), max_factor * (largest row RANGE seen))          (eps = P / 2)
-    E = max(k_sigma * (largest per-item r.m.s. of the entropy error seen), max_factor * (largest entropy error seen))
+    2 E = max(k_sigma * sqrt(2) * (largest per-item r.m.s. of the entropy error seen),
+              max_factor * (largest difference of the entropy errors of two rows of one sample seen))
 
 widened by `boot_factor` until `n_boot` items have been seen; while NOTHING has been seen every sample-update is verified.  A
 verified item whose range exceeds the P its update was certified with (or whose entropy error exceeds E) is a `violation`; it
@@ -72,7 +80,8 @@ _GAP_GRID = (0.25, 0.5, 1.0, 2.0, 4.0)      # stats["rerun_share_vs_eps"]: multi
 CERTIFICATE = "k-sigma statistical + audit"
 
 # columns of the per-item statistics (one row per verified sample-update)
-_ME, _SE, _MD, _SD, _ROWS, _SDROW, _RANGE, _MDH, _SDH = range(9)
+_ME, _SE, _MD, _SD, _ROWS, _SDROW, _RANGE, _MDH, _SDH, _RDH = range(10)
+_NSTAT = 10
 
 
 class _Async:
@@ -196,7 +205,7 @@ class CertifiedSampler:
     def __init__(self, fast: Engine, exact: Engine, eps: Optional[float] = None, *, k_sigma: float = 6.0,
                  max_factor: float = 1.05, eps_floor: float = 1e-5, audit_rate: float = 0.02, verify_batch: int = 32,
                  n_boot: int = 8, boot_factor: float = 1.5, audit_seed: int = 0, audit_rate_steady: Optional[float] = None,
-                 audit_clean_target: int = 500, entropy_eps: Optional[float] = None):
+                 audit_clean_target: int = 500, entropy_eps: Optional[float] = None, direct_share: float = 0.5):
         if fast.device != exact.device:
             raise ValueError("both engines must live on the same GPU")
         if eps is not None and not eps > 0:
@@ -209,6 +218,9 @@ class CertifiedSampler:
             raise ValueError("audit_rate must be in [0, 1]")
         if verify_batch < 1:
             raise ValueError("verify_batch must be >= 1")
+        if not 0.0 < direct_share <= 1.0:
+            raise ValueError("direct_share must be in (0, 1]")
+        self.direct_share = float(direct_share)      # see _run: above this share of verified sample-updates the exact engine draws itself
         self.fast, self.exact = fast, exact
         self.eps = None if eps is None else float(eps)          # None: from the error distribution (module docstring)
         self.entropy_eps = None if entropy_eps is None else float(entropy_eps)
@@ -228,6 +240,7 @@ class CertifiedSampler:
         self.err_seen = 0.0          # largest |e| (r04's statistic, kept for the reports)
         self.sigma_h_seen = 0.0      # largest per-item r.m.s. of the entropy error
         self.max_dh_seen = 0.0       # largest entropy error
+        self.range_dh_seen = 0.0     # largest difference of the entropy errors of two rows of one sample (what decides their order)
         self.n_seen = 0              # verified items the estimate rests on
         self.pair_raise = 0.0        # pair bound forced by violations (also with a fixed eps)
         self.entropy_raise = 0.0
@@ -244,10 +257,12 @@ class CertifiedSampler:
         return max(p, self.pair_raise, 2.0 * self.eps_floor)
 
     def entropy_bound(self) -> float:
-        """E: the bound on the error of a row's entropy (gibbs mode: the order of the positions)."""
+        """E: half of the bound on the error of the DIFFERENCE of two rows' entropies (gibbs mode: the order of the positions; the
+        kernel asks for 2 E between the last selected and the first unselected one): k_sigma x the r.m.s. of a difference of two
+        independent entropy errors, or max_factor x the largest difference seen between two rows of one sample."""
         if self.entropy_eps is not None:
             return max(self.entropy_eps, self.entropy_raise)
-        e = max(self.k_sigma * self.sigma_h_seen, self.max_factor * self.max_dh_seen)
+        e = 0.5 * max(self.k_sigma * math.sqrt(2.0) * self.sigma_h_seen, self.max_factor * self.range_dh_seen)
         if self.n_seen < self.n_boot:
             e *= self.boot_factor
         return max(e, self.entropy_raise, 1e-7)
@@ -263,8 +278,8 @@ class CertifiedSampler:
         return self.n_seen == 0 and (self.eps is None or (gibbs and self.entropy_eps is None))
 
     def _observe_items(self, st: np.ndarray, V: int) -> None:
-        """st (n, >= 9): per item max |e|, sum e^2, max |d|, sum d^2, masked rows, largest per-row sum d^2, largest row range,
-        largest |entropy error|, sum of its squares."""
+        """st (n, >= 10): per item max |e|, sum e^2, max |d|, sum d^2, masked rows, largest per-row sum d^2, largest row range,
+        largest |entropy error|, sum of its squares, range of the entropy error over the item's masked rows."""
         for it in st:
             rows = it[_ROWS]
             if rows <= 0:
@@ -277,15 +292,19 @@ class CertifiedSampler:
             self.sigma_d_item_seen = max(self.sigma_d_item_seen, math.sqrt(float(it[_SD]) / (rows * (V - 2))))
             self.sigma_d_seen = max(self.sigma_d_seen, math.sqrt(float(it[_SDROW]) / (V - 2)))
             self.max_dh_seen = max(self.max_dh_seen, float(it[_MDH]))
+            self.range_dh_seen = max(self.range_dh_seen, float(it[_RDH]))
             self.sigma_h_seen = max(self.sigma_h_seen, math.sqrt(float(it[_SDH]) / rows))
 
     def _item_stats(self, lg_fast: torch.Tensor, lg_exact: torch.Tensor, x_in: torch.Tensor, all_columns: bool) -> torch.Tensor:
-        """(n, 9) on the device, per sample over its masked rows (column order: _ME .. _SDH)."""
+        """(n, 10) on the device, per sample over its masked rows (column order: _ME .. _RDH)."""
         st = self.exact.logit_error_stats(lg_fast, lg_exact, x_in, all_columns)
-        rows = (x_in == STRUCTURE_MASK_TOKEN).sum(1).to(torch.float32)
+        m = x_in == STRUCTURE_MASK_TOKEN
+        rows = m.sum(1).to(torch.float32)
         dh = st[..., 5]
+        inf = torch.full_like(dh, float("inf"))
+        rdh = (torch.where(m, dh, -inf).amax(1) - torch.where(m, dh, inf).amin(1)).clamp_min(0.0).nan_to_num(0.0, 0.0, 0.0)
         return torch.stack([st[..., 0].amax(1), st[..., 1].sum(1), st[..., 2].amax(1), st[..., 3].sum(1), rows, st[..., 3].amax(1),
-                            st[..., 4].amax(1), dh.abs().amax(1), (dh * dh).sum(1)], 1)
+                            st[..., 4].amax(1), dh.abs().amax(1), (dh * dh).sum(1), rdh], 1)
 
     # ---- the two entry points ---------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -371,7 +390,10 @@ class CertifiedSampler:
               "audit_max_logit_err": 0.0, "audit_max_pair_err": 0.0, "audit_max_range_err": 0.0, "corrections": 0, "eps_violations": 0,
               "entropy_violations": 0, "rollback_updates_discarded": 0, "sample_forwards_fast": 0, "sample_forwards_exact": 0,
               "max_logit_err_observed": 0.0, "max_pair_err_observed": 0.0, "max_range_err_observed": 0.0,
-              "max_entropy_err_observed": 0.0, "flagged_per_update": [0] * max(Tmax, 1), "eps_used": [], "entropy_eps_used": []}
+              "max_entropy_err_observed": 0.0, "flagged_per_update": [0] * max(Tmax, 1), "eps_used": [], "entropy_eps_used": [],
+              "direct_lane_from_launch": None, "direct_lane_share_seen": None, "sample_forwards_direct": 0}
+        recent: deque = deque(maxlen=2 * max(W, 16))               # 1 / 0 per live sample-update that drew: did it need the slow lane?
+        direct = [False]                                           # the rest of the call runs on the f32-grade engine alone
         gap_log: List[List[float]] = [[] for _ in range(NG)]       # smallest gaps of every live sample-update / the bound they ran with
         timers: list = []                                          # (lane, start event, end event) of every forward + draw
 
@@ -433,7 +455,32 @@ class CertifiedSampler:
         n_share = min(W, int(getattr(fast, "shared_forward_batch", lambda b, l: 1)(W, L))) if identical else 0
         shared_lg: list = []                                       # the first update's logits of ONE sample, once computed
 
+        def launch_direct(active: np.ndarray) -> None:
+            """The lane on the f32-grade engine itself: plain draws, nothing to flag, verify or audit."""
+            n = len(active)
+            steps = step[active].copy()
+            par = up(params(exact, active, steps))
+            mixed = not (steps == steps[0]).all()
+            steps_d = up(steps) if (mixed and rule.wants_steps_on_device(exact)) else None
+            idx_d = up(active)
+            xa, sa = x[idx_d], seq[idx_d]
+            e0 = tick()
+            rule.before_forward(exact, idx_d)
+            lg = exact.forward_logits(xa, sa, rule.cond(exact, steps, steps_d), check_ids=False)
+            rule.draw(exact, xa, sa, lg, par, seed)
+            timers.append(("direct", e0, tick()))
+            x[idx_d] = xa
+            back = _Async(torch.cat([torch.zeros(n, 1 + NG, device=dev), (xa == MASK).any(1).to(torch.float32)[:, None]], 1))
+            updates.append({"active": active, "steps": steps, "epochs": epoch[active].copy(), "back": back, "direct": True})
+            step[active] += 1
+            mask_known[active] = False
+            rule.skip_empty(step)
+            st["sample_forwards_direct"] += n
+            st["sample_forwards_exact"] += n
+
         def launch_fast(active: np.ndarray, which: int) -> None:
+            if direct[0]:
+                return launch_direct(active[:exact.max_batch])
             n = len(active)
             full = n == B
             steps = step[active].copy()
@@ -486,6 +533,12 @@ class CertifiedSampler:
             res = rec["back"].get()
             fl, gp, hm = res[:, 0], res[:, 1:1 + NG], res[:, 1 + NG]
             live = epoch[rec["active"]] == rec["epochs"]
+            if rec.get("direct"):
+                for j in np.nonzero(live)[0]:
+                    s = int(rec["active"][j])
+                    has_mask[s], mask_known[s] = bool(hm[j] > 0), True
+                    settle_final(s)
+                return
             units = rule.gap_units(rec["bounds"])
             pick, kinds = [], []
             audits_wanted = 2 if (self.eps is None and self.n_seen < self.n_boot) else 0
@@ -498,6 +551,8 @@ class CertifiedSampler:
                     if np.isfinite(gp[j, c]) and units[c] > 0:
                         gap_log[c].append(float(gp[j, c]) / units[c])
                 f = int(fl[j])
+                if drew:
+                    recent.append(1 if f > 0 else 0)
                 if f > 0 or (rec["blind"] and drew):
                     pick.append(j); kinds.append("flag")
                     st["flagged"] += 1
@@ -560,10 +615,10 @@ class CertifiedSampler:
 
         def process_verify(rec) -> None:
             res = rec["back"].get()
-            self._observe_items(res[:, :9], V)
+            self._observe_items(res[:, :_NSTAT], V)
             for j, it in enumerate(rec["items"]):
-                me, md, rg, dh = float(res[j, _ME]), float(res[j, _MD]), float(res[j, _RANGE]), float(res[j, _MDH])
-                neq, hm = res[j, 9] > 0, res[j, 10] > 0
+                me, md, rg, dh, rdh = float(res[j, _ME]), float(res[j, _MD]), float(res[j, _RANGE]), float(res[j, _MDH]), float(res[j, _RDH])
+                neq, hm = res[j, _NSTAT] > 0, res[j, _NSTAT + 1] > 0
                 st["max_logit_err_observed"] = max(st["max_logit_err_observed"], me)
                 st["max_pair_err_observed"] = max(st["max_pair_err_observed"], md)
                 st["max_range_err_observed"] = max(st["max_range_err_observed"], rg)
@@ -579,9 +634,9 @@ class CertifiedSampler:
                     st["eps_violations"] += 1
                     st["audit_eps_violations"] += int(audit)
                     self.pair_raise = max(self.pair_raise, self.max_factor * rg)
-                if gibbs and dh > E_used:
+                if gibbs and rdh > 2.0 * E_used:                 # two rows' entropy errors were further apart than the order test allowed for
                     st["entropy_violations"] += 1
-                    self.entropy_raise = max(self.entropy_raise, self.max_factor * dh)
+                    self.entropy_raise = max(self.entropy_raise, 0.5 * self.max_factor * rdh)
                 s = it["s"]
                 stale = epoch[s] != it["epoch"]
                 if audit and not stale:
@@ -592,7 +647,7 @@ class CertifiedSampler:
                 if audit:                                         # a miss of the certificate: widen the bounds for what follows
                     self.pair_raise = max(self.pair_raise, self.max_factor * max(rg, P_used) * 1.5)
                     if gibbs:
-                        self.entropy_raise = max(self.entropy_raise, self.max_factor * max(dh, E_used) * 1.5)
+                        self.entropy_raise = max(self.entropy_raise, self.max_factor * max(0.5 * rdh, E_used) * 1.5)
                 st["rollback_updates_discarded"] += int(step[s] - (it["k"] + 1))
                 x[s] = rec["xs"][j]
                 step[s] = it["k"] + 1
@@ -615,6 +670,10 @@ class CertifiedSampler:
             # results one iteration late: while the host waits for them the GPU is already inside the forward just launched
             while len(updates) > (1 if len(active) else 0):
                 process_update(updates.popleft())
+            if not direct[0] and len(recent) >= max(W, 16) and sum(recent) > self.direct_share * len(recent):
+                direct[0] = True                                  # too many open decisions for speculation to pay (class docstring)
+                st["direct_lane_from_launch"] = st["fast_launches"]
+                st["direct_lane_share_seen"] = round(sum(recent) / len(recent), 4)
             while verifies:                                       # (launched in an earlier iteration, or nothing else to do)
                 process_verify(verifies.popleft())
             queued = len(pools[fill]["items"])
@@ -632,7 +691,7 @@ class CertifiedSampler:
         st["tail_seconds"] = 0.0 if t_tail is None else round(time.perf_counter() - t_tail, 4)     # after the last full-lane forward
         st["lane_width"] = W
         if timers and timers[0][1] is not None:                   # device time inside the two lanes (HIP events on the stream)
-            for lane in ("fast", "verify"):
+            for lane in ("fast", "verify", "direct"):
                 st[f"gpu_seconds_{lane}"] = round(sum(a.elapsed_time(b) for ln_, a, b in timers if ln_ == lane) * 1e-3, 4)
         gl = np.array(gap_log[0]) if gap_log[0] else np.zeros(0)
         n_upd = max(1, len(gl))
@@ -647,12 +706,13 @@ class CertifiedSampler:
             "max_logit_err_all_calls": self.err_seen, "items_seen_all_calls": self.n_seen, "first_update_shared": bool(identical),
             # share of sample-updates whose smallest gap is within m x the bound in use: what a bound of m x that one would re-run
             "rerun_share_vs_eps": {str(m): round(float((gl <= m).sum()) / n_upd, 5) for m in _GAP_GRID},
-            "rerun_share": round(st["flagged"] / n_upd, 5),
+            "rerun_share": round(st["flagged"] / n_upd, 5), "direct_share": self.direct_share,
         })
         if gibbs:
             gh = np.array(gap_log[1]) if gap_log[1] else np.zeros(0)
             st.update({"entropy_eps_min_used": min(used_h) if used_h else None, "entropy_eps_max_used": max(used_h) if used_h else None,
                        "sigma_entropy_err": self.sigma_h_seen, "max_entropy_err_all_calls": self.max_dh_seen,
+                       "max_entropy_err_difference_all_calls": self.range_dh_seen,
                        "order_share_vs_bound": {str(m): round(float((gh <= m).sum()) / max(1, len(gh)), 5) for m in _GAP_GRID}})
         self.stats = st
         return x

@@ -353,20 +353,43 @@ Part make_part(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, float
 }
 
 // How forward() will cut a batch: number of sub-batch streams, and whether the sub-batches take the small-batch path.
-int plan_parts(const esmdiff_engine* e, int B, int L) {
+// The PATH (small-batch K-slice planes vs the regular kernels: two summation orders, logits that differ at rounding level) is a
+// function of (B, L) alone — it is what the default options choose.  esmdiff_set_option may change how many launch queues run
+// the batch, never the path: a stream count or token threshold that would push the sub-batches across small_max_rows() is
+// reduced until they stay on the default path's side (tests/test_gpu_fullwidth.py::test_stream_options_never_change_a_bit).
+constexpr int kDefaultStreams = 2;
+constexpr int64_t kDefaultDualMinTokens = 2200;
+int parts_for(const esmdiff_engine* e, int B, int L, int n_streams, int64_t dual_min_tokens) {
   const int64_t tokens = (int64_t)B * L;
   if (!e->side.empty() && e->profiling != 1 && B >= 2 &&
-      (tokens >= e->dual_min_tokens || (B >= 8 && tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(768, e->dual_min_tokens))))
-    return std::min<int>({(int)e->side.size() + 1, e->n_streams, B, 4});
+      (tokens >= dual_min_tokens || (B >= 8 && tokens <= e->dual_small_max_tokens && tokens >= std::min<int64_t>(768, dual_min_tokens))))
+    return std::min<int>({(int)e->side.size() + 1, n_streams, B, 4});
   return 1;
 }
-bool plan_small(const esmdiff_engine* e, int B, int L) {
+bool parts_small(const esmdiff_engine* e, int B, int L, int np) {
   if (e->strict) return false;
-  const int np = plan_parts(e, B, L);
   const int b_first = (int)((int64_t)B * 1 / np), b_last = B - (int)((int64_t)B * (np - 1) / np);
   return e->small_fused && e->gemm_ws[0].partial && e->gemm_ws2[0].partial && (int64_t)b_last * L < ed::small_max_rows() &&
          (int64_t)b_first * L < ed::small_max_rows();
 }
+struct BatchPlan {
+  int np;       // sub-batch launch queues
+  bool small;   // the sub-batches take the small-batch path
+};
+BatchPlan plan_batch(const esmdiff_engine* e, int B, int L) {
+#ifdef ED_DEBUG   // (A/B builds move the thresholds themselves: the plan is then whatever the switches say)
+  const int np_dbg = parts_for(e, B, L, e->n_streams, e->dual_min_tokens);
+  return BatchPlan{np_dbg, parts_small(e, B, L, np_dbg)};
+#endif
+  const int np_def = parts_for(e, B, L, kDefaultStreams, kDefaultDualMinTokens);
+  const bool small = parts_small(e, B, L, np_def);
+  int np = parts_for(e, B, L, e->n_streams, e->dual_min_tokens);
+  while (np > 1 && parts_small(e, B, L, np) != small) --np;
+  if (parts_small(e, B, L, np) != small) np = np_def;
+  return BatchPlan{np, small};
+}
+int plan_parts(const esmdiff_engine* e, int B, int L) { return plan_batch(e, B, L).np; }
+bool plan_small(const esmdiff_engine* e, int B, int L) { return plan_batch(e, B, L).small; }
 // Step-0 sharing: the number of leading samples whose forward gives, bit for bit, the logits every sample of an
 // all-identical batch of B would get — a sub-batch that takes the same (regular) dispatch path as the whole batch
 // (tests: test_logits_across_dispatch_paths) — or B when nothing can be saved.

@@ -38,7 +38,18 @@ namespace g4 {
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB
 constexpr int STAGE_BYTES = 4 * HALF_BYTES;  // 64 KiB
-constexpr int GROUP_M = 8;
+// Raster of the tiles an XCD walks (its 32 CUs run 32 consecutive tiles at a time and share that XCD's 4 MB L2):
+//   ED_W4_RASTER 0  groups of GROUP_M tile rows, column by column: a round is GROUP_M rows x 32 / GROUP_M columns
+//   ED_W4_RASTER 1  groups of GROUP_M tile COLUMNS, row by row: a round is 32 / GROUP_M rows x GROUP_M columns — the group's W
+//                   panels (GROUP_M x 0.79 MB at K = 1536) stay in L2 while A streams through
+// (A/B builds: -DED_W4_GROUP_M=<n> -DED_W4_RASTER=<0|1>; the r06 traffic measurements are profiles/r06_gemm_raster_ab.txt)
+#ifndef ED_W4_GROUP_M
+#define ED_W4_GROUP_M 8
+#endif
+#ifndef ED_W4_RASTER
+#define ED_W4_RASTER 0
+#endif
+constexpr int GROUP_M = ED_W4_GROUP_M;
 // ablation builds (-DED_ABL4=<bits>, wrong results by construction): 1 no fragment reads, 2 no LDS-DMA, 4 no MFMA,
 // 8 no global stores (epilogue arithmetic kept), 16 no epilogue at all
 #ifndef ED_ABL4
@@ -117,12 +128,21 @@ __global__ __launch_bounds__(256, 1) void gemm256w4_kernel(const bf16_t* __restr
   auto tile_origin = [&](int vt, int& m0_, int& n0_) {
     const int xcd = vt & 7, qq = n_tiles >> 3, rr = n_tiles & 7;
     const int lin = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (vt >> 3);
-    const int per_group = GROUP_M * tiles_n;
-    const int grp = lin / per_group, in_grp = lin - grp * per_group;
-    const int gm0 = grp * GROUP_M;
-    const int gsz = min(GROUP_M, tiles_m - gm0);
-    m0_ = (gm0 + in_grp % gsz) * BM;
-    n0_ = (in_grp / gsz) * BN;
+    if constexpr (ED_W4_RASTER == 0) {
+      const int per_group = GROUP_M * tiles_n;
+      const int grp = lin / per_group, in_grp = lin - grp * per_group;
+      const int gm0 = grp * GROUP_M;
+      const int gsz = min(GROUP_M, tiles_m - gm0);
+      m0_ = (gm0 + in_grp % gsz) * BM;
+      n0_ = (in_grp / gsz) * BN;
+    } else {
+      const int per_group = GROUP_M * tiles_m;
+      const int grp = lin / per_group, in_grp = lin - grp * per_group;
+      const int gn0 = grp * GROUP_M;
+      const int gsz = min(GROUP_M, tiles_n - gn0);
+      n0_ = (gn0 + in_grp % gsz) * BN;
+      m0_ = (in_grp / gsz) * BM;
+    }
   };
   int m0, n0;
   tile_origin(bid, m0, n0);

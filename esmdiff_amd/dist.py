@@ -57,19 +57,35 @@ def broadcast_state_dict(loader, device, src: int = 0):
     buffer — over RCCL / xGMI from rank src's GPU when the backend is "nccl" (5.5 GB ~ 0.1 s on a ring), over gloo through host
     memory otherwise (CPU tests; two ranks sharing one GPU).  Without a process group (or a world of 1) it is loader() + upload.
 
+    With a process group this is a COLLECTIVE: every rank must call it (load_state_dict_from_lightning_ckpt does).  A failure of
+    `loader()` on the reading rank (missing file, no 'module' entry, no net.* keys ...) is broadcast as a header before anything
+    else, so that EVERY rank raises the reader's error instead of waiting in a collective until the backend's timeout.
+
     Returns (state dict of views into one flat buffer on `device`, timings {"read_s", "upload_s", "broadcast_s", "load_s",
-    "bytes"}); the Engine copies what it needs at create time, after which the flat buffer can be dropped."""
+    "bytes"}); the Engine copies what it needs at create time, after which the flat buffer can be dropped — callers should
+    `del` the returned dict once their engines exist (the float32 checkpoint is 5.5 GB per rank while it lives)."""
     import time
     device = torch.device(device)
     t0 = time.perf_counter()
     multi = dist.is_available() and dist.is_initialized()      # (a world of 1 still goes through the collectives: same code path)
     rank = dist.get_rank() if multi else src
-    sd = loader() if rank == src else None
+    sd, err = None, None
+    if rank == src:
+        try:
+            sd = loader()
+        except Exception as ex:      # reported to every rank below; without a process group it is simply re-raised
+            if not multi:
+                raise
+            err = f"{type(ex).__name__}: {ex}"
     t_read = time.perf_counter()
-    meta = [[(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]] if rank == src else [None]
+    meta = [{"error": err, "meta": None if sd is None else [(k, tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()]}] \
+        if rank == src else [None]
     if multi:
         dist.broadcast_object_list(meta, src=src)
-    meta = meta[0]
+    if meta[0]["error"] is not None:
+        raise RuntimeError(f"checkpoint loading failed on rank {src} (reported to all {dist.get_world_size() if multi else 1} ranks): "
+                           f"{meta[0]['error']}")
+    meta = meta[0]["meta"]
     sizes = [int(torch.empty(0, dtype=getattr(torch, dt)).element_size()) * int(np.prod(shape, dtype=np.int64)) for _, shape, dt in meta]
     offs, tot = [], 0
     for n in sizes:

@@ -407,7 +407,8 @@ class Engine:
 
     def set_streams(self, n_streams: int, min_tokens: Optional[int] = None) -> None:
         """Sub-batch launch queues of the 16-bit forward (esmdiff_set_option: 1 .. 4, default 2) and the token count from which a
-        batch is cut into sub-batches (default 2200).  No result bit depends on either (test_stream_counts_bit_identical)."""
+        batch is cut into sub-batches (default 2200).  No result bit depends on either: the dispatch path of a (B, L) forward is the
+        default options' choice, a setting that would move the sub-batches onto the other path is reduced (esmdiff_set_option)."""
         self._chk(self._lib.esmdiff_set_option(self._h, N.OPT_STREAMS, int(n_streams)))
         if min_tokens is not None:
             self._chk(self._lib.esmdiff_set_option(self._h, N.OPT_DUAL_MIN_TOKENS, int(min_tokens)))

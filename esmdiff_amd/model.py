@@ -38,9 +38,9 @@ class MaskedDiffusionLanguageModeling:
         self.vocab_size = STRUCTURE_VOCAB
         self.mask_index = STRUCTURE_MASK_TOKEN
         self.neg_infinity = -1000000.0
-        # precision="certified": the f32-grade engine is `net` (every generic path — parity noise, gibbs, _model_wrapper — runs on
-        # it); the Philox ddpm loop draws on an f16 engine and re-runs only the close calls on `net` (certified.py): the ids of the
-        # F32_SPLIT chain at about twice its rate
+        # precision="certified": the f32-grade engine is `net` (every generic path — parity noise, _model_wrapper — runs on it);
+        # the Philox ddpm loop and the gibbs loop (esmdiff_amd.gibbs.iterative_sampling_raw) draw on an f16 engine and verify only
+        # the decisions its measured error leaves open on `net` (certified.py): the ids of `net`'s chain at about 2.4x its rate
         self.certified = None
         if precision == "certified":
             from .certified import CertifiedSampler
@@ -241,7 +241,8 @@ def load_state_dict_from_lightning_ckpt(ckpt_path, device="cuda", max_batch: int
     """/root/reference/slm/utils/checkpoint_utils.py:41-74: a `.pt` whose 'module' dict holds `net.*` and
     `sigma_embedder.*`; the model is what the run's `.hydra/config.yaml` says when that file sits where the reference
     looks for it (:45-50), else the mdlm.yaml configuration (LogLinearNoise, time conditioning, 4101-way head);
-    noise_removal is forced on (:71)."""
+    noise_removal is forced on (:71).  Under torch.distributed this is a collective (dist.broadcast_state_dict): every rank
+    must call it; a loading error on the reading rank is raised on all of them."""
     from .weights import checkpoint_file_and_config
     print(f"Loading ESMDiff ckpt from {ckpt_path}")
     _, exp_cfg_path = checkpoint_file_and_config(ckpt_path)

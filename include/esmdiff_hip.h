@@ -132,8 +132,12 @@ int esmdiff_get_build_info(char* buf, int32_t cap);
 int esmdiff_describe_plan(const esmdiff_engine* eng, int32_t B, int32_t L, char* buf, int32_t cap);
 
 /* Explicit dispatch options (ABI 7) — what used to be environment switches and may legitimately be chosen by a caller.  Neither
- * changes a result bit (tests/test_gpu_kernels.py::test_stream_counts_bit_identical): on the regular path a row's K order
- * depends on (N, K) only, and sub-batches of one forward always take the same path.
+ * changes a result bit: the dispatch PATH of a (B, L) forward (the small-batch K-slice kernels below 1 152 rows per sub-batch,
+ * the regular kernels above: two summation orders) is what the DEFAULT options choose, a function of (B, L) alone; an option
+ * only changes how many launch queues run the batch, and a value that would push the sub-batches across that row count is
+ * reduced until they stay on the default path's side (r06; esmdiff_describe_plan shows the count in use).  On one path a row's
+ * K order depends on (N, K) only.  tests/test_gpu_kernels.py::test_stream_counts_bit_identical (inside one path),
+ * tests/test_gpu_fullwidth.py::test_stream_options_never_change_a_bit (settings that would cross the threshold).
  *   ESMDIFF_OPT_STREAMS           sub-batch launch queues of the 16-bit forward: 1 .. 4 (default 2)
  *   ESMDIFF_OPT_DUAL_MIN_TOKENS   batches of at least this many tokens are cut into sub-batches (default 2200) */
 typedef enum { ESMDIFF_OPT_STREAMS = 1, ESMDIFF_OPT_DUAL_MIN_TOKENS = 2 } esmdiff_option;

@@ -26,6 +26,8 @@ def usable_cores() -> int:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU test of several minutes; runs only with ESMDIFF_RUN_SLOW=1 (its last result is "
+                                       "committed under profiles/)")
     import torch
     torch.set_num_threads(usable_cores())
 

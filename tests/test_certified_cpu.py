@@ -196,7 +196,7 @@ def test_certified_chain_equals_exact_chain_under_bounded_logit_error(same_prote
         fast = _Net(noise=noise, seed=10 + trial)
         # eps = 0.05: the pair bound 2 eps = 0.1 is the largest difference two logits' errors can have (uniform in +-0.05);
         # eps = None: 6 x the r.m.s. pair error (0.05 sqrt(2/3)) = 0.245 > 0.1, from the first probe on
-        cs = CertifiedSampler(fast, _Net(), eps=eps_arg, verify_batch=3, audit_rate=0.1, audit_seed=trial)
+        cs = CertifiedSampler(fast, _Net(), eps=eps_arg, verify_batch=3, audit_rate=0.1, audit_seed=trial, direct_share=1.0)
         got = cs.ddpm_sample(seq, sch, seed=11)
         st = cs.stats
         assert torch.equal(got, want), (trial, st)
@@ -226,7 +226,7 @@ def test_certified_with_prior_and_final_pass():
     want = _Net().chain(seq, sch, seed=4, prior=prior)
     assert int((want == MASK).sum()) == 0
     fast = _Net(noise=0.05, seed=3)
-    cs = CertifiedSampler(fast, _Net(), eps=0.05, verify_batch=2)
+    cs = CertifiedSampler(fast, _Net(), eps=0.05, verify_batch=2, direct_share=1.0)
     got = cs.ddpm_sample(seq, sch, seed=4, input_prior=prior)
     assert torch.equal(got, want) and not cs.stats["first_update_shared"]
     assert torch.equal(got[:, :2], prior[:, :2]) and torch.equal(got[:, 9:], prior[:, 9:]) and torch.equal(got[3], prior[3])
@@ -259,7 +259,7 @@ def test_audit_catches_an_error_above_eps_on_an_unflagged_sample():
     want = _Net().chain(seq, sch, seed=21)
     fast = _Net(noise=0.01, seed=2)
     fast.inject = _inject_big_error({2})
-    cs = CertifiedSampler(fast, _Net(), eps=0.01, audit_rate=1.0, verify_batch=4)
+    cs = CertifiedSampler(fast, _Net(), eps=0.01, audit_rate=1.0, verify_batch=4, direct_share=1.0)
     got = cs.ddpm_sample(seq, sch, seed=21)
     st = cs.stats
     assert torch.equal(got, want), st
@@ -269,7 +269,7 @@ def test_audit_catches_an_error_above_eps_on_an_unflagged_sample():
     assert st["rollback_updates_discarded"] >= 0
     fast = _Net(noise=0.01, seed=2)
     fast.inject = _inject_big_error({2})
-    blind = CertifiedSampler(fast, _Net(), eps=0.01, audit_rate=0.0, verify_batch=4)
+    blind = CertifiedSampler(fast, _Net(), eps=0.01, audit_rate=0.0, verify_batch=4, direct_share=1.0)
     assert not torch.equal(blind.ddpm_sample(seq, sch, seed=21), want)
     assert blind.stats["audit_checked"] == 0 and blind.stats["audit_mismatches"] == 0
 
@@ -342,7 +342,7 @@ def test_certified_gibbs_chain_equals_exact_chain_under_bounded_logit_error(same
     plain = _Net(noise=noise, seed=1, scale=scale).gibbs_chain(seq, x0, table, temperature, top_p, seed=11)
     assert not torch.equal(plain, want), "the stand-in is too easy: the perturbed chain never leaves the exact one"
     fast = _Net(noise=noise, seed=1, scale=scale)
-    cs = CertifiedSampler(fast, _Net(scale=scale), verify_batch=3, audit_rate=0.1)
+    cs = CertifiedSampler(fast, _Net(scale=scale), verify_batch=3, audit_rate=0.1, direct_share=1.0)
     got = cs.gibbs_sample(seq, x0, table, temperature, top_p, seed=11)
     st = cs.stats
     assert torch.equal(got, want), st
@@ -365,7 +365,7 @@ def test_certified_gibbs_ragged_prompts_frames_and_empty_steps():
     want = _Net(scale=scale).gibbs_chain(seq, x0, table, 1.4, 0.9, seed=5)
     assert torch.equal(want[2], x0[2])
     fast, exact = _Net(noise=0.03, seed=4, scale=scale), _Net(scale=scale)
-    cs = CertifiedSampler(fast, exact, verify_batch=2, audit_rate=0.2)
+    cs = CertifiedSampler(fast, exact, verify_batch=2, audit_rate=0.2, direct_share=1.0)
     frames = (torch.zeros(B, L, 3, 3), torch.zeros(B, L, 3), torch.ones(B, L, dtype=torch.bool))
     got = cs.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=5, frames=frames)
     assert torch.equal(got, want), cs.stats
@@ -376,6 +376,25 @@ def test_certified_gibbs_ragged_prompts_frames_and_empty_steps():
         cs.gibbs_sample(seq, x0, table[:, :3], 1.4, 0.9, seed=5)
     with pytest.raises(ValueError, match="x0 shape"):
         cs.gibbs_sample(seq, x0[:, :5], table, 1.4, 0.9, seed=5)
+
+
+def test_certified_switches_to_the_exact_engine_when_speculation_cannot_pay():
+    """When most sample-updates need the slow lane (here: a fast engine ten times too noisy for the gaps of this stand-in), the
+    sampler stops speculating: the rest of the call runs on the exact engine alone, the chain is still the exact one, and far
+    fewer fast forwards are spent than the whole job would take."""
+    B, L, steps = 8, 14, 6
+    seq, x0, table = _gibbs_setup(B, L, steps, False)
+    want = _Net(scale=1.0).gibbs_chain(seq, x0, table, 1.4, 0.9, seed=2)
+    fast, exact = _Net(noise=0.3, seed=8, scale=1.0), _Net(scale=1.0)
+    fast.max_batch = exact.max_batch = 4
+    cs = CertifiedSampler(fast, exact, verify_batch=3)                     # direct_share = 0.5, the default
+    got = cs.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=2)
+    st = cs.stats
+    assert torch.equal(got, want), st
+    assert st["direct_lane_from_launch"] is not None and st["direct_lane_share_seen"] > 0.5 and st["sample_forwards_direct"] > 0
+    assert st["sample_forwards_fast"] <= 30 and st["sample_forwards_direct"] >= 10          # of 48 sample-updates (decided after 16 results)
+    with pytest.raises(ValueError, match="direct_share"):
+        CertifiedSampler(_Net(), _Net(), direct_share=0.0)
 
 
 def test_gibbs_rows_step_is_the_plain_step_per_prompt():

@@ -482,6 +482,41 @@ def test_logits_across_dispatch_paths():
     assert 0 < rec["B2_vs_B100_max_abs"] < 0.02, rec                # ... and differs from the regular one at bf16-rounding level
 
 
+def test_stream_options_never_change_a_bit():
+    """esmdiff_set_option must not move a batch onto another dispatch path.  At L_tok = 258 the small-batch path ends
+    at 1 152 rows per sub-batch: B = 16 is 2 x 2 064 rows (regular) by default and would be 4 x 1 032 (small) with STREAMS = 4;
+    B = 8 is one regular stream by default and would be 2 x 1 032 (small) with DUAL_MIN_TOKENS = 1; B = 4 (1 032 rows, small) must
+    stay small with any setting.  Logits are compared bit for bit against the default setting's, and the plan text shows the
+    stream count was reduced rather than the path changed."""
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.schedule import ddpm_schedule
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ModelConfig(n_layers=2)
+    sd = random_init_state_dict(cfg, seed=5)
+    L = 258
+    g = torch.Generator().manual_seed(4)
+    tf = ddpm_schedule(25).t_freq[3]
+    eng = Engine(cfg, sd, max_batch=16, max_len=L)
+    for B, settings in ((16, ((4, None), (3, None), (1, None))), (8, ((2, 1), (4, 1), (1, None))), (4, ((4, 1), (1, None)))):
+        xs = torch.randint(0, 4096, (B, L), generator=g)
+        xs[:, ::3] = MASK
+        seq = _seq(B, L, g)
+        eng.set_streams(2, 2200)
+        plan0 = eng.describe_plan(B, L)
+        base = eng.forward_logits(xs.cuda(), seq.cuda(), tf).clone()
+        for n_streams, min_tokens in settings:
+            eng.set_streams(n_streams, min_tokens)
+            plan = eng.describe_plan(B, L)
+            got = eng.forward_logits(xs.cuda(), seq.cuda(), tf)
+            assert torch.equal(got, base), (B, n_streams, min_tokens, plan0, plan)
+            assert ("path=small" in plan) == ("path=small" in plan0), (plan0, plan)
+    eng.set_streams(4, 1)
+    assert "streams=3 " in eng.describe_plan(16, L) and "path=regular" in eng.describe_plan(16, L)     # 4 x 1 032 rows was refused: 3 x >= 1 290
+    assert "streams=1 " in eng.describe_plan(8, L) and "path=regular" in eng.describe_plan(8, L)       # 2 x 1 032 rows was refused
+    eng.close()
+
+
 def test_step0_sharing_is_exact():
     """Step-0 sharing (esmdiff_set_step0_sharing): when all samples of a call start from identical tokens, the first forward
     runs on a sub-batch — the ids must be BIT-IDENTICAL to the unshared run, the counters must show the saved rows, and a

@@ -394,6 +394,44 @@ def test_checkpoint_fanout_one_reader_gloo_world3(tmp_path):
     assert t["path"] == "no process group" and all(torch.equal(alone[k], sd[k]) for k in sd)
 
 
+def _fanout_fail_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    import torch.distributed as dist
+    from esmdiff_amd.dist import broadcast_state_dict
+    from esmdiff_amd.weights import load_checkpoint_state_dict
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        broadcast_state_dict(lambda: load_checkpoint_state_dict(Path(tmp) / "nothing_here.pt"), "cpu")
+        msg = "no error"
+    except RuntimeError as ex:
+        msg = str(ex)
+    (Path(tmp) / f"err{rank}.txt").write_text(msg)
+    dist.barrier()                                              # every rank is still alive and in step
+    dist.destroy_process_group()
+
+
+def test_checkpoint_fanout_reader_failure_reaches_every_rank(tmp_path):
+    """loading is a collective, so a failure of the ONE reader (missing file, no 'module' entry ...) must fail every
+    rank — the others would otherwise sit in the broadcast until the backend's timeout.  gloo, world 2: both ranks raise within
+    seconds with the reader's error text."""
+    import time
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    t0 = time.time()
+    mp.spawn(_fanout_fail_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert time.time() - t0 < 45
+    for r in range(2):
+        msg = (tmp_path / f"err{r}.txt").read_text()
+        assert "checkpoint loading failed on rank 0" in msg and "nothing_here.pt" in msg, (r, msg)
+    from esmdiff_amd.dist import broadcast_state_dict
+    with pytest.raises(FileNotFoundError):                      # without a process group the loader's own exception comes through
+        broadcast_state_dict(lambda: torch.load(tmp_path / "nothing_here.pt"), "cpu")
+
+
 def test_engine_capacity_covers_every_issued_batch():
     """max_batch must come from the batches the splitters really issue (per target, per mode, remainder batch
     included), and any batch can be chunked to a smaller engine."""
