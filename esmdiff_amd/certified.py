@@ -38,8 +38,9 @@ forces a flagged sample to be settled in the update it was flagged in:
 
   direct      speculation only pays while few sample-updates need the slow lane: a verified sample-update costs an f32-grade
               forward ON TOP of the fast one.  When more than `direct_share` (0.5) of the last two lanes' worth of sample-updates were
-              flagged, the rest of the call runs on the f32-grade engine alone (its draws need no certificate), so a certified call is
-              never much slower than the f32-grade engine by itself.  That is the regime of the gibbs mode on weights whose output
+              flagged, the lane runs on the f32-grade engine alone (its draws need no certificate) until the share — still reported
+              by the same kernel, from the f32-grade logits — has fallen below 0.6 x `direct_share`; so a certified call is never much
+              slower than the f32-grade engine by itself.  That is the regime of the gibbs mode on weights whose output
               distributions are all nearly uniform (random initialisation): the entropies of the positions then lie ~4e-5 apart and
               the ORDER of two of them is decided below what f16 resolves (profiles/r06_certified_gibbs_*.txt).
 
@@ -242,6 +243,7 @@ class CertifiedSampler:
         self.max_dh_seen = 0.0       # largest entropy error
         self.range_dh_seen = 0.0     # largest difference of the entropy errors of two rows of one sample (what decides their order)
         self.n_seen = 0              # verified items the estimate rests on
+        self.lane_memory: dict = {}  # mode -> did the last call's first window of sample-updates exceed direct_share? (start there)
         self.pair_raise = 0.0        # pair bound forced by violations (also with a fixed eps)
         self.entropy_raise = 0.0
         self.stats: dict = {}
@@ -391,9 +393,13 @@ class CertifiedSampler:
               "entropy_violations": 0, "rollback_updates_discarded": 0, "sample_forwards_fast": 0, "sample_forwards_exact": 0,
               "max_logit_err_observed": 0.0, "max_pair_err_observed": 0.0, "max_range_err_observed": 0.0,
               "max_entropy_err_observed": 0.0, "flagged_per_update": [0] * max(Tmax, 1), "eps_used": [], "entropy_eps_used": [],
-              "direct_lane_from_launch": None, "direct_lane_share_seen": None, "sample_forwards_direct": 0}
+              "direct_lane_from_launch": None, "direct_lane_share_seen": None, "sample_forwards_direct": 0, "direct_launches": 0,
+              "direct_lane_switches": []}
         recent: deque = deque(maxlen=2 * max(W, 16))               # 1 / 0 per live sample-update that drew: did it need the slow lane?
-        direct = [False]                                           # the rest of the call runs on the f32-grade engine alone
+        # the lane runs on the f32-grade engine alone; a call starts where the last call of this mode started out (the CLI runs
+        # batch after batch of one protein): the direct lane keeps reporting the share, so it leaves as soon as speculation pays
+        direct = [bool(self.lane_memory.get(rule.mode, False))]
+        first_share: list = []
         gap_log: List[List[float]] = [[] for _ in range(NG)]       # smallest gaps of every live sample-update / the bound they ran with
         timers: list = []                                          # (lane, start event, end event) of every forward + draw
 
@@ -454,6 +460,7 @@ class CertifiedSampler:
         step_first = step.copy()
         n_share = min(W, int(getattr(fast, "shared_forward_batch", lambda b, l: 1)(W, L))) if identical else 0
         shared_lg: list = []                                       # the first update's logits of ONE sample, once computed
+        shared_lg_exact: list = []
 
         def launch_direct(active: np.ndarray) -> None:
             """The lane on the f32-grade engine itself: plain draws, nothing to flag, verify or audit."""
@@ -464,19 +471,35 @@ class CertifiedSampler:
             steps_d = up(steps) if (mixed and rule.wants_steps_on_device(exact)) else None
             idx_d = up(active)
             xa, sa = x[idx_d], seq[idx_d]
+            bounds = (self.pair_bound(), self.entropy_bound())
             e0 = tick()
-            rule.before_forward(exact, idx_d)
-            lg = exact.forward_logits(xa, sa, rule.cond(exact, steps, steps_d), check_ids=False)
-            rule.draw(exact, xa, sa, lg, par, seed)
+            first = n_share > 0 and not mixed and bool((steps == step_first[active]).all()) and bool((epoch[active] == 0).all())
+            if first and n > 1:                                    # identical inputs: one sample's forward serves all (f32-grade logits do
+                if not shared_lg_exact:                            # not depend on the batch they are computed in)
+                    rule.before_forward(exact, up(active[:1]))
+                    shared_lg_exact.append(exact.forward_logits(xa[:1], sa[:1], rule.cond(exact, steps[:1], None), check_ids=False).clone())
+                    st["sample_forwards_exact"] += 1 - n
+                else:
+                    st["sample_forwards_exact"] -= n
+                lg = shared_lg_exact[0].expand(n, L, shared_lg_exact[0].shape[-1]).contiguous()
+            else:
+                rule.before_forward(exact, idx_d)
+                lg = exact.forward_logits(xa, sa, rule.cond(exact, steps, steps_d), check_ids=False)
+            # the report is taken here too (same ids, bit for bit): it says what the fast lane WOULD have had to verify, which is
+            # what decides when speculation pays again
+            flags = torch.zeros(n, dtype=torch.int32, device=dev)
+            gaps = torch.full((n, NG), float("inf"), dtype=torch.float32, device=dev)
+            rule.draw(exact, xa, sa, lg, par, seed, bounds, flags, gaps)
             timers.append(("direct", e0, tick()))
             x[idx_d] = xa
-            back = _Async(torch.cat([torch.zeros(n, 1 + NG, device=dev), (xa == MASK).any(1).to(torch.float32)[:, None]], 1))
+            back = _Async(torch.cat([flags.to(torch.float32)[:, None], gaps, (xa == MASK).any(1).to(torch.float32)[:, None]], 1))
             updates.append({"active": active, "steps": steps, "epochs": epoch[active].copy(), "back": back, "direct": True})
             step[active] += 1
             mask_known[active] = False
             rule.skip_empty(step)
             st["sample_forwards_direct"] += n
             st["sample_forwards_exact"] += n
+            st["direct_launches"] += 1
 
         def launch_fast(active: np.ndarray, which: int) -> None:
             if direct[0]:
@@ -538,6 +561,8 @@ class CertifiedSampler:
                     s = int(rec["active"][j])
                     has_mask[s], mask_known[s] = bool(hm[j] > 0), True
                     settle_final(s)
+                    if np.isfinite(gp[j, 0]):
+                        recent.append(1 if fl[j] > 0 else 0)
                 return
             units = rule.gap_units(rec["bounds"])
             pick, kinds = [], []
@@ -670,10 +695,19 @@ class CertifiedSampler:
             # results one iteration late: while the host waits for them the GPU is already inside the forward just launched
             while len(updates) > (1 if len(active) else 0):
                 process_update(updates.popleft())
-            if not direct[0] and len(recent) >= max(W, 16) and sum(recent) > self.direct_share * len(recent):
-                direct[0] = True                                  # too many open decisions for speculation to pay (class docstring)
-                st["direct_lane_from_launch"] = st["fast_launches"]
-                st["direct_lane_share_seen"] = round(sum(recent) / len(recent), 4)
+            if len(recent) >= max(W, 16):
+                share = sum(recent) / len(recent)
+                if not first_share:
+                    first_share.append(share)
+                    self.lane_memory[rule.mode] = share > self.direct_share
+                if not direct[0] and share > self.direct_share:
+                    direct[0] = True                              # too many open decisions for speculation to pay (class docstring)
+                    st["direct_lane_switches"].append(("direct", st["fast_launches"] + st["direct_launches"], round(share, 4)))
+                    if st["direct_lane_from_launch"] is None:
+                        st["direct_lane_from_launch"], st["direct_lane_share_seen"] = st["fast_launches"], round(share, 4)
+                elif direct[0] and share < 0.6 * self.direct_share:
+                    direct[0] = False                             # the chain reached a phase where few decisions are open
+                    st["direct_lane_switches"].append(("fast", st["fast_launches"] + st["direct_launches"], round(share, 4)))
             while verifies:                                       # (launched in an earlier iteration, or nothing else to do)
                 process_verify(verifies.popleft())
             queued = len(pools[fill]["items"])

@@ -415,6 +415,11 @@ struct SPart {   // one sub-batch of a strict forward: the engine's float32 work
   hipStream_t st;
 };
 
+// sub-batch streams of a float32-grade forward (one function for forward_strict and esmdiff_describe_plan)
+static int strict_parts(const esmdiff_engine* e, int B, int L) {
+  return (e->split && !e->side.empty() && e->profiling != 1 && B >= 2 && (int64_t)B * L >= e->strict_dual_min_tokens) ? 2 : 1;
+}
+
 static int strict_part(esmdiff_engine* e, const SPart& w, const float* cond, int ld, int L) {
   const esmdiff_config& c = e->cfg;
   const int D = c.d_model, H = c.n_heads, FH = c.ffn_hidden;
@@ -553,8 +558,7 @@ int forward_strict(esmdiff_engine* e, const int64_t* seq, const int64_t* xtok, c
   // F32_SPLIT at large batches: two sub-batches on two streams, as the bf16 engine does (every kernel's row results are
   // independent of the batch, so the cut changes no bit): the persistent split GEMMs leave CUs idle in their last round and the
   // other sub-batch's kernels fill them.
-  const int64_t tokens = (int64_t)B * L;
-  const int np = (e->split && !e->side.empty() && e->profiling != 1 && B >= 2 && tokens >= e->strict_dual_min_tokens) ? 2 : 1;
+  const int np = strict_parts(e, B, L);
   const int64_t WS = 3 * (int64_t)std::max(D, FH);
   SPart parts[2];
   for (int pi = 0; pi < np; ++pi) {
@@ -734,7 +738,7 @@ int esmdiff_describe_plan(const esmdiff_engine* e, int32_t B, int32_t L, char* b
   n += snprintf(at(), room(), "precision=%s head=%s B=%d L=%d", prec, (e->strict || e->head_split) ? "f32-grade" : prec, B, L);
   if (e->strict) {
     const int64_t tokens = (int64_t)B * L;
-    const int np = (e->split && !e->side.empty() && B >= 2 && tokens >= e->strict_dual_min_tokens) ? 2 : 1;
+    const int np = strict_parts(e, B, L);
     n += snprintf(at(), room(), " streams=%d path=%s k_sliced_small_batches=%d", np,
                   e->split ? "split(3 f16 MFMA passes, 256x256w4)" : "strict(f32 MFMA)", e->sk_parts && tokens <= e->splitk_max_rows ? 1 : 0);
   } else {
@@ -742,10 +746,11 @@ int esmdiff_describe_plan(const esmdiff_engine* e, int32_t B, int32_t L, char* b
     const bool small = plan_small(e, B, L);
     const int m0 = (int)((int64_t)B / np) * L;
     char g1[32], g2[32], g3[32], g4[32];
-    ed::describe_gemm(m0, 3 * D, D, e->gemm_ws[0].partial != nullptr, g1, sizeof g1);
-    ed::describe_gemm(m0, D, D, e->gemm_ws[0].partial != nullptr, g2, sizeof g2);
-    ed::describe_gemm(m0, 2 * FH, D, e->gemm_ws[0].partial != nullptr, g3, sizeof g3);
-    ed::describe_gemm(m0, D, FH, false, g4, sizeof g4);
+    const size_t wsf = e->gemm_ws[0].partial ? e->gemm_ws[0].partial_floats : 0;
+    ed::describe_gemm(m0, 3 * D, D, wsf, g1, sizeof g1);
+    ed::describe_gemm(m0, D, D, wsf, g2, sizeof g2);
+    ed::describe_gemm(m0, 2 * FH, D, wsf, g3, sizeof g3);
+    ed::describe_gemm(m0, D, FH, 0, g4, sizeof g4);
     n += snprintf(at(), room(), " streams=%d rows_per_stream=%d path=%s", np, m0, small ? "small-batch(K-slice planes summed by the LayerNorm)" : "regular");
     if (small)
       n += snprintf(at(), room(), " gemm[qkv]=%s gemm[out]=128x*/S%d gemm[ffn_up]=%s gemm[ffn_down]=128x*/S%d", g1, ed::gemm_partial_splits(D, D), g3,

@@ -416,15 +416,18 @@ static int small_tile_mi(int M, int N, int S) {
   return ((M + 127) / 128) * (N / BN) * S <= 128 ? 1 : 2;
 }
 
-hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
-                            int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream,
-                            const GemmWorkspace* ws) {
-  if (M <= 0) return hipSuccess;
-  if (N % BN != 0 || K % BK != 0 || (ldc & 3)) return hipErrorInvalidValue;
-  // Tile selection: the 256x256 kernel (one persistent workgroup per CU) once it has >= 128 tiles to hand out, this
-  // 128x128 kernel otherwise.  Measured crossovers (us, 128 vs 256): N = 1536, K = 4096: M = 4128 67 / 81, M = 6192
-  // 109 / 87; N = 4608: M = 1032 28 / 37, M = 2064 48 / 42; N = 8192: M = 1032 47 / 40.
-  // ESMDIFF_GEMM_TILE=128|256 forces one (A/B benchmarking and tests).
+// Which kernel a shape runs on — ONE function for the launcher and for the text esmdiff_describe_plan prints beside the results
+// (two copies of the rule drift apart as soon as one is edited).
+//   w4      the 256x256 four-wave kernel (gemm256w4.hip; one persistent workgroup per CU)
+//   mi, S   else: this file's 128-column kernel with 64 * mi rows per tile and S K-slices (S > 1 needs the split-K workspace)
+struct GemmChoice {
+  bool w4;
+  int mi, S;
+};
+static GemmChoice choose_gemm(int M, int N, int K, bool has_ws, size_t ws_floats) {
+  // Tile selection: the 256x256 kernel once it has >= 128 tiles to hand out, the 128x128 kernel otherwise.  Measured crossovers
+  // (us, 128 vs 256): N = 1536, K = 4096: M = 4128 67 / 81, M = 6192 109 / 87; N = 4608: M = 1032 28 / 37, M = 2064 48 / 42;
+  // N = 8192: M = 1032 47 / 40.  ESMDIFF_GEMM_TILE=128|256 forces one (-DED_DEBUG builds: A/B benchmarking).
   // (Measured and rejected: splitting the rows so that 256-row tiles fill whole 256-CU rounds and the leftover
   // rows go through this kernel — 93 + 29 us apart, 138 us back to back, vs 132 us unsplit at N = K = 1536.)
   static const int forced = [] {
@@ -438,54 +441,51 @@ hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const f
   // (r02, inside the two-stream forward: the N = 1536 linears of a 2 817 .. 5 376-row sub-batch — 72 .. 126 tiles — also
   // run better on the persistent 256x256 kernel, which leaves the other CUs to the other stream: B = 24 .. 40 at L_tok = 258
   // +1 .. 3 %; at 7 - 8 row tiles (QKV of a 1 548-row sub-batch, 126 tiles) the 128-column kernel still wins, B = 12 -3 %)
-  // The 256x256 kernel (gemm256w4.hip) walks K in pairs of 64-wide tiles and needs >= 6 of them; other K (none in ESM3-open, the
-  // decoder or the encoder: 1536, 4096, 1280, 3584, 768) stay on this kernel.  (The r01 eight-wave 256x256 kernel that used to
-  // take those shapes left the product in r05: scratch/gemm256_8wave_kernel.hip.txt.)
+  // The 256x256 kernel walks K in pairs of 64-wide tiles and needs >= 6 of them; other K (none in ESM3-open, the decoder or the
+  // encoder: 1536, 4096, 1280, 3584, 768) stay on this kernel.  (The r01 eight-wave 256x256 kernel that used to take those
+  // shapes left the product in r05: scratch/gemm256_8wave_kernel.hip.txt of the round-5 tree, git commit 8ee0514.)
   const int t256m = (M + 255) / 256, t256 = t256m * (N / 256);
   if (N % 256 == 0 && K % (2 * BK) == 0 && K >= 6 * BK &&
       (forced == 256 || (forced == 0 && (t256 >= min_tiles || (t256 >= 72 && t256m >= 12)))))
-    return launch_gemm256w4_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
+    return GemmChoice{true, 2, 1};
   const int tiles_n = N / BN;
   // split-K factor, a function of (N, K) only: for K >= 2048 (FFN-down) the largest divisor of K/64 that is <= 8 and
   // keeps tiles_n * S <= 96.  Measured (us per launch, M = 240 / 774): FFN-down K = 4096 S = 8: 42 -> 17 / 41 -> 35;
   // but K = 1536 shapes lose at the larger M (out-proj S = 8: 21 -> 16 / 20 -> 27; QKV S = 2: 21 -> 20 / 22 -> 33) —
   // the f32 partials (S x M x N x 4 B, written and re-read) outweigh the shorter K loop — so they are not split.
   int S = 1;
-  const int64_t pstride = (int64_t)((M + 127) / 128) * 128 * N;
-  if (M < small_max_rows() && ws && ws->partial && K >= 2048) {
+  if (M < small_max_rows() && has_ws && K >= 2048) {
     const int nk = K / BK;
     for (int c = 8; c >= 2; --c)
       if (nk % c == 0 && tiles_n * c <= 96) {
         S = c;
         break;
       }
-    if ((size_t)S * pstride > ws->partial_floats) S = 1;
+    if ((size_t)S * (size_t)((M + 127) / 128) * 128 * N > ws_floats) S = 1;
   }
-  const int mi = M < small_max_rows() ? small_tile_mi(M, N, S) : 2;
-  return launch_tiles(A, W, out, bias, M, N, K, ldc, n_valid, alpha, epilogue, stream, mi, S,
-                      S > 1 ? ws->partial : nullptr, pstride, false);
+  return GemmChoice{false, M < small_max_rows() ? small_tile_mi(M, N, S) : 2, S};
+}
+
+hipError_t launch_gemm_bf16(const bf16_t* A, const bf16_t* W, void* out, const float* bias, int M, int N,
+                            int K, int ldc, int n_valid, float alpha, int epilogue, hipStream_t stream,
+                            const GemmWorkspace* ws) {
+  if (M <= 0) return hipSuccess;
+  if (N % BN != 0 || K % BK != 0 || (ldc & 3)) return hipErrorInvalidValue;
+  const bool has_ws = ws && ws->partial;
+  const GemmChoice c = choose_gemm(M, N, K, has_ws, has_ws ? ws->partial_floats : 0);
+  if (c.w4) return launch_gemm256w4_bf16(A, W, out, bias, M, N, K, ldc, alpha, epilogue, stream);
+  const int64_t pstride = (int64_t)((M + 127) / 128) * 128 * N;
+  return launch_tiles(A, W, out, bias, M, N, K, ldc, n_valid, alpha, epilogue, stream, c.mi, c.S,
+                      c.S > 1 ? ws->partial : nullptr, pstride, false);
 }
 
 // Which kernel launch_gemm_bf16 picks for a shape, as text (esmdiff_describe_plan): "256x256w4" or "128x<rows>[/S<k-slices>]".
-void describe_gemm(int M, int N, int K, bool ws, char* out, size_t cap) {
-  const int t256m = (M + 255) / 256, t256 = t256m * (N / 256);
-  if (N % 256 == 0 && K % (2 * BK) == 0 && K >= 6 * BK && (t256 >= 128 || (t256 >= 72 && t256m >= 12))) {
-    snprintf(out, cap, "256x256w4");
-    return;
-  }
-  int S = 1;
-  const int tiles_n = N / BN;
-  if (M < small_max_rows() && ws && K >= 2048) {
-    const int nk = K / BK;
-    for (int c = 8; c >= 2; --c)
-      if (nk % c == 0 && tiles_n * c <= 96) {
-        S = c;
-        break;
-      }
-  }
-  const int mi = M < small_max_rows() ? small_tile_mi(M, N, S) : 2;
-  if (S > 1) snprintf(out, cap, "128x%d/S%d", 64 * mi, S);
-  else snprintf(out, cap, "128x%d", 64 * mi);
+// ws_floats: the size of the split-K workspace the launch will be handed (0: none).
+void describe_gemm(int M, int N, int K, size_t ws_floats, char* out, size_t cap) {
+  const GemmChoice c = choose_gemm(M, N, K, ws_floats > 0, ws_floats);
+  if (c.w4) snprintf(out, cap, "256x256w4");
+  else if (c.S > 1) snprintf(out, cap, "128x%d/S%d", 64 * c.mi, c.S);
+  else snprintf(out, cap, "128x%d", 64 * c.mi);
 }
 
 // ---- residual-branch linears of the small-batch path ------------------------------------------------------------

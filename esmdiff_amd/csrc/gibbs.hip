@@ -310,10 +310,12 @@ __global__ __launch_bounds__(GNT) void gibbs_row_kernel(const int64_t* __restric
       // nucleus: the draw's winner is the best of everything that MIGHT be kept and is itself certainly kept (the fall-back —
       // nothing valid inside the nucleus — is never certified)
       const bool nuc_ok = bi != 0x7fffffff && (ap & 0xffff) == bi && (ap & 0x10000) != 0;
+      const bool any = (ap & 0xffff) != 0xffff;   // some valid token is possibly kept (else: the fall-back, never certified)
       float gap;   // in logit units
-      if (inv_temperature == 0.0f) gap = a1 - a2;
+      if (!any) gap = 0.f;
+      else if (inv_temperature == 0.0f) gap = a1 - a2;
       else gap = a2 > 0.f ? (ed_logf(a1) - ed_logf(a2)) / inv_temperature : 3.402823466e38f;
-      const bool race_ok = inv_temperature == 0.0f ? (a1 - a2 > gm.R) : (a1 > a2 * gm.race);
+      const bool race_ok = any && (inv_temperature == 0.0f ? (a1 - a2 > gm.R) : (a1 > a2 * gm.race));
       row_flag[row] = (uint8_t)((race_ok ? 0 : 1) | (nuc_ok ? 0 : 2));
       row_gap[row] = fmaxf(gap, 0.f);
     }

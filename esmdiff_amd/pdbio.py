@@ -170,13 +170,17 @@ def _backbone_coords_from_pdb(pdb_path, target_atoms=("N", "CA", "C")) -> np.nda
     # C atoms of AMINO-ACID residues, ATOM and HETATM records alike (selenomethionine and other modified residues are HETATM),
     # nothing of ligands, waters or nucleic acids; of alternate locations the first one seen in each residue (altloc="first").
     first_alt = {}
+    skipped = {}       # residues outside the amino-acid list that nevertheless carry backbone atoms: (chain, number, name) -> atom names
     with open(pdb_path) as fh:
         for line in fh:
             name = line[:6].strip()
             if name in ("MODEL", "ENDMDL"):
                 close()
                 first_alt.clear()
-            elif name in ("ATOM", "HETATM") and len(line) >= 54 and line[17:20].strip() in _AMINO_ACID_RESNAMES:
+            elif name in ("ATOM", "HETATM") and len(line) >= 54 and line[17:20].strip() not in _AMINO_ACID_RESNAMES:
+                if line[12:16].strip() in ("N", "CA", "C"):
+                    skipped.setdefault((line[21], line[22:27], line[17:20].strip()), set()).add(line[12:16].strip())
+            elif name in ("ATOM", "HETATM") and len(line) >= 54:
                 alt = line[16]
                 if alt != " ":
                     res = (line[21], line[22:27])                      # chain, residue number + insertion code
@@ -186,6 +190,12 @@ def _backbone_coords_from_pdb(pdb_path, target_atoms=("N", "CA", "C")) -> np.nda
                 if j is not None:
                     cur[j].append((float(line[30:38]), float(line[38:46]), float(line[46:54])))
     close()
+    odd = sorted({k[2] for k, atoms in skipped.items() if atoms >= {"N", "CA", "C"}})
+    if odd:      # biotite's filter_amino_acids knows the whole CCD "L-peptide linking" class; this reader a hand-written list
+        import warnings
+        warnings.warn(f"{pdb_path}: residues {odd} carry N / CA / C atoms but are not in this reader's amino-acid list and were skipped — "
+                      "the chain is shorter than biotite (the reference's reader) would make it; add the residue name to "
+                      "esmdiff_amd.pdbio._AMINO_ACID_RESNAMES if it is a modified amino acid", stacklevel=2)
     if not models:
         raise ValueError(f"no backbone ATOM records in {pdb_path}")
     if len({m.shape for m in models}) != 1:

@@ -393,6 +393,12 @@ def test_certified_switches_to_the_exact_engine_when_speculation_cannot_pay():
     assert torch.equal(got, want), st
     assert st["direct_lane_from_launch"] is not None and st["direct_lane_share_seen"] > 0.5 and st["sample_forwards_direct"] > 0
     assert st["sample_forwards_fast"] <= 30 and st["sample_forwards_direct"] >= 10          # of 48 sample-updates (decided after 16 results)
+    # the next call of the same mode starts where this one started out (the CLI runs batch after batch of one protein): no
+    # speculation is wasted at its beginning; the lane would leave again as soon as the reported share fell
+    assert cs.lane_memory == {"gibbs": True}
+    want2 = _Net(scale=1.0).gibbs_chain(seq, x0, table, 1.4, 0.9, seed=3)
+    got2 = cs.gibbs_sample(seq, x0, table, 1.4, 0.9, seed=3)
+    assert torch.equal(got2, want2) and cs.stats["sample_forwards_fast"] == 0 and cs.stats["sample_forwards_direct"] >= 40
     with pytest.raises(ValueError, match="direct_share"):
         CertifiedSampler(_Net(), _Net(), direct_share=0.0)
 

@@ -150,6 +150,13 @@ def test_load_coords_filters_like_biotite(tmp_path):
     assert np.allclose(full[0, 3, :, 0], [100, 101, 102])
     ca = load_coords(p, verbose=False)
     assert ca.shape == (1, 4, 3) and np.allclose(ca[0, :, 0], [2, 6, 10, 101])
+    # a residue name outside the reader's amino-acid list that carries a whole backbone is skipped LOUDLY: biotite
+    # would keep any CCD "L-peptide linking" residue, so the chain lengths would differ silently otherwise
+    extra = "".join(atom("HETATM", 200 + j, nm, " ", "ZZQ", "A", 5, 900.0 + j) for j, nm in enumerate(("N", "CA", "C")))
+    q = tmp_path / "odd.pdb"
+    q.write_text("".join(lines[:-1]) + extra + "ENDMDL\nEND\n")
+    with pytest.warns(UserWarning, match="ZZQ"):
+        assert load_coords(q, verbose=False).shape == (1, 4, 3)
 
 
 def test_merge_pdbfiles_matches_reference_golden(golden_dir, tmp_path):

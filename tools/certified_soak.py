@@ -54,7 +54,7 @@ if a.weights == "random":
     sd = random_init_state_dict(cfg, seed=11, device="cuda", with_geom=True)
 else:
     from esmdiff_amd.weights import trained_like_state_dict
-    sd = trained_like_state_dict(cfg, seed=11, device="cuda")
+    sd = trained_like_state_dict(cfg, seed=11, device="cuda", with_geom=True)
 B, L, T = 100, 258, a.steps
 g = torch.Generator().manual_seed(258)
 seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g), torch.tensor([2])])[None].repeat(B, 1).cuda()
@@ -98,7 +98,7 @@ else:
 
 say(f"# certified soak: mode={a.mode} weights={a.weights} inpaint={a.inpaint} B={B} L_tok={L} steps={T} jobs<={a.jobs} first_seed={a.first_seed} "
     f"certificate='{cs.stats.get('certificate', 'k-sigma statistical + audit')}' k_sigma={cs.k_sigma} audit {cs.audit_rate} -> {cs.audit_rate_steady} after {cs.audit_clean_target} clean")
-say("seed ids_equal samples_differing cert_s exact_s flagged race nucleus order corrections audit_checked audit_mismatches eps_viol entropy_viol P_used E_used max_range_err max_entropy_err audit_rate")
+say("seed ids_equal samples_differing cert_s exact_s flagged race nucleus order corrections audit_checked audit_mismatches eps_viol entropy_viol P_used E_used max_range_err max_entropy_err audit_rate fwd_fast fwd_direct lane_switches")
 tot = {k: 0 for k in ("jobs", "jobs_equal", "samples_differing", "flagged", "corrections", "audit_checked", "audit_mismatches", "eps_violations",
                       "entropy_violations", "sample_updates", "sample_forwards_fast", "sample_forwards_exact")}
 t_cert = t_exact = 0.0
@@ -128,7 +128,8 @@ for k in range(a.jobs):
     fr = st["flag_reasons"]
     say(seed, ok, ndiff, round(dt, 3), round(de, 3), st["flagged"], fr["race"], fr["nucleus"], fr["order"], st["corrections"], st["audit_checked"],
         st["audit_mismatches"], st["eps_violations"], st["entropy_violations"], f"{2 * st['eps_max_used']:.3e}", f"{st.get('entropy_eps_max_used', 0) or 0:.3e}",
-        f"{st['max_range_err_observed']:.3e}", f"{st['max_entropy_err_observed']:.3e}", st["audit_rate_now"])
+        f"{st['max_range_err_observed']:.3e}", f"{st['max_entropy_err_observed']:.3e}", st["audit_rate_now"], st["sample_forwards_fast"],
+        st["sample_forwards_direct"], st["direct_lane_switches"])
 n = max(tot["jobs"], 1)
 r3 = lambda m: f"{3.0 / m:.2e}" if m else "n/a"
 say(f"# totals: {tot}")
