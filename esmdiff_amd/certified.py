@@ -53,7 +53,7 @@ a draw is arbitrary (winner and runner-up of a noisy race), so the bound in use 
     2 E = max(k_sigma * sqrt(2) * (largest per-item r.m.s. of the entropy error seen),
               max_factor * (largest difference of the entropy errors of two rows of one sample seen))
 
-widened by `boot_factor` until `n_boot` items have been seen; while NOTHING has been seen every sample-update is verified.  A
+widened by `boot_factor` (1.5) until `n_boot` (64) items have been seen; while NOTHING has been seen every sample-update is verified.  A
 verified item whose range exceeds the P its update was certified with (or whose entropy error exceeds E) is a `violation`; it
 raises the bound for everything that follows (also when eps is fixed).  The certificate is STATISTICAL: "k-sigma of the
 measured error distribution + audit".  What it asserts is checked by measurement — job-level equality with the f32-grade
@@ -205,7 +205,7 @@ class CertifiedSampler:
 
     def __init__(self, fast: Engine, exact: Engine, eps: Optional[float] = None, *, k_sigma: float = 6.0,
                  max_factor: float = 1.05, eps_floor: float = 1e-5, audit_rate: float = 0.02, verify_batch: int = 32,
-                 n_boot: int = 8, boot_factor: float = 1.5, audit_seed: int = 0, audit_rate_steady: Optional[float] = None,
+                 n_boot: int = 64, boot_factor: float = 1.5, audit_seed: int = 0, audit_rate_steady: Optional[float] = None,
                  audit_clean_target: int = 500, entropy_eps: Optional[float] = None, direct_share: float = 0.5):
         if fast.device != exact.device:
             raise ValueError("both engines must live on the same GPU")
