@@ -243,6 +243,7 @@ class CertifiedSampler:
         self.max_dh_seen = 0.0       # largest entropy error
         self.range_dh_seen = 0.0     # largest difference of the entropy errors of two rows of one sample (what decides their order)
         self.n_seen = 0              # verified items the estimate rests on
+        self.trace_sample: Optional[int] = None   # diagnostics: stats["trace"] lists every event of this (local) sample index
         self.lane_memory: dict = {}  # mode -> did the last call's first window of sample-updates exceed direct_share? (start there)
         self.pair_raise = 0.0        # pair bound forced by violations (also with a fixed eps)
         self.entropy_raise = 0.0
@@ -576,6 +577,9 @@ class CertifiedSampler:
                     if np.isfinite(gp[j, c]) and units[c] > 0:
                         gap_log[c].append(float(gp[j, c]) / units[c])
                 f = int(fl[j])
+                if s == self.trace_sample:
+                    st.setdefault("trace", []).append(("update", k, "flags", f, "gaps", [float(v) for v in gp[j]], "epoch", int(rec["epochs"][j]),
+                                                       "launch", st["fast_launches"], "bounds", rec["bounds"]))
                 if drew:
                     recent.append(1 if f > 0 else 0)
                 if f > 0 or (rec["blind"] and drew):
@@ -664,6 +668,9 @@ class CertifiedSampler:
                     self.entropy_raise = max(self.entropy_raise, 0.5 * self.max_factor * rdh)
                 s = it["s"]
                 stale = epoch[s] != it["epoch"]
+                if s == self.trace_sample:
+                    st.setdefault("trace", []).append(("verify", it["k"], it["kind"], "neq", bool(neq), "stale", bool(stale), "epoch", it["epoch"],
+                                                       "now", int(epoch[s]), "step_now", int(step[s])))
                 if audit and not stale:
                     self.audit_clean_run = 0 if neq else self.audit_clean_run + 1
                 if stale or not neq:

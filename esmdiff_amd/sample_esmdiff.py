@@ -11,7 +11,10 @@ heuristic, sample_esmdiff.py:146; the default here is larger because an MI355X h
 sharded over ranks and rank 0 writes the output.
 
 Both sampling modes are built: `--mode ddpm` (MDLM ancestral sampler) and the reference's default `--mode gibbs`
-(entropy-ordered iterative unmasking, temperature 1.4 / top-p 0.9).
+(entropy-ordered iterative unmasking, temperature 1.4 / top-p 0.9).  `--precision` defaults to `certified` in both modes (r06): the
+ids of a float32-grade run of the same seed (esmdiff_amd/certified.py: an f16 engine draws, the decisions its measured error
+leaves open are verified on an f32_split engine; a statistical certificate whose counters go into the run's json); `--precision
+bf16` is the throughput path the benchmark's headline is quoted on.
 
 Output: the reference decodes tokens to backbone coordinates with ESM3's VQ-VAE decoder and writes a
 multi-MODEL PDB (sample_esmdiff.py:225-231).  With --decoder_ckpt (esm's StructureTokenDecoder weights, which cannot be

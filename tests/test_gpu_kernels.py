@@ -1074,13 +1074,18 @@ def test_parity_stream_runs_across_batches_and_sigma0_conditioning():
 
 
 def test_cli_ddpm_full_size_random_init(tmp_path):
-    """The CLI end to end on ESM3-open-sized random weights: 58-residue synthetic target, 4 samples, 3 steps."""
+    """The CLI end to end on ESM3-open-sized random weights: 58-residue synthetic target, 4 samples, 3 steps — at the default
+    precision (certified: an f16 and an f32_split engine of the 1.4 B model; the run's json carries the certificate's counters)."""
     from esmdiff_amd.sample_esmdiff import main
     main(["--mode", "ddpm", "--random_init", "--synthetic_len", "58", "--num_samples", "4", "--num_steps", "3",
           "--output", str(tmp_path), "--no_timestamp", "--seed", "3"])
     out = tmp_path / "step3_eps1e-05_N4" / "synthetic58.tokens.npy"
     ids = np.load(out)
     assert ids.shape == (4, 58) and ids.min() >= 0 and ids.max() <= 4100 and (ids != 4096).all()
+    import json
+    meta = json.loads((tmp_path / "step3_eps1e-05_N4" / "synthetic58.json").read_text())
+    assert meta["precision"] == "certified" and meta["certified"]["certificate"] == "k-sigma statistical + audit"
+    assert meta["certified"]["audit_mismatches"] == 0
 
 
 def test_sampler_whole_configs1_batch_vs_torch_sampler_with_rand_like(tiny):
@@ -1364,7 +1369,8 @@ def test_gibbs_strategy_random_and_invalid_ids(tiny):
 def test_cli_gibbs_default_mode(tmp_path):
     from esmdiff_amd.sample_esmdiff import main
     main(["--random_init", "--synthetic_len", "40", "--num_samples", "3", "--num_steps", "8", "--output", str(tmp_path),
-          "--no_timestamp", "--seed", "2"])                                # --mode defaults to gibbs, as in the reference
+          "--no_timestamp", "--seed", "2", "--precision", "bf16"])         # --mode defaults to gibbs, as in the reference (the default
+                                                                           # precision, certified, at full size: test_cli_ddpm_full_size_random_init)
     ids = np.load(tmp_path / "T1.4_step8_topp0.9_N3" / "synthetic40.tokens.npy")
     assert ids.shape == (3, 40) and ids.min() >= 0 and ids.max() < 4096
 

