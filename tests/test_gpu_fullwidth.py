@@ -711,4 +711,4 @@ def test_dispatch_plan_and_build_info_say_what_runs():
     assert "precision=f32_split" in plan and "head=f32-grade" in plan and "streams=2" in plan and "k_sliced_small_batches=0" in plan, plan
     sp.close()
     info = N.build_info()
-    assert "abi=7" in info and "debug_env=0" in info, info
+    assert "abi=8" in info and "debug_env=0" in info, info
