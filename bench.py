@@ -730,7 +730,7 @@ def main():
         # attention).  Two timed jobs each (the F32_SPLIT referee costs 5-11 s per job); ids of the first job against the F32_SPLIT
         # engine's own gibbs chain.
         gibbs_rec = None
-        if args.alt_steps > 0:
+        try:
             from esmdiff_amd.geometry import build_affine3d_from_coordinates
             from esmdiff_amd.gibbs import unmask_schedule
             gibbs_rec = {}
@@ -774,13 +774,16 @@ def main():
                     "eps_violations": g_stats["eps_violations"], "entropy_violations": g_stats["entropy_violations"],
                     "sample_forwards_fast": g_stats["sample_forwards_fast"], "sample_forwards_exact": g_stats["sample_forwards_exact"],
                     "sample_forwards_direct": g_stats["sample_forwards_direct"], "direct_lane_switches": g_stats["direct_lane_switches"],
-                    "pair_bound": 2 * g_stats["eps_max_used"], "entropy_bound": g_stats["entropy_eps_max_used"],
+                    "pair_bound": None if g_stats["eps_max_used"] is None else 2 * g_stats["eps_max_used"],
+                    "entropy_bound": g_stats.get("entropy_eps_max_used"),
                     "sigma_entropy_err": g_stats["sigma_entropy_err"]}
             gibbs_rec["what"] = ("the CLI's default mode through CertifiedSampler.gibbs_sample: ids of the F32_SPLIT engine's gibbs chain.  Speculation "
                                  "pays where few decisions are open (configs[4]'s shape); where most are (all positions nearly uniform at random "
                                  "initialisation: the ORDER of two entropies ~4e-5 apart is below what f16 resolves) the sampler runs the "
                                  "F32_SPLIT engine directly and costs what that engine costs.  Labelled extra — NOT the headline value")
             cert_rec["gibbs"] = gibbs_rec
+        except Exception as ex_:      # a labelled extra must never take the headline line down with it
+            cert_rec["gibbs"] = {"error": f"{type(ex_).__name__}: {ex_}", "partial": gibbs_rec}
         ex.close()
 
     if rank == 0:

@@ -501,6 +501,8 @@ class CertifiedSampler:
             st["sample_forwards_direct"] += n
             st["sample_forwards_exact"] += n
             st["direct_launches"] += 1
+            st["eps_used"].append(0.5 * bounds[0])                # (the bounds the report of this launch was taken with)
+            st["entropy_eps_used"].append(bounds[1])
 
         def launch_fast(active: np.ndarray, which: int) -> None:
             if direct[0]:

@@ -381,10 +381,12 @@ BatchPlan plan_batch(const esmdiff_engine* e, int B, int L) {
   // forward was not deterministic from run to run (the f16 engine: 2 of 100 samples ~1e-4 off between two runs of the same batch).
   // The path (small vs regular) stays what the frameless default plan chooses, so coordinates never move a batch onto the other
   // summation order.
+#ifndef ED_FRAMES_TWO_STREAMS   // (A/B builds of scratch/r06_exact_batch_indep.py: the two-queue forward with frames, to look for the race)
   if (e->has_geom && e->frames_B > 0) {
     const bool small_f = parts_small(e, B, L, parts_for(e, B, L, kDefaultStreams, kDefaultDualMinTokens));
     if (parts_small(e, B, L, 1) == small_f) return BatchPlan{1, small_f};
   }
+#endif
 #ifdef ED_DEBUG   // (A/B builds move the thresholds themselves: the plan is then whatever the switches say)
   const int np_dbg = parts_for(e, B, L, e->n_streams, e->dual_min_tokens);
   return BatchPlan{np_dbg, parts_small(e, B, L, np_dbg)};
@@ -430,7 +432,9 @@ struct SPart {   // one sub-batch of a strict forward: the engine's float32 work
 // left the chain by one sample; tests/test_gpu_strict.py::test_split_forward_with_frames_is_batch_independent).  The race was not
 // located in the time left; the inpainting path pays the two-stream gain (~5 %) for a float32-grade result that is one.
 static int strict_parts(const esmdiff_engine* e, int B, int L) {
+#ifndef ED_FRAMES_TWO_STREAMS
   if (e->has_geom && e->frames_B > 0) return 1;
+#endif
   return (e->split && !e->side.empty() && e->profiling != 1 && B >= 2 && (int64_t)B * L >= e->strict_dual_min_tokens) ? 2 : 1;
 }
 

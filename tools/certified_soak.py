@@ -137,7 +137,7 @@ for k in range(a.jobs):
         tot[key] += st[key]
     fr = st["flag_reasons"]
     say(seed, ok, ndiff, round(dt, 3), round(de, 3), st["flagged"], fr["race"], fr["nucleus"], fr["order"], st["corrections"], st["audit_checked"],
-        st["audit_mismatches"], st["eps_violations"], st["entropy_violations"], f"{2 * st['eps_max_used']:.3e}", f"{st.get('entropy_eps_max_used', 0) or 0:.3e}",
+        st["audit_mismatches"], st["eps_violations"], st["entropy_violations"], f"{2 * (st['eps_max_used'] or 0):.3e}", f"{st.get('entropy_eps_max_used', 0) or 0:.3e}",
         f"{st['max_range_err_observed']:.3e}", f"{st['max_entropy_err_observed']:.3e}", st["audit_rate_now"], st["sample_forwards_fast"],
         st["sample_forwards_direct"], st["direct_lane_switches"])
 n = max(tot["jobs"], 1)
