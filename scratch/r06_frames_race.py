@@ -17,7 +17,7 @@ ca = torch.cumsum(torch.nn.functional.normalize(torch.randn(L, 3, generator=g), 
 xyz = torch.stack([ca + torch.tensor([-1.2, 0.7, 0.0]), ca, ca + torch.tensor([1.3, 0.6, 0.1])], 1)
 xyz[97:161] = float("inf"); xyz[0] = xyz[-1] = float("nan")
 frames = tuple(f.cuda() for f in build_affine3d_from_coordinates(xyz[None].repeat(B, 1, 1, 1)))
-for prec in ("f32_split", "f16"):
+for prec in os.environ.get("PRECS", "f32_split,f16").split(","):
     eng = Engine(cfg, sd, max_batch=B, max_len=L, precision=prec)
     def diff(a, b):
         return torch.nonzero((a != b).flatten(1).any(1)).flatten().tolist()
