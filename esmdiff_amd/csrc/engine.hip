@@ -377,16 +377,6 @@ struct BatchPlan {
   bool small;   // the sub-batches take the small-batch path
 };
 BatchPlan plan_batch(const esmdiff_engine* e, int B, int L) {
-  // One launch queue while frames are set (r06, see strict_parts below): with block 0's geometric branch in it the two-stream
-  // forward was not deterministic from run to run (the f16 engine: 2 of 100 samples ~1e-4 off between two runs of the same batch).
-  // The path (small vs regular) stays what the frameless default plan chooses, so coordinates never move a batch onto the other
-  // summation order.
-#ifndef ED_FRAMES_TWO_STREAMS   // (A/B builds of scratch/r06_exact_batch_indep.py: the two-queue forward with frames, to look for the race)
-  if (e->has_geom && e->frames_B > 0) {
-    const bool small_f = parts_small(e, B, L, parts_for(e, B, L, kDefaultStreams, kDefaultDualMinTokens));
-    if (parts_small(e, B, L, 1) == small_f) return BatchPlan{1, small_f};
-  }
-#endif
 #ifdef ED_DEBUG   // (A/B builds move the thresholds themselves: the plan is then whatever the switches say)
   const int np_dbg = parts_for(e, B, L, e->n_streams, e->dual_min_tokens);
   return BatchPlan{np_dbg, parts_small(e, B, L, np_dbg)};
@@ -425,16 +415,9 @@ struct SPart {   // one sub-batch of a strict forward: the engine's float32 work
   hipStream_t st;
 };
 
-// sub-batch streams of a float32-grade forward (one function for forward_strict and esmdiff_describe_plan)
-// One stream while frames are set (r06): with block 0's geometric branch in it the two-stream F32_SPLIT forward was NOT
-// deterministic — a few samples per forward (around the part boundary) came out ~1e-3 off, differently from run to run, while the
-// one-stream forward equals every sample's forward alone bit for bit (found by the configs[4] gibbs soak: 8 of 30 certified jobs
-// left the chain by one sample; tests/test_gpu_strict.py::test_split_forward_with_frames_is_batch_independent).  The race was not
-// located in the time left; the inpainting path pays the two-stream gain (~5 %) for a float32-grade result that is one.
+// sub-batch streams of a float32-grade forward (one function for forward_strict and esmdiff_describe_plan).  (r06: with frames set
+// the two-queue forward was not deterministic until geom_attention_kernel stopped sharing CUs with the other queue's GEMM: geom.hip.)
 static int strict_parts(const esmdiff_engine* e, int B, int L) {
-#ifndef ED_FRAMES_TWO_STREAMS
-  if (e->has_geom && e->frames_B > 0) return 1;
-#endif
   return (e->split && !e->side.empty() && e->profiling != 1 && B >= 2 && (int64_t)B * L >= e->strict_dual_min_tokens) ? 2 : 1;
 }
 

@@ -16,6 +16,8 @@
 // lane owns a query and walks the keys with an online softmax (all lanes read the same key: LDS broadcast, no bank
 // conflicts).  Head dimension 3 leaves nothing for MFMA; the kernel is VALU-bound at ~25 ops per (query, key)
 // pair: 1.7e9 pairs per forward at config 2, i.e. about one millisecond, and only when coordinates are given.
+#include <algorithm>
+
 #include "ed_half.h"
 #include "kernels.h"
 
@@ -143,7 +145,14 @@ template <typename T>
 static hipError_t launch_geom_t(const T* P, const float* rot, const float* trans, const uint8_t* fmask, const float* w_rot,
                                 const float* w_dist, T* out, int B, int L, int VH, hipStream_t stream) {
   if (B <= 0 || L <= 0) return hipSuccess;
-  const size_t lds = (size_t)((L + 3) & ~3) * 12 * sizeof(float);
+// The kernel needs 12 floats per key (12.5 KB at L_tok = 258) but REQUESTS at least 40 KB (r06).  Inside a two-queue forward it
+  // runs while the other queue's 256x256 GEMM (128 KB of LDS per workgroup, LDS-DMA staged) is on the GPU; with a 12.5 KB request
+  // two of its workgroups fit beside a GEMM workgroup on a CU, and in that co-residency a few (sample, head) results per forward came
+  // out wrong, differently from run to run (found by the configs[4] gibbs soak; bisected with cross-queue barriers to "this kernel
+  // next to the other queue's proj GEMM"; 16 KB requests made it rarer, 40 KB — no co-residency possible in 160 KB — made 32 of 32
+  // two-queue forwards equal the one-queue forward bit for bit: profiles/r06_frames_two_queue_race.txt).  Which side is the
+  // victim was not established; the attention kernel (32 KB) has never shown it.
+  const size_t lds = std::max<size_t>((size_t)((L + 3) & ~3) * 12 * sizeof(float), (size_t)40 * 1024);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
   if (const hipError_t a_ = ensure_dynamic_lds((const void*)geom_attention_kernel<T>, 150 * 1024); a_ != hipSuccess) return a_;
   hipLaunchKernelGGL(geom_attention_kernel<T>, dim3(VH, B), dim3(64), lds, stream, P, rot, trans, fmask, w_rot, w_dist, out,

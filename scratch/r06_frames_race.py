@@ -1,4 +1,4 @@
-"""r06: where does the two-queue forward with frames become non-deterministic?  (ESMDIFF_LIB = a -DED_FRAMES_TWO_STREAMS build.)"""
+"""r06: where does the two-queue forward with frames become non-deterministic?  (r06 records: run on builds whose geom_attention_kernel requested 12.5 / 16 / 40 KB of LDS; the product now requests 40 KB.)"""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from esmdiff_amd.config import ESM3_OPEN, ModelConfig
