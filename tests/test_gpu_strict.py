@@ -1110,6 +1110,8 @@ def test_split_forward_with_frames_is_batch_independent():
             out = eng.forward_logits(x[idx], seq[idx], None).clone()
             eng.set_frames(None)
             return out
+        plain = [eng.forward_logits(x, seq, None).clone() for _ in range(3)]            # (without frames, for completeness)
+        assert torch.equal(plain[0], plain[1]) and torch.equal(plain[0], plain[2])
         full = fwd(torch.arange(B))
         assert "streams=2 " in eng.describe_plan(B, L), eng.describe_plan(B, L)          # the two-queue forward is what is under test
         rec[f"{prec}_rerun_differing_samples"] = 0
