@@ -27,7 +27,9 @@ UNITS = {
     "gemm_split": [],
     "attention_split": [],
     "strict": [],
-    "geom": [],
+    # no packed float ops in the geometric kernel: next to the other queue's GEMM they compute lanes 48-63 wrong (csrc/geom.hip,
+    # profiles/r06_frames_two_queue_race.txt); tests/test_host_cpu.py checks the code object
+    "geom": ["-fno-slp-vectorize", "-fno-vectorize"],
     "encoder": [],
     "attention": [],
     "norm": [],
@@ -79,8 +81,8 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     LIBDIR.mkdir(exist_ok=True)
     OBJDIR.mkdir(exist_ok=True)
     stamp = OBJDIR / "flags.txt"
-    flags = " ".join(COMMON)
-    if not stamp.exists() or stamp.read_text() != flags:   # different flags (e.g. -DED_GEMM_DEBUG): rebuild all
+    flags = " ".join(COMMON) + " | " + " ".join(f"{n}: {' '.join(f)}" for n, f in UNITS.items() if f)
+    if not stamp.exists() or stamp.read_text() != flags:   # different flags (e.g. -DED_GEMM_DEBUG, a unit's own flags): rebuild all
         force = True
     if LIB.exists() and not force and LIB.stat().st_mtime >= _newest_src():
         return LIB

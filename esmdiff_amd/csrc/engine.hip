@@ -416,7 +416,7 @@ struct SPart {   // one sub-batch of a strict forward: the engine's float32 work
 };
 
 // sub-batch streams of a float32-grade forward (one function for forward_strict and esmdiff_describe_plan).  (r06: with frames set
-// the two-queue forward was not deterministic until geom_attention_kernel stopped sharing CUs with the other queue's GEMM: geom.hip.)
+// the two-queue forward was not deterministic while geom_attention_kernel held packed float ops beside the other queue's GEMM: geom.hip.)
 static int strict_parts(const esmdiff_engine* e, int B, int L) {
   return (e->split && !e->side.empty() && e->profiling != 1 && B >= 2 && (int64_t)B * L >= e->strict_dual_min_tokens) ? 2 : 1;
 }

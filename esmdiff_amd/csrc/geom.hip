@@ -145,14 +145,22 @@ template <typename T>
 static hipError_t launch_geom_t(const T* P, const float* rot, const float* trans, const uint8_t* fmask, const float* w_rot,
                                 const float* w_dist, T* out, int B, int L, int VH, hipStream_t stream) {
   if (B <= 0 || L <= 0) return hipSuccess;
-// The kernel needs 12 floats per key (12.5 KB at L_tok = 258) but REQUESTS at least 40 KB (r06).  Inside a two-queue forward it
-  // runs while the other queue's 256x256 GEMM (128 KB of LDS per workgroup, LDS-DMA staged) is on the GPU; with a 12.5 KB request
-  // two of its workgroups fit beside a GEMM workgroup on a CU, and in that co-residency a few (sample, head) results per forward came
-  // out wrong, differently from run to run (found by the configs[4] gibbs soak; bisected with cross-queue barriers to "this kernel
-  // next to the other queue's proj GEMM"; 16 KB requests made it rarer, 40 KB — no co-residency possible in 160 KB — made 32 of 32
-  // two-queue forwards equal the one-queue forward bit for bit: profiles/r06_frames_two_queue_race.txt).  Which side is the
-  // victim was not established; the attention kernel (32 KB) has never shown it.
-  const size_t lds = std::max<size_t>((size_t)((L + 3) & ~3) * 12 * sizeof(float), (size_t)40 * 1024);
+  // This translation unit is compiled WITHOUT SLP vectorisation (esmdiff_amd/build.py: -fno-slp-vectorize -fno-vectorize), i.e. with
+  // no packed float ops (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32).  Inside a two-queue forward this kernel runs
+  // while the other queue's 256x256 GEMM is on the GPU, and with a 12.5 KB LDS request two of its one-wave workgroups fit beside
+  // a GEMM workgroup on a CU.  In that co-residency the SLP-vectorised build computed lanes 48-63 of the first query trip wrong in
+  // a few (sample, head) workgroups per forward, differently from run to run (r06: found by the configs[4] gibbs soak; bisected
+  // to this kernel next to the other queue's GEMM; reproduced outside the engine, at ISA level, and narrowed: the neighbour must
+  // execute MFMAs AND have LDS traffic, the victim must execute packed float ops on values that global loads just delivered;
+  // full s_waitcnt before every use does not help, 500 idle cycles behind every vmcnt wait do, and the build without packed ops
+  // was right in 40 of 40 rounds where the packed build was wrong in 37: profiles/r06_frames_two_queue_race.txt).  The first fix
+  // (r06) was a 40 KB LDS request, which keeps the kernel off the GEMM's CUs but also runs 3 instead of 12 workgroups per CU
+  // (2.95 ms instead of 1.72 ms at 50 x 258); the unpacked build at the size it needs takes 1.44 ms.
+  // ED_GEOM_MIN_LDS_KB: A/B builds only (scratch/r06_lds_neighbour.sh).
+#ifndef ED_GEOM_MIN_LDS_KB
+#define ED_GEOM_MIN_LDS_KB 0
+#endif
+  const size_t lds = std::max<size_t>((size_t)((L + 3) & ~3) * 12 * sizeof(float), (size_t)ED_GEOM_MIN_LDS_KB * 1024);
   if (lds > 150 * 1024) return hipErrorInvalidValue;
   if (const hipError_t a_ = ensure_dynamic_lds((const void*)geom_attention_kernel<T>, 150 * 1024); a_ != hipSuccess) return a_;
   hipLaunchKernelGGL(geom_attention_kernel<T>, dim3(VH, B), dim3(64), lds, stream, P, rot, trans, fmask, w_rot, w_dist, out,

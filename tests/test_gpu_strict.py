@@ -1077,8 +1077,8 @@ def test_certified_sampler_inpainting_prior_small_batches_and_streaming(streamed
 
 def test_split_forward_with_frames_is_batch_independent():
     """r06 (found by the configs[4] gibbs soak): with coordinate conditioning the two-queue forward gave a few samples per forward
-    logits ~1e-3 off, differently from run to run — geom_attention_kernel sharing CUs with the other queue's 256x256 GEMM
-    (csrc/geom.hip; profiles/r06_frames_two_queue_race.txt).  The certified sampler's referee must be a FUNCTION of the sample:
+    logits ~1e-3 off, differently from run to run — the packed float ops of geom_attention_kernel beside the other queue's 256x256 GEMM
+    (csrc/geom.hip is now compiled without them; profiles/r06_frames_two_queue_race.txt).  The certified sampler's referee must be a FUNCTION of the sample:
     at full size, with frames, a sample's F32_SPLIT logits are bitwise the same in the whole batch of 100 (two queues), in
     sub-batches (40 contiguous, 33 scattered, 64 reversed, the part boundary), alone, and in three more runs of the same batch.
     The 16-bit engines (batch-dependent by design: dispatch paths) must be deterministic from run to run."""

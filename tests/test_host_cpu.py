@@ -142,3 +142,36 @@ def test_hand_placed_gemm_has_no_sgpr_reload_hazard():
                     assert meta.get("sgpr_spill_count", 0) == 0, (name, meta)
             assert meta.get("agpr_count") == 256, (name, meta)      # the 128 x 128 wave tile lives in the accumulation registers
         assert seen == 10, seen            # 5 bf16/f16 epilogues + 4 SPLIT = 1 + the K-sliced SPLIT = 2 store kernel
+
+
+def test_geometric_kernel_ships_without_packed_float_ops():
+    """csrc/geom.hip is compiled without SLP vectorisation (esmdiff_amd/build.py): beside the other queue's 256x256 GEMM the
+    packed float ops (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32) of the vectorised build computed lanes 48-63
+    wrong (profiles/r06_frames_two_queue_race.txt).  The check disassembles the gfx950 code objects inside the SHIPPED library
+    (no GPU needed) and finds the four geom_attention_kernel instantiations — bf16 / f16 operands and float32 — free of them."""
+    import re
+    import subprocess
+    import tempfile
+    from esmdiff_amd import _native as N
+    llvm = Path("/opt/rocm/lib/llvm/bin")
+    if not (llvm / "clang-offload-bundler").exists() or not (llvm / "llvm-objdump").exists():
+        pytest.skip("no ROCm LLVM tools")
+    with tempfile.TemporaryDirectory() as td:
+        fat = Path(td) / "fat.bin"
+        subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", str(N.lib_path()), str(fat)], check=True)
+        blob = fat.read_bytes()
+        starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob)]
+        assert starts, "no offload bundles in the library"
+        seen = 0
+        for n, i in enumerate(starts):
+            j = starts[n + 1] if n + 1 < len(starts) else len(blob)
+            bundle, co = Path(td) / f"b{n}.bundle", Path(td) / f"b{n}.co"
+            bundle.write_bytes(blob[i:j])
+            subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                            f"--input={bundle}", f"--output={co}"], check=True, capture_output=True)
+            text = subprocess.run([str(llvm / "llvm-objdump"), "-d", str(co)], capture_output=True, text=True, check=True).stdout
+            for name, body in re.findall(r"^[0-9a-f]+ <([^>]*geom_attention_kernel[^>]*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", text, re.S | re.M):
+                packed = re.findall(r"\bv_pk_\w+", body)
+                assert not packed, (name, sorted(set(packed)))
+                seen += 1
+        assert seen == 4, seen
