@@ -59,3 +59,19 @@ for tag, code in probes.items():
     tmp.write_text(text.replace(old, "    float r0 = 0.f, r1 = 0.f, r2 = 0.f;\n    if (den > 0.f) { " + code + " den = 0.f; }\n    if (den > 0.f) {"))
     build(tag, asm_of(tmp))
 tmp.unlink()
+# i11 / i12: the float32 kernel's register allocation padded to 104 (still fits beside a 408-register GEMM wave on a SIMD) / 128 (does not)
+for tag, n in (("i11", 104), ("i12", 128)):
+    t, k = re.subn(r"(\.amdhsa_next_free_vgpr) 60(\n[^\n]*\n\s*\.amdhsa_accum_offset) 60", rf"\1 {n}\2 {n}", base)
+    assert k == 1
+    build(tag, t.replace(".vgpr_count:     60", f".vgpr_count:     {n}"))
+# e1: d1 (stores q_rot) without the key walk; e2: also without the key fill (no LDS access at all)
+walk_old = "    if (fmask[row]) {  // rows without a frame are zeroed below; skip their walk"
+assert walk_old in text
+e1 = text.replace(walk_old, "    if (false) {").replace(old, "    float r0 = qr[0] + 0.f * qd[0], r1 = qr[1] + 0.f * qd[1], r2 = qr[2] + 0.f * qd[2];\n    den = 0.f;\n    if (den > 0.f) {")
+tmp.write_text(e1)
+build("e1", asm_of(tmp))
+fill_old = "  for (int l = lane; l < L; l += 64) {\n    const int64_t row = row0 + l;\n    float R[9], t[3], v[3], o[3];"
+assert fill_old in e1
+tmp.write_text(e1.replace(fill_old, "  for (int l = lane; l < 0; l += 64) {\n    const int64_t row = row0 + l;\n    float R[9], t[3], v[3], o[3];"))
+build("e2", asm_of(tmp))
+tmp.unlink()

@@ -2,6 +2,8 @@
 // halves with ONE packed float op and with two plain float ops, and compares the results bit for bit — `reps` times at different
 // addresses.  err[q] counts mismatches of lane quarter q, err[4 + trip range] when they happened.
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC scratch/ubench/pk_minimal.hip -o scratch/ubench/pk_minimal.so
+// (registers v40..v51: with v100.. the kernel allocates 112 registers and can NOT share a SIMD with a 408-register GEMM wave — the first
+// version of this probe could never fail)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -16,19 +18,19 @@ __global__ __launch_bounds__(64) void pkmin_kernel(const float4* __restrict__ G,
     const float4* p = G + idx;
     uint32_t a0, a1, b0, b1;
     asm volatile(
-        "global_load_dwordx4 v[100:103], %4, off\n\t"
+        "global_load_dwordx4 v[40:43], %4, off\n\t"
         "s_waitcnt vmcnt(0)\n\t"
-        "v_pk_mul_f32 v[104:105], v[100:101], v[102:103]\n\t"
-        "v_mul_f32 v106, v100, v102\n\t"
-        "v_mul_f32 v107, v101, v103\n\t"
+        "v_pk_mul_f32 v[44:45], v[40:41], v[42:43]\n\t"
+        "v_mul_f32 v46, v40, v42\n\t"
+        "v_mul_f32 v47, v41, v43\n\t"
         "s_nop 4\n\t"
-        "v_mov_b32 %0, v104\n\t"
-        "v_mov_b32 %1, v105\n\t"
-        "v_mov_b32 %2, v106\n\t"
-        "v_mov_b32 %3, v107\n\t"
+        "v_mov_b32 %0, v44\n\t"
+        "v_mov_b32 %1, v45\n\t"
+        "v_mov_b32 %2, v46\n\t"
+        "v_mov_b32 %3, v47\n\t"
         : "=v"(a0), "=v"(a1), "=v"(b0), "=v"(b1)
         : "v"(p)
-        : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "memory");
+        : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "memory");
     if (a0 != b0 || a1 != b1) {
       ++bad;
       if (first_rep == 0xffffffffu) first_rep = r;

@@ -144,11 +144,14 @@ def test_hand_placed_gemm_has_no_sgpr_reload_hazard():
         assert seen == 10, seen            # 5 bf16/f16 epilogues + 4 SPLIT = 1 + the K-sliced SPLIT = 2 store kernel
 
 
-def test_geometric_kernel_ships_without_packed_float_ops():
-    """csrc/geom.hip is compiled without SLP vectorisation (esmdiff_amd/build.py): beside the other queue's 256x256 GEMM the
-    packed float ops (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 / v_pk_mov_b32) of the vectorised build computed lanes 48-63
-    wrong (profiles/r06_frames_two_queue_race.txt).  The check disassembles the gfx950 code objects inside the SHIPPED library
-    (no GPU needed) and finds the four geom_attention_kernel instantiations — bf16 / f16 operands and float32 — free of them."""
+def test_no_kernel_ships_the_packed_float_form_that_fails_beside_the_gemm():
+    """r06 (profiles/r06_frames_two_queue_race.txt, third pass): v_pk_fma_f32 / v_pk_mul_f32 whose op_sel takes the LOW result half from
+    the HIGH register of src1 (op_sel:[.,1,.]) compute that half without the product — fma returns C.lo, mul returns +-0 — in lanes
+    48-63 whenever a wave of the product's 256x256 GEMM shares the SIMD (scratch/ubench/pk_opsel.hip: a 30-line self-checking kernel,
+    every round).  hipcc's SLP vectoriser emits that form for 3x3 rotations; block 0's geometric kernel had it, ran beside the other
+    queue's GEMM in the two-queue forward, and gave a few wrong (row, head) outputs per forward.  csrc/geom.hip is therefore compiled
+    without SLP vectorisation (esmdiff_amd/build.py), and this check disassembles EVERY gfx950 code object inside the shipped
+    library (no GPU needed): no kernel may hold the form, and the four geom_attention_kernel instantiations hold no packed float op."""
     import re
     import subprocess
     import tempfile
@@ -162,7 +165,7 @@ def test_geometric_kernel_ships_without_packed_float_ops():
         blob = fat.read_bytes()
         starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", blob)]
         assert starts, "no offload bundles in the library"
-        seen = 0
+        geom_seen = kernels = packed_total = 0
         for n, i in enumerate(starts):
             j = starts[n + 1] if n + 1 < len(starts) else len(blob)
             bundle, co = Path(td) / f"b{n}.bundle", Path(td) / f"b{n}.co"
@@ -170,8 +173,17 @@ def test_geometric_kernel_ships_without_packed_float_ops():
             subprocess.run([str(llvm / "clang-offload-bundler"), "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
                             f"--input={bundle}", f"--output={co}"], check=True, capture_output=True)
             text = subprocess.run([str(llvm / "llvm-objdump"), "-d", str(co)], capture_output=True, text=True, check=True).stdout
-            for name, body in re.findall(r"^[0-9a-f]+ <([^>]*geom_attention_kernel[^>]*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", text, re.S | re.M):
-                packed = re.findall(r"\bv_pk_\w+", body)
-                assert not packed, (name, sorted(set(packed)))
-                seen += 1
-        assert seen == 4, seen
+            for name, body in re.findall(r"^[0-9a-f]+ <([^>]+)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", text, re.S | re.M):
+                kernels += 1
+                for ins in re.findall(r"\bv_pk_(?:fma|mul)_f32[^\n]*", body):
+                    packed_total += 1
+                    sel = re.search(r"\bop_sel:\[([01,]+)\]", ins)
+                    if sel:
+                        bits = [int(b) for b in sel.group(1).split(",")]
+                        assert not (len(bits) > 1 and bits[1]), (name, ins.split("//")[0].strip())
+                if "geom_attention_kernel" in name:
+                    packed = re.findall(r"\bv_pk_\w+", body)
+                    assert not packed, (name, sorted(set(packed)))
+                    geom_seen += 1
+        assert geom_seen == 4, geom_seen
+        assert kernels > 200 and packed_total > 1000, (kernels, packed_total)     # the scan saw the library (and its packed ops)
