@@ -27,8 +27,9 @@ UNITS = {
     "gemm_split": [],
     "attention_split": [],
     "strict": [],
-    # no packed float ops in the geometric kernel: next to the other queue's GEMM they compute lanes 48-63 wrong (csrc/geom.hip,
-    # profiles/r06_frames_two_queue_race.txt); tests/test_host_cpu.py checks the code object
+    # no packed float ops in the geometric kernel: v_pk_fma_f32 / v_pk_mul_f32 with op_sel[1] = 1 (the SLP form of its 3x3 rotations)
+    # compute lanes 48-63 wrong next to the other queue's GEMM (csrc/geom.hip, profiles/r06_frames_two_queue_race.txt);
+    # tests/test_host_cpu.py scans every code object of the shipped library for that form
     "geom": ["-fno-slp-vectorize", "-fno-vectorize"],
     "encoder": [],
     "attention": [],

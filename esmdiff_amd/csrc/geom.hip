@@ -150,10 +150,12 @@ static hipError_t launch_geom_t(const T* P, const float* rot, const float* trans
   // while the other queue's 256x256 GEMM is on the GPU, and with a 12.5 KB LDS request two of its one-wave workgroups fit beside
   // a GEMM workgroup on a CU.  In that co-residency the SLP-vectorised build computed lanes 48-63 of the first query trip wrong in
   // a few (sample, head) workgroups per forward, differently from run to run (r06: found by the configs[4] gibbs soak; bisected
-  // to this kernel next to the other queue's GEMM; reproduced outside the engine, at ISA level, and narrowed: the neighbour must
-  // execute MFMAs AND have LDS traffic, the victim must execute packed float ops on values that global loads just delivered;
-  // full s_waitcnt before every use does not help, 500 idle cycles behind every vmcnt wait do, and the build without packed ops
-  // was right in 40 of 40 rounds where the packed build was wrong in 37: profiles/r06_frames_two_queue_race.txt).  The first fix
+  // to this kernel next to the other queue's GEMM; reproduced outside the engine and reduced to one instruction form: v_pk_fma_f32 /
+  // v_pk_mul_f32 whose op_sel takes the LOW result half from the HIGH register of src1 — the SLP vectoriser's form of the 3x3
+  // rotations above — lose that half's product in lanes 48-63 whenever a wave sharing the SIMD issues memory instructions between
+  // back-to-back MFMAs, as every pipelined GEMM does; a 30-line self-checking reproducer needs none of our kernels
+  // (scratch/ubench/pk_opsel.hip beside scratch/ubench/mfma_neighbour.hip; profiles/r06_frames_two_queue_race.txt, third pass).
+  // The build without packed ops was right in 40 of 40 rounds where the packed build was wrong in 37.  The first fix
   // (r06) was a 40 KB LDS request, which keeps the kernel off the GEMM's CUs but also runs 3 instead of 12 workgroups per CU
   // (2.95 ms instead of 1.72 ms at 50 x 258); the unpacked build at the size it needs takes 1.44 ms.
   // ED_GEOM_MIN_LDS_KB: A/B builds only (scratch/r06_lds_neighbour.sh).
