@@ -175,12 +175,16 @@ def test_no_kernel_ships_the_packed_float_form_that_fails_beside_the_gemm():
             text = subprocess.run([str(llvm / "llvm-objdump"), "-d", str(co)], capture_output=True, text=True, check=True).stdout
             for name, body in re.findall(r"^[0-9a-f]+ <([^>]+)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", text, re.S | re.M):
                 kernels += 1
-                for ins in re.findall(r"\bv_pk_(?:fma|mul)_f32[^\n]*", body):
+                for op, rest in re.findall(r"\b(v_pk_\w+|v_dot\w+)\b([^\n]*)", body):
                     packed_total += 1
-                    sel = re.search(r"\bop_sel:\[([01,]+)\]", ins)
+                    sel = re.search(r"\bop_sel:\[([01,]+)\]", rest)
                     if sel:
                         bits = [int(b) for b in sel.group(1).split(",")]
-                        assert not (len(bits) > 1 and bits[1]), (name, ins.split("//")[0].strip())
+                        # measured safe beside the GEMM with src1's HIGH register in the low half: v_pk_add_f32 (the LayerNorm kernels'
+                        # horizontal add; 10 of 10 clean rounds where the fma / mul forms fail in every one).  Every other packed op
+                        # with that op_sel is either known to fail (v_pk_fma_f32, v_pk_mul_f32) or untested: measure it with
+                        # scratch/ubench/pk_opsel.hip before shipping it
+                        assert not (len(bits) > 1 and bits[1]) or op == "v_pk_add_f32", (name, op + rest.split("//")[0].rstrip())
                 if "geom_attention_kernel" in name:
                     packed = re.findall(r"\bv_pk_\w+", body)
                     assert not packed, (name, sorted(set(packed)))
