@@ -1130,6 +1130,50 @@ def test_split_forward_with_frames_is_batch_independent():
     _record("split_forward_with_frames_batch_independence", rec)
 
 
+def test_two_queue_forward_with_frames_equals_the_one_queue_forward_in_every_engine():
+    """r06: every kernel of block 0's geometric branch runs beside the OTHER queue's 256x256 GEMM in a two-queue forward; on this hardware
+    a co-resident wave's v_pk_fma_f32 / v_pk_mul_f32 with op_sel[1] = 1 then lose a product in lanes 48-63 (profiles/
+    r06_frames_two_queue_race.txt) — the geometric kernel is compiled without that form.  Two blocks of the production width (the branch
+    lives in block 0), configs[1]'s batch, frames on all but the inpainted window: eight two-queue forwards must equal the one-queue
+    forward (profiling mode 1) bit for bit in the bf16, f16 and F32_SPLIT engines.  (Checked against an A/B library whose geom.hip WAS
+    SLP-vectorised — scratch/build_variant.py geom geompk -fslp-vectorize -fvectorize — where this test fails.)"""
+    from esmdiff_amd.config import ModelConfig
+    from esmdiff_amd.engine import Engine
+    from esmdiff_amd.geometry import build_affine3d_from_coordinates
+    from esmdiff_amd.weights import random_init_state_dict
+    cfg = ModelConfig(n_layers=2)
+    sd = random_init_state_dict(cfg, seed=11, device="cuda", with_geom=True)
+    B, L = 100, 258
+    g = torch.Generator().manual_seed(1)
+    seq = _seq(B, L, g).cuda()
+    x = torch.randint(0, 4096, (B, L), generator=g)
+    x[:, 0], x[:, -1] = 4098, 4097
+    x[:, 97:161] = MASK
+    x = x.cuda()
+    ca = torch.cumsum(torch.nn.functional.normalize(torch.randn(L, 3, generator=g), dim=-1) * 3.8, 0)
+    xyz = torch.stack([ca + torch.tensor([-1.2, 0.7, 0.0]), ca, ca + torch.tensor([1.3, 0.6, 0.1])], 1)
+    xyz[97:161] = float("inf")
+    xyz[0] = xyz[-1] = float("nan")
+    frames = build_affine3d_from_coordinates(xyz[None].repeat(B, 1, 1, 1))
+    rec = {}
+    for prec in ("bf16", "f16", "f32_split"):
+        eng = Engine(cfg, sd, max_batch=B, max_len=L, precision=prec)
+        eng.set_frames(*frames)
+        assert "streams=2 " in eng.describe_plan(B, L), eng.describe_plan(B, L)
+        eng.set_profiling(1)
+        ref = eng.forward_logits(x, seq, None).clone()
+        eng.set_profiling(0)
+        bad = 0
+        for _ in range(8):
+            out = eng.forward_logits(x, seq, None)
+            bad += int((out != ref).flatten(1).any(1).sum())
+        rec[f"{prec}_differing_samples_in_8_forwards"] = bad
+        eng.set_frames(None)
+        eng.close()
+    _record("two_queue_with_frames_vs_one_queue", rec)
+    assert not any(rec.values()), rec
+
+
 @pytest.mark.parametrize("streamed", [False, True])
 def test_certified_gibbs_tiny_with_coordinates_ragged_and_streaming(streamed):
     """CertifiedSampler.gibbs_sample on the real engines (TINY model, the reference's default mode, sample_esmdiff.py:66-130):
