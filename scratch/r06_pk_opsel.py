@@ -31,7 +31,7 @@ def aggress():
     else:     # synth1 MFMA only, synth2 MFMA + ds_read_b128 (the GEMM's k-step), synth3 ds_read_b128 only, synth0 registers held: scratch/ubench/mfma_neighbour.hip
         assert nbl.nb_launch(int(AGGRESSOR[5:]), 1200, 128 * 1024, 256, sink.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-FORMS = ["fma op_sel:[0,1,0] op_sel_hi:[1,0,1]", "fma plain", "fma op_sel_hi:[1,0,1]", "mul op_sel:[0,1] op_sel_hi:[1,0]", "add A,A op_sel:[0,1] op_sel_hi:[1,0]", "fma op_sel:[1,0,0]", "fma op_sel:[0,0,1]", "fma op_sel:[0,1,0]", "mul s[..],B op_sel:[1,0]"]
+FORMS = ["fma op_sel:[0,1,0] op_sel_hi:[1,0,1]", "fma plain", "fma op_sel_hi:[1,0,1]", "mul op_sel:[0,1] op_sel_hi:[1,0]", "add A,A op_sel:[0,1] op_sel_hi:[1,0]", "fma op_sel:[1,0,0]", "fma op_sel:[0,0,1]", "fma op_sel:[0,1,0]", "mul s[..],B op_sel:[1,0]", "fma_f16 op_sel:[0,1,0] op_sel_hi:[1,0,1]", "mul_f16 op_sel:[0,1] op_sel_hi:[1,0]", "add_f16 op_sel:[0,1] op_sel_hi:[1,0]"]
 for mode in [int(m) for m in os.environ.get("MODES", "0,1,2,3,4,5,6,7,8").split(",")]:
     def launch(err, stream):
         assert lib.opsel_launch(mode, G.data_ptr(), G.numel() // 8, B, VH, REPS, LDS, err.data_ptr(), stream) == 0

@@ -10,6 +10,8 @@
 //   6  v_pk_fma_f32 D, A, B, C op_sel:[0,0,1]                       lo = A.lo * B.lo + C.hi
 //   7  v_pk_fma_f32 D, A, B, C op_sel:[0,1,0]                       lo = A.lo * B.hi + C.lo, hi half plain
 //   8  v_pk_mul_f32 D, s[..], B op_sel:[1,0]                        a scalar pair as src0, its high half in the lo result (the product's only op_sel forms)
+//   9 / 10 / 11  v_pk_fma_f16 / v_pk_mul_f16 / v_pk_add_f16 with op_sel:[0,1(,0)] op_sel_hi:[1,0(,1)] (16-bit halves of ONE register swapped)
+//      against the plain packed op on a copy of B whose halves were swapped with v_alignbit_b32 (inputs masked to finite f16 values)
 // err[q] mismatching (lane, rep) of lane quarter q; err[4] lo-half mismatches, err[5] hi-half mismatches; err[6] lo == C.lo exactly
 //   hipcc --offload-arch=gfx950 -O3 -shared -fPIC scratch/ubench/pk_opsel.hip -o scratch/ubench/pk_opsel.so
 // (registers v40..v51: with v100.. the kernel allocates 112 registers and can NOT share a SIMD with a 408-register GEMM wave — the first
@@ -68,7 +70,22 @@ __global__ __launch_bounds__(64) void opsel_kernel(const float4* __restrict__ G,
       asm volatile(LOADS "v_pk_fma_f32 v[48:49], v[40:41], v[42:43], v[44:45] op_sel:[0,1,0]\n\t"
                          "v_fma_f32 v50, v40, v43, v44\n\tv_fma_f32 v51, v41, v43, v45\n\t" OUTS
                    : "=v"(a0), "=v"(a1), "=v"(b0), "=v"(b1) : "v"(p) : CLOB);
-    else if (MODE == 8)
+    else if (MODE >= 9 && MODE <= 11) {
+      // a0 / b0: the op_sel form / the plain form on swapped B; a1 = b1 = 0
+#define F16PREP "v_and_b32 v40, 0x3bff3bff, v40\n\tv_and_b32 v42, 0x3bff3bff, v42\n\tv_and_b32 v44, 0x3bff3bff, v44\n\tv_alignbit_b32 v46, v42, v42, 16\n\t"
+      if (MODE == 9)
+        asm volatile(LOADS F16PREP "v_pk_fma_f16 v48, v40, v42, v44 op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\tv_pk_fma_f16 v50, v40, v46, v44\n\t"
+                           "v_mov_b32 v49, 0\n\tv_mov_b32 v51, 0\n\t" OUTS
+                     : "=v"(a0), "=v"(a1), "=v"(b0), "=v"(b1) : "v"(p) : CLOB);
+      else if (MODE == 10)
+        asm volatile(LOADS F16PREP "v_pk_mul_f16 v48, v40, v42 op_sel:[0,1] op_sel_hi:[1,0]\n\tv_pk_mul_f16 v50, v40, v46\n\t"
+                           "v_mov_b32 v49, 0\n\tv_mov_b32 v51, 0\n\t" OUTS
+                     : "=v"(a0), "=v"(a1), "=v"(b0), "=v"(b1) : "v"(p) : CLOB);
+      else
+        asm volatile(LOADS F16PREP "v_pk_add_f16 v48, v40, v42 op_sel:[0,1] op_sel_hi:[1,0]\n\tv_pk_add_f16 v50, v40, v46\n\t"
+                           "v_mov_b32 v49, 0\n\tv_mov_b32 v51, 0\n\t" OUTS
+                     : "=v"(a0), "=v"(a1), "=v"(b0), "=v"(b1) : "v"(p) : CLOB);
+    } else if (MODE == 8)
       asm volatile(LOADS "v_readfirstlane_b32 s20, v40\n\tv_readfirstlane_b32 s21, v41\n\ts_nop 4\n\t"
                          "v_pk_mul_f32 v[48:49], s[20:21], v[42:43] op_sel:[1,0]\n\t"
                          "v_mul_f32 v50, s21, v42\n\tv_mul_f32 v51, s21, v43\n\t" OUTS
@@ -105,6 +122,9 @@ extern "C" int opsel_launch(int mode, const void* G, uint32_t n8, int B, int VH,
     case 6: GO(6); break;
     case 7: GO(7); break;
     case 8: GO(8); break;
+    case 9: GO(9); break;
+    case 10: GO(10); break;
+    case 11: GO(11); break;
     default: GO(5); break;
   }
   return (int)hipGetLastError();
